@@ -1,0 +1,156 @@
+"""ctypes binding of libgrl_hip.so (the C ABI declared in include/grl_hip.h).
+
+There is deliberately NO fallback: if the shared library is missing or stale, or a kernel
+returns an error, a RuntimeError is raised.  Build it with ``python __graft_entry__.py`` (or
+``make -C grl_image_restoration_amd/csrc``).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
+ABI_VERSION = 1
+
+EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
+
+# every symbol include/grl_hip.h declares (tests check the .so exports all of them)
+EXPORTS = [
+    "grl_linear_fwd",
+    "grl_attention_fwd",
+    "grl_layernorm_fwd",
+    "grl_abi_version",
+    "grl_build_info",
+]
+
+
+class GrlLinearArgs(C.Structure):
+    _fields_ = [
+        ("a", C.c_void_p),
+        ("a_is_bf16", C.c_int32),
+        ("lda", C.c_int64),
+        ("pool_df", C.c_int32),
+        ("pool_H", C.c_int32),
+        ("pool_W", C.c_int32),
+        ("w", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("M", C.c_int32),
+        ("Npad", C.c_int32),
+        ("Kpad", C.c_int32),
+        ("epi", C.c_int32),
+        ("gscale", C.c_void_p),
+        ("ln_g", C.c_void_p),
+        ("ln_b", C.c_void_p),
+        ("n_real", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("res_scale", C.c_float),
+        ("resid", C.c_void_p),
+        ("ldr", C.c_int64),
+        ("add2", C.c_void_p),
+        ("add2_is_bf16", C.c_int32),
+        ("ldadd2", C.c_int64),
+        ("out", C.c_void_p),
+        ("out_is_bf16", C.c_int32),
+        ("ldo", C.c_int64),
+    ]
+
+
+class GrlTokenGrid(C.Structure):
+    _fields_ = [
+        ("ptr", C.c_void_p),
+        ("ld", C.c_int64),
+        ("col0", C.c_int32),
+        ("Himg", C.c_int32),
+        ("Wimg", C.c_int32),
+        ("wh", C.c_int32),
+        ("ww", C.c_int32),
+        ("shy", C.c_int32),
+        ("shx", C.c_int32),
+    ]
+
+
+class GrlAttnArgs(C.Structure):
+    _fields_ = [
+        ("q", GrlTokenGrid),
+        ("k", GrlTokenGrid),
+        ("v", GrlTokenGrid),
+        ("o", GrlTokenGrid),
+        ("B", C.c_int32),
+        ("nh", C.c_int32),
+        ("nwy", C.c_int32),
+        ("nwx", C.c_int32),
+        ("table", C.c_void_p),
+        ("trows", C.c_int32),
+        ("masked", C.c_int32),
+        ("fixed_max", C.c_int32),
+        ("ones_col", C.c_int32),
+        ("head_dim", C.c_int32),
+    ]
+
+
+class GrlConvArgs(C.Structure):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("x_is_bf16", C.c_int32),
+        ("ldx", C.c_int64),
+        ("w", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("Cin_pad", C.c_int32),
+        ("Cout_pad", C.c_int32),
+        ("act", C.c_int32),
+        ("resid", C.c_void_p),
+        ("ldr", C.c_int64),
+        ("pool", C.c_void_p),
+        ("out", C.c_void_p),
+        ("out_is_bf16", C.c_int32),
+        ("ldo", C.c_int64),
+    ]
+
+
+_lib = None
+
+
+def lib():
+    """Loads the library once; raises if it is missing or built against another ABI."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the GRL HIP extension is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repo root. "
+            "There is no CPU/PyTorch fallback for the hot path."
+        )
+    L = C.CDLL(LIB_PATH)
+    L.grl_abi_version.restype = C.c_int
+    if L.grl_abi_version() != ABI_VERSION:
+        raise RuntimeError(f"stale {LIB_PATH}: ABI {L.grl_abi_version()} != {ABI_VERSION}; rebuild")
+    L.grl_build_info.restype = C.c_char_p
+    L.grl_linear_fwd.argtypes = [C.c_void_p, C.POINTER(GrlLinearArgs)]
+    L.grl_linear_fwd.restype = C.c_int
+    L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
+    L.grl_attention_fwd.restype = C.c_int
+    L.grl_layernorm_fwd.argtypes = [
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_int32, C.c_int32, C.c_int32, C.c_float,
+    ]
+    L.grl_layernorm_fwd.restype = C.c_int
+    if hasattr(L, "grl_conv3x3_fwd"):
+        L.grl_conv3x3_fwd.argtypes = [C.c_void_p, C.POINTER(GrlConvArgs)]
+        L.grl_conv3x3_fwd.restype = C.c_int
+    _lib = L
+    return L
+
+
+def check(code: int, what: str):
+    if code != 0:
+        kind = {-1: "bad argument", -2: "unsupported shape"}.get(code, f"hipError {code}")
+        raise RuntimeError(f"libgrl_hip: {what} failed: {kind}")
+
+
+def stream_ptr():
+    import torch
+
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,309 @@
+// Cosine window / anchored-stripe attention for GRL on gfx950 (MI355X).
+//
+// One kernel serves the three attentions of a GRL block:
+//   window   : q,k,v = window tokens                 (mixed_attn_block_efficient.py:128-165)
+//   a2w      : q = anchors,  k,v = stripe tokens     (:256-258)
+//   w2a      : q = stripe tokens, k = anchors, v = a2w output   (:259)
+// Roll, window/stripe partition + reverse, head split, relative-position index and the shifted
+// window masks of the reference (ops.py:36-157,352-375) never touch memory here: they are index
+// arithmetic on the token grids described by GrlTokenGrid.
+//
+// Formulation (flash-style, nothing of size Nq x Nk is materialised):
+//   S^T tile (32 keys x 32 queries) = mfma_32x32x16_bf16(K_tile, Q_tile), accumulator
+//   *initialised with the relative-position bias* gathered from an LDS table, so that
+//   S^T = log2e * (scale * cos(q,k) + bias [- bound]) comes straight out of the matrix core
+//   (scale*log2e is folded into q by the QKV epilogue).  P = exp2(S^T) is packed to bf16 in
+//   registers in exactly the order the PV product wants its B operand (a permutation of the
+//   key index inside a tile, mirrored when V^T fragments are read), and O^T += V^T P^T runs on
+//   the matrix core again.  With `ones_col`, the softmax denominator is row `ones_col` of O^T.
+//   fixed_max=1 uses the per-head bound scale+max(bias) instead of a running maximum (valid
+//   because |cos| <= 1); fixed_max=0 is ordinary online softmax.
+//
+// Work decomposition: one workgroup = (window, head, block of up to 256 queries); each wave
+// owns 2 query tiles (64 queries) whose Q fragments and O^T accumulators stay in registers;
+// K (XOR-swizzled rows) and V^T chunks of 256 keys are staged in LDS and shared by the waves.
+#include "common.h"
+#include "grl_hip_internal.h"
+
+namespace {
+
+constexpr int QT = 2;            // query tiles per wave
+constexpr int KC = 256;          // keys per LDS chunk
+constexpr int VROW = KC * 2 + 8; // V^T row stride in bytes (pad: conflict-free ds_read_b64)
+constexpr float MASK_L2 = -100.0f * LOG2E_F;
+constexpr float NEG_BIG = -1.0e30f;
+
+struct GridGeo {
+    int Himg, Wimg, wh, ww, shy, shx;
+};
+
+__device__ __forceinline__ int region1d(int p, int n, int s, int sh) {
+    // ops.py:76-100: labels 0 | 1 | 2 split at n-s and n-sh; a zero shift labels the whole axis alike
+    if (sh == 0) return 0;
+    return p < n - s ? 0 : (p < n - sh ? 1 : 2);
+}
+
+// token n of window (wy,wx) of image b -> (row index in the token matrix, region id)
+__device__ __forceinline__ void locate(const GrlTokenGrid& g, int b, int wy, int wx, int n, int64_t& row, int& rid) {
+    const int hq = n / g.ww, wq = n - hq * g.ww;
+    const int ry = wy * g.wh + hq, rx = wx * g.ww + wq;
+    int oy = ry + g.shy; if (oy >= g.Himg) oy -= g.Himg;
+    int ox = rx + g.shx; if (ox >= g.Wimg) ox -= g.Wimg;
+    row = ((int64_t)b * g.Himg + oy) * g.Wimg + ox;
+    rid = 3 * region1d(ry, g.Himg, g.wh, g.shy) + region1d(rx, g.Wimg, g.ww, g.shx);
+}
+
+template <bool FIXED, bool ONES, bool KW4>
+__global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
+    const int qblk = (nthreads >> 6) * (QT * 32);
+    const int nqs = (Nq + qblk - 1) / qblk;
+    int bid = blockIdx.x;
+    const int qs = bid % nqs; bid /= nqs;
+    const int head = bid % p.nh; bid /= p.nh;
+    const int wx = bid % p.nwx; bid /= p.nwx;
+    const int wy = bid % p.nwy;
+    const int b = bid / p.nwy;
+    const int D = p.q.ww + p.k.ww - 1;
+
+    // ---- LDS carve ----
+    float* tab = (float*)smem;                                   // trows
+    char* Ks = smem + (((size_t)p.trows * 4 + 15) & ~(size_t)15); // KC x 64 B
+    char* Vt = Ks + KC * 64;                                     // 32 x VROW
+    int* koff = (int*)(Vt + 32 * VROW);                          // KC
+    unsigned char* kreg = (unsigned char*)(koff + KC);           // KC
+
+    for (int i = tid; i < p.trows; i += nthreads) tab[i] = p.table[(int64_t)head * p.trows + i];
+
+    // does this window need the mask path at all?  (window touches the wrapped border, or ragged keys)
+    const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+    const bool need_mask = border || (Nk & 31) != 0;
+
+    // ---- per-lane query state ----
+    int U[QT], idq[QT];
+    int64_t qrow[QT];
+    bool qvalid[QT];
+    bf16x8 qf[QT][2];
+    f32x16 O[QT];
+    float mrun[QT], lrun[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int n = qs * qblk + wave * (QT * 32) + t * 32 + l31;
+        qvalid[t] = n < Nq;
+        if (!qvalid[t]) n = Nq - 1;
+        locate(p.q, b, wy, wx, n, qrow[t], idq[t]);
+        const int hq = n / p.q.ww, wq = n - hq * p.q.ww;
+        U[t] = hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1);
+        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * 32 + 8 * half;
+        qf[t][0] = *(const bf16x8*)(src);
+        qf[t][1] = *(const bf16x8*)(src + 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+        mrun[t] = NEG_BIG;
+        lrun[t] = 0.f;
+    }
+
+    const int nchunks = (Nk + KC - 1) / KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * KC;
+        const int klen = min(KC, Nk - k0);
+        const int ntiles = (klen + 31) >> 5;
+        __syncthreads();
+        // ---- stage K rows (swizzled 16-B slots) and V^T; per-key table offset + region id ----
+        for (int i = tid; i < ntiles * 32 * 4; i += nthreads) {
+            const int kk = i >> 2, seg = i & 3;
+            const int n = k0 + kk;
+            const bool valid = n < Nk;
+            int64_t row; int rid;
+            locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
+            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (valid) {
+                kv = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
+                vv = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
+            }
+            *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
+            if (seg == 0) {
+                const int nn = valid ? n : 0;
+                const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
+                koff[kk] = hk * D + wk;
+                kreg[kk] = valid ? (unsigned char)rid : (unsigned char)255;
+            }
+        }
+        __syncthreads();
+
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int kb = kt * 32;
+            // K fragments: A operand rows = keys kb + l31, k-slots = head dims 8*half (+16 for step 1)
+            bf16x8 kf[2];
+            {
+                const int kk = kb + l31;
+                const int sw = (kk >> 2) & 3;
+                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
+                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
+            }
+            // bias gather -> accumulator init
+            f32x16 S[QT];
+            if constexpr (KW4) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int v0 = koff[kb + 8 * g + 4 * half];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) {
+                        const float* tp = tab + (U[t] - v0);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) S[t][4 * g + e] = *(tp - e);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int v = koff[kb + mfma32_row(r, half)];
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) S[t][r] = tab[U[t] - v];
+                }
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], S[t], 0, 0, 0);
+                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S[t], 0, 0, 0);
+            }
+            if (need_mask) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const uint32_t ids = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int idk = (ids >> (8 * e)) & 255;
+#pragma unroll
+                        for (int t = 0; t < QT; ++t) {
+                            float s = S[t][4 * g + e];
+                            if (idk == 255) s = NEG_BIG;
+                            else if (border && idk != idq[t]) s += MASK_L2;
+                            S[t][4 * g + e] = s;
+                        }
+                    }
+                }
+            }
+            // softmax numerators, packed straight into the PV B-operand order
+            bf16x8 pb[QT][2];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                float sub = 0.f;
+                if constexpr (!FIXED) {
+                    float mx = S[t][0];
+#pragma unroll
+                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
+                    mx = fmaxf(mx, xhalf(mx));
+                    const float mnew = fmaxf(mrun[t], mx);
+                    const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
+                    mrun[t] = mnew;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+                    lrun[t] *= alpha;
+                    sub = mnew;
+                }
+                float ps = 0.f;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const float pr = __builtin_amdgcn_exp2f(S[t][r] - sub);
+                    if constexpr (!ONES) ps += pr;
+                    pb[t][r >> 3][r & 7] = (bf16)pr;
+                }
+                if constexpr (!ONES) lrun[t] += ps;
+            }
+            // V^T fragments: rows = head dim l31; k-slot e <-> key kb + 16*s + 8*(e>>2) + 4*half + (e&3)
+            bf16x8 vf[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const char* vp = Vt + l31 * VROW + (kb + 16 * s + 4 * half) * 2;
+                const bf16x4 lo = *(const bf16x4*)(vp);
+                const bf16x4 hi = *(const bf16x4*)(vp + 16);
+                vf[s] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[t][0], O[t], 0, 0, 0);
+                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[t][1], O[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane holds head dims 8*g + 4*half + [0..3] of query l31 ----
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float l;
+        if constexpr (ONES) {
+            const int oc = p.ones_col;
+            const int base_row = oc & ~4;  // row index with the half bit cleared
+            float cand = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                if (mfma32_row(r, 0) == base_row) cand = O[t][r];
+            const float other = xhalf(cand);
+            l = (half == ((oc >> 2) & 1)) ? cand : other;
+        } else {
+            l = lrun[t] + xhalf(lrun[t]);
+        }
+        const float inv = 1.0f / l;
+        if (qvalid[t]) {
+            bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * 32 + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                uint2 pk;
+                pk.x = pack_bf16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv);
+                pk.y = pack_bf16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv);
+                *(uint2*)(dst + 8 * g) = pk;
+            }
+        }
+    }
+}
+
+template <bool FIXED, bool ONES>
+int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t st) {
+    const bool kw4 = (p.k.ww % 4) == 0;
+#define GRL_ATTN_GO(KW4V)                                                                                   \
+    {                                                                                                       \
+        auto kfn = attn_kernel<FIXED, ONES, KW4V>;                                                          \
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                           (int)lds);                                                       \
+        if (e != hipSuccess) return (int)e;                                                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(block), lds, st, p);                                       \
+    }
+    if (kw4) GRL_ATTN_GO(true) else GRL_ATTN_GO(false)
+#undef GRL_ATTN_GO
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
+    const GrlAttnArgs& p = *args;
+    const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
+    if (Nq <= 0 || Nk <= 0 || p.B <= 0 || p.nh <= 0) return GRL_ERR_BAD_ARG;
+    if (p.q.Himg != p.nwy * p.q.wh || p.q.Wimg != p.nwx * p.q.ww) return GRL_ERR_BAD_ARG;
+    if (p.k.Himg != p.nwy * p.k.wh || p.k.Wimg != p.nwx * p.k.ww) return GRL_ERR_BAD_ARG;
+    if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1)) return GRL_ERR_BAD_ARG;
+    if (p.head_dim > 32 || p.ones_col >= 32) return GRL_ERR_BAD_ARG;
+    if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 4) || (p.q.col0 % 8) || (p.k.col0 % 8) ||
+        (p.v.col0 % 8) || (p.o.col0 % 4))
+        return GRL_ERR_BAD_ARG;
+    const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
+    const int qblk = waves * QT * 32;
+    const int nqs = (Nq + qblk - 1) / qblk;
+    const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
+    if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
+    const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC * 4 + KC;
+    if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    const bool ones = p.ones_col >= 0;
+    if (p.fixed_max) return ones ? launch_kw<true, true>(p, (int)grid, waves * 64, lds, st)
+                                 : launch_kw<true, false>(p, (int)grid, waves * 64, lds, st);
+    return ones ? launch_kw<false, true>(p, (int)grid, waves * 64, lds, st)
+                : launch_kw<false, false>(p, (int)grid, waves * 64, lds, st);
+}

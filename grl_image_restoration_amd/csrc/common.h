@@ -1,0 +1,48 @@
+// Shared device helpers for the GRL gfx950 kernels.
+// gfx950 / CDNA4 only: wave64, MFMA bf16 32x32x16 + 16x16x32, 160 KiB LDS per CU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef __bf16 bf16;
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(2 * sizeof(__bf16)))) __bf16 bf16x2;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
+
+#define GRL_WAVE 64
+#define LOG2E_F 1.4426950408889634f
+
+// C/D fragment row of register r for the 32x32 MFMA shapes (cdna guide section 3):
+//   col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+__device__ __forceinline__ int mfma32_row(int r, int half) { return (r & 3) + 8 * (r >> 2) + 4 * half; }
+
+__device__ __forceinline__ float bf16_to_f32(bf16 x) { return (float)x; }
+
+__device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
+    bf16x2 v;
+    v[0] = (bf16)lo;
+    v[1] = (bf16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+
+// exchange with the lane 32 apart (both halves of a wave64)
+__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+
+// sum over the 16 lanes that share (lane >> 4)
+__device__ __forceinline__ float row16_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    v += __shfl_xor(v, 8, 64);
+    return v;
+}
+
+#define GRL_CHECK_LAUNCH()                         \
+    do {                                           \
+        hipError_t e__ = hipGetLastError();        \
+        if (e__ != hipSuccess) return (int)e__;    \
+    } while (0)

@@ -1,0 +1,291 @@
+// Token-wise linear layers of the GRL block as one MFMA kernel family (gfx950).
+//
+//   out[m, :] = epilogue( A[m, :] . W^T + bias )          M = B*H*W tokens (huge), N,K <= 576
+//
+// Replaces, per SURVEY 8(a): P1 QKVProjection (mixed_attn_block.py:661-676), P2 AnchorLinear
+// (:714-736, avg-pool fused into the A load), M1 proj + B1 norm1/residual
+// (mixed_attn_block_efficient.py:379,543-548), F1 Mlp (swin_v1_block.py:37-43) + norm2/residual
+// (efficient.py:554).
+//
+// Design (MI355X): these GEMMs are HBM-bound (108 FLOP/B for QKV), so the kernel is built
+// around one pass over the activations:
+//   * a wave owns 32 token rows; its whole A slab (32 x Kpad, bf16) lives in VGPRs and is
+//     re-used for every N chunk, so A is read from HBM exactly once;
+//   * weights (bf16, zero-padded to [Npad][Kpad]) stream through LDS in chunks of NT*16 rows,
+//     padded by 16 B per row so the ds_read_b128 fragment reads are bank-conflict free;
+//   * the product is computed transposed (D^T = W . A^T, mfma_f32_16x16x32_bf16) so every
+//     lane ends up with 4 consecutive output channels of one token: row reductions for
+//     LayerNorm / per-head L2 normalisation need only two cross-lane steps and stores are
+//     8-16 B wide;
+//   * epilogues fuse bias, exact GELU, cosine-attention q/k normalisation + logit scale,
+//     LayerNorm + residual (+ the CAB branch) so no intermediate goes back to HBM.
+#include "common.h"
+#include "grl_hip_internal.h"
+
+namespace {
+
+constexpr int WAVES = 8;             // 512 threads, 2 waves / SIMD
+constexpr int ROWS_PER_WAVE = 32;    // 2 MFMA m-tiles
+constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
+
+template <int KSTEPS>
+__device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, int lane, bf16x8 (&a)[2][KSTEPS]) {
+    const int r = lane & 15, kg = lane >> 4;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        int m = row0 + 16 * mt + r;
+        const bool valid = m < p.M;
+        if (!valid) m = p.M - 1;
+        if (p.pool_df > 1) {
+            // A row = mean over a df x df block of token rows (AnchorLinear avg-pool, fp32 source)
+            const int df = p.pool_df;
+            const int Wa = p.pool_W / df, Ha = p.pool_H / df;
+            const int xa = m % Wa, ya = (m / Wa) % Ha, b = m / (Wa * Ha);
+            const float inv = 1.0f / (float)(df * df);
+            const float* base = (const float*)p.a + ((int64_t)(b * p.pool_H + ya * df) * p.pool_W + xa * df) * p.lda;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int dy = 0; dy < df; ++dy)
+                    for (int dx = 0; dx < df; ++dx) {
+                        const float4* q = (const float4*)(base + ((int64_t)dy * p.pool_W + dx) * p.lda + 32 * s + 8 * kg);
+                        float4 v0 = q[0], v1 = q[1];
+                        acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
+                        acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
+                    }
+#pragma unroll
+                for (int e = 0; e < 8; ++e) a[mt][s][e] = (bf16)(valid ? acc[e] * inv : 0.0f);
+            }
+        } else if (p.a_is_bf16) {
+            const bf16* base = (const bf16*)p.a + (int64_t)m * p.lda;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                bf16x8 v = *(const bf16x8*)(base + 32 * s + 8 * kg);
+                if (!valid) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                a[mt][s] = v;
+            }
+        } else {
+            const float* base = (const float*)p.a + (int64_t)m * p.lda;
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                const float4* q = (const float4*)(base + 32 * s + 8 * kg);
+                float4 v0 = q[0], v1 = q[1];
+                if (!valid) { v0 = float4{0, 0, 0, 0}; v1 = v0; }
+                bf16x8 v;
+                v[0] = (bf16)v0.x; v[1] = (bf16)v0.y; v[2] = (bf16)v0.z; v[3] = (bf16)v0.w;
+                v[4] = (bf16)v1.x; v[5] = (bf16)v1.y; v[6] = (bf16)v1.z; v[7] = (bf16)v1.w;
+                a[mt][s] = v;
+            }
+        }
+    }
+}
+
+// One workgroup: ROWS_PER_WG token rows x all Npad output channels.
+template <int KSTEPS, int NT, int EPI>
+__global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KPAD = KSTEPS * 32;
+    constexpr int ROWB = KPAD * 2 + 16;  // padded LDS row (bytes)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row0 = blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE;
+    const int r16 = lane & 15, g4 = lane >> 4;
+
+    bf16x8 a[2][KSTEPS];
+    load_a_slab<KSTEPS>(p, row0, lane, a);
+
+    const int nchunks = p.Npad / (NT * 16);
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int n0 = ch * NT * 16;
+        // ---- stage the weight chunk [NT*16][KPAD] into LDS (16 B per thread-iteration) ----
+        __syncthreads();
+        {
+            constexpr int SEGS_PER_ROW = KPAD / 8;
+            constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
+            const bf16* wsrc = (const bf16*)p.w + (int64_t)n0 * KPAD;
+            for (int i = tid; i < SEGS; i += WAVES * 64) {
+                const int rr = i / SEGS_PER_ROW, cc = i % SEGS_PER_ROW;
+                *(bf16x8*)(smem + rr * ROWB + cc * 16) = *(const bf16x8*)(wsrc + (int64_t)rr * KPAD + cc * 8);
+            }
+        }
+        __syncthreads();
+
+        f32x4 acc[2][NT];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const bf16x8 w = *(const bf16x8*)(smem + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
+                // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
+                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[0][s], acc[0][nt], 0, 0, 0);
+                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[1][s], acc[1][nt], 0, 0, 0);
+            }
+        }
+
+        // ---- epilogue: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16 ----
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4);
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                acc[mt][nt][0] += b4.x; acc[mt][nt][1] += b4.y; acc[mt][nt][2] += b4.z; acc[mt][nt][3] += b4.w;
+            }
+        }
+
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int m = row0 + 16 * mt + r16;
+            const bool valid = m < p.M;
+            if constexpr (EPI == GRL_EPI_GROUPNORM) {
+                // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
+                // gscale == 0 marks a pass-through group (v).  F.normalize eps: efficient.py:85.
+#pragma unroll
+                for (int g = 0; g < NT / 2; ++g) {
+                    float ss = 0.f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        ss += acc[mt][2 * g][e] * acc[mt][2 * g][e];
+                        ss += acc[mt][2 * g + 1][e] * acc[mt][2 * g + 1][e];
+                    }
+                    ss += __shfl_xor(ss, 16, 64);
+                    ss += __shfl_xor(ss, 32, 64);
+                    const float gs = p.gscale[(n0 >> 5) + g];
+                    const float f = gs != 0.0f ? gs / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { acc[mt][2 * g][e] *= f; acc[mt][2 * g + 1][e] *= f; }
+                }
+            } else if constexpr (EPI == GRL_EPI_GELU) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][nt][e] = gelu_erf(acc[mt][nt][e]);
+            } else if constexpr (EPI == GRL_EPI_LN_RES) {
+                // LayerNorm over the n_real real channels (eps 1e-5), then residual (+ optional extra branch)
+                float s1 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s1 += (16 * nt + 4 * g4 + e) < p.n_real ? acc[mt][nt][e] : 0.f;
+                s1 += __shfl_xor(s1, 16, 64);
+                s1 += __shfl_xor(s1, 32, 64);
+                const float mean = s1 / (float)p.n_real;
+                float s2 = 0.f;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const float d = acc[mt][nt][e] - mean;
+                        s2 += (16 * nt + 4 * g4 + e) < p.n_real ? d * d : 0.f;
+                    }
+                s2 += __shfl_xor(s2, 16, 64);
+                s2 += __shfl_xor(s2, 32, 64);
+                const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const int c = 16 * nt + 4 * g4;
+                    const float4 g = *(const float4*)(p.ln_g + c);
+                    const float4 bb = *(const float4*)(p.ln_b + c);
+                    float4 res = float4{0, 0, 0, 0};
+                    if (valid) res = *(const float4*)(p.resid + (int64_t)m * p.ldr + c);
+                    float y[4];
+                    y[0] = res.x + p.res_scale * ((acc[mt][nt][0] - mean) * rstd * g.x + bb.x);
+                    y[1] = res.y + p.res_scale * ((acc[mt][nt][1] - mean) * rstd * g.y + bb.y);
+                    y[2] = res.z + p.res_scale * ((acc[mt][nt][2] - mean) * rstd * g.z + bb.z);
+                    y[3] = res.w + p.res_scale * ((acc[mt][nt][3] - mean) * rstd * g.w + bb.w);
+                    if (p.add2 != nullptr && valid) {
+                        if (p.add2_is_bf16) {
+                            const bf16x4 t = *(const bf16x4*)((const bf16*)p.add2 + (int64_t)m * p.ldadd2 + c);
+                            y[0] += (float)t[0]; y[1] += (float)t[1]; y[2] += (float)t[2]; y[3] += (float)t[3];
+                        } else {
+                            const float4 t = *(const float4*)((const float*)p.add2 + (int64_t)m * p.ldadd2 + c);
+                            y[0] += t.x; y[1] += t.y; y[2] += t.z; y[3] += t.w;
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[mt][nt][e] = (c + e) < p.n_real ? y[e] : 0.f;  // keep pad channels 0
+                }
+            }
+            if (!valid) continue;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = n0 + 16 * nt + 4 * g4;
+                if (p.out_is_bf16) {
+                    uint2 pk;
+                    pk.x = pack_bf16(acc[mt][nt][0], acc[mt][nt][1]);
+                    pk.y = pack_bf16(acc[mt][nt][2], acc[mt][nt][3]);
+                    *(uint2*)((bf16*)p.out + (int64_t)m * p.ldo + c) = pk;
+                } else {
+                    *(float4*)((float*)p.out + (int64_t)m * p.ldo + c) =
+                        float4{acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
+                }
+            }
+        }
+    }
+}
+
+template <int KSTEPS, int NT>
+int launch_epi(const GrlLinearArgs& p, hipStream_t st) {
+    const int grid = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const size_t lds = (size_t)NT * 16 * (KSTEPS * 64 + 16);
+#define GRL_LAUNCH_EPI(E)                                                                                   \
+    case E: {                                                                                               \
+        auto kfn = linear_kernel<KSTEPS, NT, E>;                                                            \
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                           (int)lds);                                                       \
+        if (e != hipSuccess) return (int)e;                                                                 \
+        hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, st, p);                                  \
+        break;                                                                                              \
+    }
+    switch (p.epi) {
+        GRL_LAUNCH_EPI(GRL_EPI_PLAIN)
+        GRL_LAUNCH_EPI(GRL_EPI_GELU)
+        GRL_LAUNCH_EPI(GRL_EPI_GROUPNORM)
+        GRL_LAUNCH_EPI(GRL_EPI_LN_RES)
+        default: return GRL_ERR_UNSUPPORTED;
+    }
+#undef GRL_LAUNCH_EPI
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int KSTEPS>
+int launch_nt(const GrlLinearArgs& p, int nt, hipStream_t st) {
+    switch (nt) {
+        case 4: return launch_epi<KSTEPS, 4>(p, st);
+        case 6: return launch_epi<KSTEPS, 6>(p, st);
+        case 8: return launch_epi<KSTEPS, 8>(p, st);
+        case 12: return launch_epi<KSTEPS, 12>(p, st);
+        default: return GRL_ERR_UNSUPPORTED;
+    }
+}
+
+}  // namespace
+
+extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
+    const GrlLinearArgs& p = *args;
+    if (p.M <= 0) return 0;
+    if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % 8 != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
+    if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
+    // widest chunk (<= 12 n-tiles) that divides Npad
+    int nt = 0;
+    const int tiles = p.Npad / 16;
+    const int cand[4] = {12, 8, 6, 4};
+    for (int i = 0; i < 4; ++i)
+        if (tiles % cand[i] == 0) { nt = cand[i]; break; }
+    if (tiles == 2) return GRL_ERR_UNSUPPORTED;
+    if (nt == 0) return GRL_ERR_UNSUPPORTED;
+    if (p.epi == GRL_EPI_LN_RES && nt * 16 != p.Npad) return GRL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.Kpad / 32) {
+        case 2: return launch_nt<2>(p, nt, st);
+        case 4: return launch_nt<4>(p, nt, st);
+        case 6: return launch_nt<6>(p, nt, st);
+        case 8: return launch_nt<8>(p, nt, st);
+        case 12: return launch_nt<12>(p, nt, st);
+        default: return GRL_ERR_UNSUPPORTED;
+    }
+}

@@ -1,0 +1,58 @@
+// Small memory-bound kernels of the GRL path: row LayerNorm (norm_start / norm_end,
+// models/networks/grl.py:494,501) and library self-description.
+#include "common.h"
+#include "grl_hip_internal.h"
+
+namespace {
+
+// one wave per token row; n_pad <= 256 channels; pad channels written as 0
+__global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
+                                                        int64_t ldy, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int M, int n_real, int n_pad,
+                                                        float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= M) return;
+    const float* xr = x + (int64_t)row * ldx;
+    const int c = lane * 4;
+    float4 v = float4{0, 0, 0, 0};
+    if (c < n_pad) v = *(const float4*)(xr + c);
+    float e[4] = {v.x, v.y, v.z, v.w};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (c + i) < n_real ? e[i] : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)n_real;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float d = e[i] - mean;
+        q += (c + i) < n_real ? d * d : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)n_real + eps);
+    if (c < n_pad) {
+        float o4[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            o4[i] = (c + i) < n_real ? (e[i] - mean) * rstd * gamma[c + i] + beta[c + i] : 0.f;
+        *(float4*)(y + (int64_t)row * ldy + c) = float4{o4[0], o4[1], o4[2], o4[3]};
+    }
+}
+
+}  // namespace
+
+extern "C" int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                                 const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps) {
+    if (M <= 0) return 0;
+    if (n_pad > 256 || (n_pad & 3) || n_real > n_pad || (ldx & 3) || (ldy & 3)) return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma,
+                       beta, M, n_real, n_pad, eps);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int grl_abi_version(void) { return GRL_ABI_VERSION; }
+extern "C" const char* grl_build_info(void) { return "grl_hip gfx950 (MI355X) " __DATE__ " " __TIME__; }

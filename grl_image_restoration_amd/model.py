@@ -1,0 +1,589 @@
+"""``GRL`` -- drop-in replacement for the reference network at its own boundary.
+
+Boundary: the reference engine does ``self.model = hydra.utils.instantiate(cfg.model)``
+(engines/base.py:44) and then only calls ``model(x)``, ``parameters()``, ``state_dict()`` /
+``load_state_dict(strict=True)`` and ``convert_checkpoint`` (tools/trainer.py:93-115).  This class
+accepts the constructor arguments of ``models.networks.grl.GRL`` (grl.py:220-256, unknown YAML keys
+swallowed like the reference does), owns parameters with the *same names and shapes*, and runs
+the forward pass (grl.py:506-551) on MI355X through libgrl_hip.so.
+
+There is no CPU / eager fallback for the hot path: calling the model on CPU tensors raises.
+"""
+import math
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import ops, tables
+from .geometry import BlockGeo, block_schedule, pad_multiple, table_rows, to_2tuple
+
+LOG2E = tables.LOG2E
+
+
+def _pad32(n: int) -> int:
+    return (n + 31) // 32 * 32
+
+
+# ------------------------------------------------------------------------------------------------
+# parameter containers (names mirror the reference so state_dicts are interchangeable)
+# ------------------------------------------------------------------------------------------------
+class _Affine(nn.Module):  # mixed_attn_block_efficient.py:23-34
+    def __init__(self, nh):
+        super().__init__()
+        self.logit_scale = nn.Parameter(torch.log(10 * torch.ones((nh, 1, 1))))
+        self.cpb_mlp = nn.Sequential(nn.Linear(2, 512, bias=True), nn.ReLU(inplace=True), nn.Linear(512, nh, bias=False))
+
+
+class _Body(nn.Module):
+    def __init__(self, body):
+        super().__init__()
+        self.body = body
+
+
+class _AnchorLinear(nn.Module):  # mixed_attn_block.py:714-725
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.reduction = nn.Linear(cin, cout, bias=True)
+
+
+class _WindowAttn(nn.Module):
+    def __init__(self, nh):
+        super().__init__()
+        self.attn_transform = _Affine(nh)
+
+
+class _StripeAttn(nn.Module):
+    def __init__(self, nh):
+        super().__init__()
+        self.attn_transform1 = _Affine(nh)
+        self.attn_transform2 = _Affine(nh)
+
+
+class _MixedAttention(nn.Module):  # mixed_attn_block_efficient.py:317-349
+    def __init__(self, dim, nh_w, nh_s):
+        super().__init__()
+        self.qkv = _Body(nn.Linear(dim, dim * 3, bias=True))
+        self.anchor = _Body(nn.ModuleList([_AnchorLinear(dim, dim // 2)]))
+        self.window_attn = _WindowAttn(nh_w)
+        self.stripe_attn = _StripeAttn(nh_s)
+        self.proj = nn.Linear(dim, dim)
+
+
+class _ChannelAttention(nn.Module):  # mixed_attn_block.py:948-963
+    def __init__(self, c, reduction):
+        super().__init__()
+        self.attention = nn.Sequential(
+            nn.AdaptiveAvgPool2d(1), nn.Conv2d(c, c // reduction, 1, padding=0), nn.ReLU(inplace=True),
+            nn.Conv2d(c // reduction, c, 1, padding=0), nn.Sigmoid(),
+        )
+
+
+class _CAB(nn.Module):  # mixed_attn_block.py:970-979
+    def __init__(self, c, compress_ratio=4, reduction=18):
+        super().__init__()
+        self.cab = nn.Sequential(
+            nn.Conv2d(c, c // compress_ratio, 3, 1, 1), nn.GELU(), nn.Conv2d(c // compress_ratio, c, 3, 1, 1),
+            _ChannelAttention(c, reduction),
+        )
+
+
+class _Mlp(nn.Module):  # swin_v1_block.py:15-35
+    def __init__(self, dim, hidden):
+        super().__init__()
+        self.fc1 = nn.Linear(dim, hidden)
+        self.fc2 = nn.Linear(hidden, dim)
+
+
+class _Block(nn.Module):  # mixed_attn_block_efficient.py:406-508
+    def __init__(self, dim, nh_w, nh_s, mlp_ratio, local_connection):
+        super().__init__()
+        self.attn = _MixedAttention(dim, nh_w, nh_s)
+        self.norm1 = nn.LayerNorm(dim)
+        if local_connection:
+            self.conv = _CAB(dim)
+        self.mlp = _Mlp(dim, int(dim * mlp_ratio))
+        self.norm2 = nn.LayerNorm(dim)
+
+
+class _Stage(nn.Module):  # grl.py:31-137
+    def __init__(self, dim, depth, nh_w, nh_s, mlp_ratio, local_connection):
+        super().__init__()
+        self.blocks = nn.ModuleList([_Block(dim, nh_w, nh_s, mlp_ratio, local_connection) for _ in range(depth)])
+        self.conv = nn.Conv2d(dim, dim, 3, 1, 1)
+
+
+class _Up(nn.Module):  # upsample.py:6-50
+    def __init__(self, mods):
+        super().__init__()
+        self.up = nn.Sequential(*mods)
+
+
+_BUFFER_PREFIXES = ("table_", "index_", "mask_")
+
+
+class GRL(nn.Module):
+    """MI355X-native GRL.  Constructor signature of models/networks/grl.py:220-256."""
+
+    def __init__(
+        self,
+        img_size=64,
+        in_channels=3,
+        out_channels=None,
+        embed_dim=96,
+        upscale=2,
+        img_range=1.0,
+        upsampler="",
+        depths=[6, 6, 6, 6, 6, 6],
+        num_heads_window=[3, 3, 3, 3, 3, 3],
+        num_heads_stripe=[3, 3, 3, 3, 3, 3],
+        window_size=8,
+        stripe_size=[8, 8],
+        stripe_groups=[None, None],
+        stripe_shift=False,
+        mlp_ratio=4.0,
+        qkv_bias=True,
+        qkv_proj_type="linear",
+        anchor_proj_type="avgpool",
+        anchor_one_stage=True,
+        anchor_window_down_factor=1,
+        out_proj_type="linear",
+        local_connection=False,
+        drop_rate=0.0,
+        attn_drop_rate=0.0,
+        drop_path_rate=0.1,
+        norm_layer=nn.LayerNorm,
+        pretrained_window_size=[0, 0],
+        pretrained_stripe_size=[0, 0],
+        conv_type="1conv",
+        init_method="n",
+        fairscale_checkpoint=False,
+        offload_to_cpu=False,
+        euclidean_dist=False,
+        **kwargs,  # name, double_window, stripe_square, separable_conv_act, use_buffer, ... (swallowed, grl.py:255)
+    ):
+        super().__init__()
+        unsupported = []
+        if qkv_proj_type != "linear":
+            unsupported.append(f"qkv_proj_type={qkv_proj_type!r}")
+        if anchor_proj_type != "avgpool" or not anchor_one_stage:
+            unsupported.append(f"anchor_proj_type={anchor_proj_type!r}/anchor_one_stage={anchor_one_stage}")
+        if out_proj_type != "linear":
+            unsupported.append(f"out_proj_type={out_proj_type!r}")
+        if conv_type != "1conv":
+            unsupported.append(f"conv_type={conv_type!r}")
+        if euclidean_dist:
+            unsupported.append("euclidean_dist=True")
+        if not qkv_bias:
+            unsupported.append("qkv_bias=False")
+        if list(pretrained_window_size) != [0, 0] or list(pretrained_stripe_size) != [0, 0]:
+            unsupported.append("pretrained_*_size != [0, 0]")
+        if init_method not in ("n", "r", "l", "w") and init_method.find("t") < 0:
+            unsupported.append(f"init_method={init_method!r}")
+        if unsupported:
+            raise NotImplementedError(
+                "grl_image_restoration_amd.GRL implements the configurations the reference ships "
+                "(config/model/grl/*.yaml); not supported: " + ", ".join(unsupported)
+            )
+        out_channels = out_channels or in_channels
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.embed_dim, self.upscale, self.upsampler, self.img_range = embed_dim, upscale, upsampler, img_range
+        self.depths = list(depths)
+        self.num_heads_window, self.num_heads_stripe = list(num_heads_window), list(num_heads_stripe)
+        self.window_size = to_2tuple(window_size)
+        self.stripe_size, self.stripe_groups = list(stripe_size), list(stripe_groups)
+        self.stripe_shift = stripe_shift
+        self.mlp_ratio = mlp_ratio
+        self.df = anchor_window_down_factor
+        self.local_connection = local_connection
+        self.res_scale = 0.1 if init_method == "r" else 1.0
+        self.input_resolution = to_2tuple(img_size)
+        self.pad_size = pad_multiple(self.window_size[0], self.stripe_size, self.stripe_groups, self.df)
+        if embed_dim % 2 or any((embed_dim // 2) % h for h in self.num_heads_window + self.num_heads_stripe):
+            raise ValueError("embed_dim/2 must be divisible by the number of heads")
+        if max((embed_dim // 2) // h for h in self.num_heads_window + self.num_heads_stripe) > 32:
+            raise NotImplementedError("head_dim > 32 is not supported by the gfx950 attention kernel")
+        if in_channels == 3:
+            mean = torch.tensor((0.4488, 0.4371, 0.4040)).view(1, 3, 1, 1)
+        else:
+            mean = torch.zeros(1, 1, 1, 1)
+        self.register_buffer("_mean", mean, persistent=False)
+
+        num_out_feats = 64
+        self.conv_first = nn.Conv2d(in_channels, embed_dim, 3, 1, 1)
+        self.norm_start = nn.LayerNorm(embed_dim)
+        self.layers = nn.ModuleList(
+            [
+                _Stage(embed_dim, depths[i], num_heads_window[i], num_heads_stripe[i], mlp_ratio, local_connection)
+                for i in range(len(depths))
+            ]
+        )
+        self.norm_end = nn.LayerNorm(embed_dim)
+        self.conv_after_body = nn.Conv2d(embed_dim, embed_dim, 3, 1, 1)
+        if upsampler == "pixelshuffle":
+            self.conv_before_upsample = nn.Sequential(nn.Conv2d(embed_dim, num_out_feats, 3, 1, 1), nn.LeakyReLU(inplace=True))
+            m = []
+            if (upscale & (upscale - 1)) == 0:
+                for _ in range(int(math.log(upscale, 2))):
+                    m += [nn.Conv2d(num_out_feats, 4 * num_out_feats, 3, 1, 1), nn.PixelShuffle(2)]
+            elif upscale == 3:
+                m += [nn.Conv2d(num_out_feats, 9 * num_out_feats, 3, 1, 1), nn.PixelShuffle(3)]
+            else:
+                raise ValueError(f"scale {upscale} is not supported. Supported scales: 2^n and 3.")
+            self.upsample = _Up(m)
+            self.conv_last = nn.Conv2d(num_out_feats, out_channels, 3, 1, 1)
+        elif upsampler == "pixelshuffledirect":
+            self.upsample = _Up([nn.Conv2d(embed_dim, (upscale**2) * out_channels, 3, 1, 1), nn.PixelShuffle(upscale)])
+        elif upsampler == "nearest+conv":
+            assert upscale == 4, "only support x4 now."
+            self.conv_before_upsample = nn.Sequential(nn.Conv2d(embed_dim, num_out_feats, 3, 1, 1), nn.LeakyReLU(inplace=True))
+            self.conv_up1 = nn.Conv2d(num_out_feats, num_out_feats, 3, 1, 1)
+            self.conv_up2 = nn.Conv2d(num_out_feats, num_out_feats, 3, 1, 1)
+            self.conv_hr = nn.Conv2d(num_out_feats, num_out_feats, 3, 1, 1)
+            self.conv_last = nn.Conv2d(num_out_feats, out_channels, 3, 1, 1)
+        else:
+            self.conv_last = nn.Conv2d(embed_dim, out_channels, 3, 1, 1)
+
+        self.apply(self._init_weights)  # grl.py:381,455-469
+        self._init_method_rescale(init_method)
+        self._plan_cache: Dict = {}
+        self._register_load_state_dict_pre_hook(self._drop_reference_buffers)
+
+    # ---- init / checkpoint contract ------------------------------------------------------------
+    @staticmethod
+    def _init_weights(m):
+        if isinstance(m, nn.Linear):
+            nn.init.trunc_normal_(m.weight, std=0.02)
+            if m.bias is not None:
+                nn.init.constant_(m.bias, 0)
+        elif isinstance(m, nn.LayerNorm):
+            nn.init.constant_(m.bias, 0)
+            nn.init.constant_(m.weight, 1.0)
+
+    def _init_method_rescale(self, init_method):
+        """TransformerStage._init_weights (grl.py:139-162) for the 'l' / 'w' / 't*' variants."""
+        if not (init_method in ("l", "w") or init_method.find("t") >= 0):
+            return
+        for layer in self.layers:
+            for n, m in layer.named_modules():
+                if init_method == "w":
+                    if isinstance(m, (nn.Linear, nn.Conv2d)) and n.find("cpb_mlp") < 0:
+                        m.weight.data *= 0.1
+                elif init_method == "l":
+                    if isinstance(m, nn.LayerNorm):
+                        nn.init.constant_(m.bias, 0)
+                        nn.init.constant_(m.weight, 0)
+                else:
+                    scale = 0.1 ** (len(init_method) - 1) * int(init_method[-1])
+                    if isinstance(m, nn.Linear) and n.find("cpb_mlp") < 0:
+                        nn.init.trunc_normal_(m.weight, std=scale)
+                    elif isinstance(m, nn.Conv2d):
+                        m.weight.data *= 0.1
+
+    @staticmethod
+    def _drop_reference_buffers(state_dict, prefix, *args):
+        """The reference keeps 13 table/index/mask buffers in its state_dict (grl.py:309-310) and never
+        trusts them from disk (convert_checkpoint, grl.py:556-569).  This implementation needs none of
+        them, so they are dropped on load to keep ``load_state_dict(strict=True)`` working."""
+        for k in list(state_dict.keys()):
+            if k[len(prefix):].startswith(_BUFFER_PREFIXES):
+                state_dict.pop(k)
+
+    def convert_checkpoint(self, state_dict):
+        """grl.py:556-569: drop buffers that depend on the geometry from a Lightning checkpoint."""
+        for k in list(state_dict.keys()):
+            if (
+                k.find("relative_coords_table") >= 0 or k.find("relative_position_index") >= 0
+                or k.find("attn_mask") >= 0 or k.find("model.table_") >= 0 or k.find("model.index_") >= 0
+                or k.find("model.mask_") >= 0
+            ):
+                state_dict.pop(k)
+        return state_dict
+
+    def load_state_dict(self, state_dict, strict=True, **kw):
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self.invalidate_plan()
+        return out
+
+    def invalidate_plan(self):
+        """Call after changing parameters in place; packed weights/tables are rebuilt lazily."""
+        self._plan_cache = {}
+
+    def train(self, mode: bool = True):
+        if mode:
+            self.invalidate_plan()
+        return super().train(mode)
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {"absolute_pos_embed"}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {"relative_position_bias_table"}
+
+    # ---- weight packing ------------------------------------------------------------------------
+    def _pack_block(self, blk: _Block, geo: BlockGeo, dev) -> dict:
+        C = self.embed_dim
+        CP = _pad32(C)
+        nh_w, nh_s = geo.nh_w, geo.nh_s
+        d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
+        a = blk.attn
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        def aff(m: _Affine):
+            return tables.clamped_scale(m.logit_scale).to(dev)
+
+        sc_w, sc_1, sc_2 = aff(a.window_attn.attn_transform), aff(a.stripe_attn.attn_transform1), aff(a.stripe_attn.attn_transform2)
+        fixed = bool(tables.fixed_max_is_safe(torch.cat([sc_w, sc_1, sc_2])))
+
+        # --- QKV: one 32-wide slot per (branch, q|k|v, head); v slots carry a constant-1 column ---
+        W = a.qkv.body.weight.detach().float()
+        b = a.qkv.body.bias.detach().float()
+        G = 3 * nh_w + 3 * nh_s
+        Wp = torch.zeros(G * 32, CP, **f32)
+        bp = torch.zeros(G * 32, **f32)
+        gs = torch.zeros(G, **f32)
+        for br, (nh, d, base_o, base_g) in enumerate(((nh_w, d_w, 0, 0), (nh_s, d_s, 3 * C // 2, 3 * nh_w))):
+            for which in range(3):
+                for h in range(nh):
+                    g = base_g + which * nh + h
+                    o0 = base_o + which * (C // 2) + h * d
+                    Wp[g * 32 : g * 32 + d, :C] = W[o0 : o0 + d]
+                    bp[g * 32 : g * 32 + d] = b[o0 : o0 + d]
+                    if which == 2 and d < 32:
+                        bp[g * 32 + d] = 1.0
+                    if which == 0:
+                        gs[g] = (sc_w[h] if br == 0 else sc_2[h]) * LOG2E
+                    elif which == 1:
+                        gs[g] = 1.0 if br == 0 else sc_1[h] * LOG2E
+        pk = dict(qkv_w=Wp.to(torch.bfloat16), qkv_b=bp, qkv_gs=gs, fixed=fixed)
+
+        # --- anchor projection (avg-pool fused in the kernel) ---
+        Wa = a.anchor.body[0].reduction.weight.detach().float()
+        ba = a.anchor.body[0].reduction.bias.detach().float()
+        Wap = torch.zeros(nh_s * 32, CP, **f32)
+        bap = torch.zeros(nh_s * 32, **f32)
+        for h in range(nh_s):
+            Wap[h * 32 : h * 32 + d_s, :C] = Wa[h * d_s : (h + 1) * d_s]
+            bap[h * 32 : h * 32 + d_s] = ba[h * d_s : (h + 1) * d_s]
+        pk.update(anc_w=Wap.to(torch.bfloat16), anc_b=bap, anc_gs=torch.ones(nh_s, **f32))
+
+        # --- output projection over the slotted attention output + norm1 ---
+        Wo = a.proj.weight.detach().float()
+        KA = (nh_w + nh_s) * 32
+        Wop = torch.zeros(CP, KA, **f32)
+        for h in range(nh_w):
+            Wop[:C, h * 32 : h * 32 + d_w] = Wo[:, h * d_w : (h + 1) * d_w]
+        for h in range(nh_s):
+            Wop[:C, (nh_w + h) * 32 : (nh_w + h) * 32 + d_s] = Wo[:, C // 2 + h * d_s : C // 2 + (h + 1) * d_s]
+
+        def padv(v, n=CP):
+            out = torch.zeros(n, **f32)
+            out[: v.numel()] = v.detach().float()
+            return out
+
+        pk.update(proj_w=Wop.to(torch.bfloat16), proj_b=padv(a.proj.bias), n1_g=padv(blk.norm1.weight), n1_b=padv(blk.norm1.bias))
+
+        # --- MLP + norm2 ---
+        Hd = blk.mlp.fc1.weight.shape[0]
+        HP = _pad32(Hd)
+        W1 = torch.zeros(HP, CP, **f32)
+        W1[:Hd, :C] = blk.mlp.fc1.weight.detach().float()
+        W2 = torch.zeros(CP, HP, **f32)
+        W2[:C, :Hd] = blk.mlp.fc2.weight.detach().float()
+        pk.update(fc1_w=W1.to(torch.bfloat16), fc1_b=padv(blk.mlp.fc1.bias, HP), fc2_w=W2.to(torch.bfloat16),
+                  fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
+
+        # --- relative-position bias tables in the kernel's exp2 domain ---
+        def table(m: _Affine, win, df, scale):
+            coords = tables.coords_table(win, df, device=dev)
+            bias = tables.bias_rows(m.cpb_mlp[0].weight.to(dev), m.cpb_mlp[0].bias.to(dev), m.cpb_mlp[2].weight.to(dev), coords)
+            return tables.kernel_table(bias, scale, fixed)
+
+        pk["tab_w"] = table(a.window_attn.attn_transform, geo.window, 1, sc_w)
+        pk["tab_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df, sc_1)
+        pk["tab_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df, sc_2)
+        assert pk["tab_w"].shape[1] == table_rows(geo.window, geo.window)
+        assert pk["tab_a2w"].shape[1] == table_rows(geo.anchor_stripe, geo.stripe)
+
+        # --- CAB (convs run through MIOpen for now; weights padded to the channels-last layout) ---
+        if self.local_connection:
+            c0, c2 = blk.conv.cab[0], blk.conv.cab[2]
+            se = blk.conv.cab[3].attention
+            w0 = torch.zeros(c0.weight.shape[0], CP, 3, 3, **f32)
+            w0[:, :C] = c0.weight.detach().float()
+            w2 = torch.zeros(CP, c2.weight.shape[1], 3, 3, **f32)
+            w2[:C] = c2.weight.detach().float()
+            pk.update(
+                cab0_w=w0.contiguous(memory_format=torch.channels_last), cab0_b=c0.bias.detach().float().to(dev),
+                cab2_w=w2.contiguous(memory_format=torch.channels_last), cab2_b=padv(c2.bias),
+                se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).to(dev), se1_b=se[1].bias.detach().float().to(dev),
+                se3_w=se[3].weight.detach().float().reshape(C, -1).to(dev), se3_b=se[3].bias.detach().float().to(dev),
+            )
+        return pk
+
+    def _plan(self, x_size, dev):
+        key = (tuple(x_size), str(dev))
+        plan = self._plan_cache.get(key)
+        if plan is not None:
+            return plan
+        C, CP = self.embed_dim, _pad32(self.embed_dim)
+        f32 = dict(dtype=torch.float32, device=dev)
+        sched = block_schedule(self.depths, self.num_heads_window, self.num_heads_stripe, self.window_size,
+                               self.stripe_size, self.stripe_groups, self.stripe_shift, self.df, x_size)
+
+        def padv(v):
+            out = torch.zeros(CP, **f32)
+            out[:C] = v.detach().float()
+            return out
+
+        def padconv(conv):
+            w = torch.zeros(CP, CP, 3, 3, **f32)
+            w[:C, :C] = conv.weight.detach().float()
+            return w.contiguous(memory_format=torch.channels_last), padv(conv.bias)
+
+        with torch.no_grad():
+            stages = []
+            for si, stage in enumerate(self.layers):
+                blocks = [self._pack_block(blk, sched[si][bi], dev) for bi, blk in enumerate(stage.blocks)]
+                cw, cb = padconv(stage.conv)
+                stages.append(dict(blocks=blocks, conv_w=cw, conv_b=cb))
+            plan = dict(
+                sched=sched, stages=stages,
+                ns_g=padv(self.norm_start.weight), ns_b=padv(self.norm_start.bias),
+                ne_g=padv(self.norm_end.weight), ne_b=padv(self.norm_end.bias),
+            )
+        self._plan_cache = {key: plan}  # one geometry at a time keeps memory bounded
+        return plan
+
+    # ---- forward -------------------------------------------------------------------------------
+    def check_image_size(self, x):
+        """grl.py:479-489."""
+        _, _, h, w = x.size()
+        ph = (self.pad_size - h % self.pad_size) % self.pad_size
+        pw = (self.pad_size - w % self.pad_size) % self.pad_size
+        try:
+            x = F.pad(x, (0, pw, 0, ph), "reflect")
+        except BaseException:
+            x = F.pad(x, (0, pw, 0, ph), "constant")
+        return x
+
+    def _cab(self, r, pk, B, H, W, CP):
+        """CAB branch (mixed_attn_block.py:948-983) on the channels-last token matrix."""
+        C = self.embed_dim
+        x4 = r.view(B, H, W, CP).permute(0, 3, 1, 2)
+        y = F.conv2d(x4, pk["cab0_w"], pk["cab0_b"], padding=1)
+        y = F.gelu(y)
+        y = F.conv2d(y, pk["cab2_w"], pk["cab2_b"], padding=1)  # (B, CP, H, W), pad channels 0
+        s = y.mean(dim=(2, 3))[:, :C]
+        s = F.relu(F.linear(s, pk["se1_w"], pk["se1_b"]))
+        s = torch.sigmoid(F.linear(s, pk["se3_w"], pk["se3_b"]))
+        y = y * F.pad(s, (0, CP - C))[:, :, None, None]
+        return y.permute(0, 2, 3, 1).reshape(B * H * W, CP)
+
+    def _block(self, r, pk, geo: BlockGeo, B, H, W):
+        C, CP = self.embed_dim, r.shape[1]
+        M = B * H * W
+        nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
+        d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
+        Ha, Wa = H // df, W // df
+        dev = r.device
+        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"])
+        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W))
+        att = torch.empty(M, (nh_w + nh_s) * 32, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(B * Ha * Wa, nh_s * 32, dtype=torch.bfloat16, device=dev)
+        ws, sh = geo.window, geo.window_shift
+        TG = ops.TokenGrid
+        # window attention (mixed_attn_block_efficient.py:128-165)
+        ops.attention(
+            TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w * 32, H, W, ws[0], ws[1], sh, sh),
+            TG(qkv, 2 * nh_w * 32, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
+            B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0, fixed_max=pk["fixed"],
+            ones_col=d_w if d_w < 32 else -1, head_dim=d_w,
+        )
+        # anchored stripe attention (mixed_attn_block_efficient.py:215-270)
+        s0 = 3 * nh_w * 32
+        st, ss = geo.stripe, geo.stripe_shift_size
+        ast, ass = geo.anchor_stripe, geo.anchor_shift_size
+        g_q = TG(qkv, s0, H, W, st[0], st[1], ss[0], ss[1])
+        g_k = TG(qkv, s0 + nh_s * 32, H, W, st[0], st[1], ss[0], ss[1])
+        g_v = TG(qkv, s0 + 2 * nh_s * 32, H, W, st[0], st[1], ss[0], ss[1])
+        g_a = TG(anc, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
+        g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
+        oc = d_s if d_s < 32 else -1
+        ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
+                      fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
+        ops.attention(g_q, g_a, g_y, TG(att, nh_w * 32, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
+                      table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
+        cab = self._cab(r, pk, B, H, W, CP) if self.local_connection else None
+        # x = x + res_scale * norm1(proj(attn)) + cab(x)   (efficient.py:543-548)
+        r1 = ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
+                        ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab)
+        # x = x + res_scale * norm2(mlp(x))                 (efficient.py:554)
+        h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU)
+        return ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
+                          ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1)
+
+    def forward_features(self, f):
+        """grl.py:491-504.  f: (B, C, H, W) fp32 -> (B, C, H, W)."""
+        B, C, H, W = f.shape
+        CP = _pad32(C)
+        plan = self._plan((H, W), f.device)
+        t0 = torch.zeros(B * H * W, CP, dtype=torch.float32, device=f.device)
+        t0[:, :C] = f.permute(0, 2, 3, 1).reshape(-1, C)
+        t = ops.layernorm(t0, plan["ns_g"], plan["ns_b"], C)
+        for si, st in enumerate(plan["stages"]):
+            r = t
+            for bi, pk in enumerate(st["blocks"]):
+                r = self._block(r, pk, plan["sched"][si][bi], B, H, W)
+            # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
+            c = F.conv2d(r.view(B, H, W, CP).permute(0, 3, 1, 2), st["conv_w"], st["conv_b"], padding=1)
+            t = c.permute(0, 2, 3, 1).reshape(B * H * W, CP) + t
+        t = ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
+        return t.view(B, H, W, CP)[..., :C].permute(0, 3, 1, 2)
+
+    def forward(self, x):
+        """grl.py:506-551."""
+        if not x.is_cuda:
+            raise RuntimeError(
+                "grl_image_restoration_amd.GRL runs only on an AMD GPU (MI355X/gfx950): got a CPU tensor and "
+                "there is deliberately no CPU fallback"
+            )
+        if self.training and torch.is_grad_enabled():
+            raise NotImplementedError("training (backward) through the HIP path is not available yet")
+        L.lib()  # fail loudly if the extension is missing
+        H, W = x.shape[2:]
+        x = self.check_image_size(x.float())
+        mean = self._mean.to(x.device, x.dtype)
+        x = (x - mean) * self.img_range
+
+        def conv(m, t):
+            return F.conv2d(t, m.weight, m.bias, padding=1)
+
+        if self.upsampler == "pixelshuffle":
+            f = conv(self.conv_first, x)
+            y = conv(self.conv_after_body, self.forward_features(f)) + f
+            y = F.leaky_relu(conv(self.conv_before_upsample[0], y), 0.01)
+            for m in self.upsample.up:
+                y = conv(m, y) if isinstance(m, nn.Conv2d) else m(y)
+            y = conv(self.conv_last, y)
+        elif self.upsampler == "pixelshuffledirect":
+            f = conv(self.conv_first, x)
+            y = conv(self.conv_after_body, self.forward_features(f)) + f
+            y = F.pixel_shuffle(conv(self.upsample.up[0], y), self.upscale)
+        elif self.upsampler == "nearest+conv":
+            f = conv(self.conv_first, x)
+            y = conv(self.conv_after_body, self.forward_features(f)) + f
+            y = F.leaky_relu(conv(self.conv_before_upsample[0], y), 0.01)
+            y = F.leaky_relu(conv(self.conv_up1, F.interpolate(y, scale_factor=2, mode="nearest")), 0.2)
+            y = F.leaky_relu(conv(self.conv_up2, F.interpolate(y, scale_factor=2, mode="nearest")), 0.2)
+            y = conv(self.conv_last, F.leaky_relu(conv(self.conv_hr, y), 0.2))
+        else:
+            f = conv(self.conv_first, x)
+            res = conv(self.conv_after_body, self.forward_features(f)) + f
+            y = x + conv(self.conv_last, res) if self.in_channels == self.out_channels else conv(self.conv_last, res)
+        y = y / self.img_range + mean
+        return y[:, :, : H * self.upscale, : W * self.upscale].contiguous()

@@ -1,0 +1,130 @@
+"""Tensor-level wrappers over the C ABI (include/grl_hip.h).
+
+These functions only validate tensors and fill the argument structs; all arithmetic happens in
+the HIP kernels.  Inputs must be CUDA (ROCm) tensors -- there is no CPU path.
+"""
+import ctypes as C
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import _lib as L
+
+
+def _dev_check(*ts):
+    for t in ts:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise RuntimeError(
+                "grl_image_restoration_amd: the hot path runs only on an AMD GPU (got a CPU tensor); "
+                "there is no CPU fallback"
+            )
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def linear(
+    a: torch.Tensor,
+    w: torch.Tensor,
+    bias: torch.Tensor,
+    *,
+    epi: int = L.EPI_PLAIN,
+    out_dtype=torch.bfloat16,
+    out: Optional[torch.Tensor] = None,
+    gscale: Optional[torch.Tensor] = None,
+    ln_g: Optional[torch.Tensor] = None,
+    ln_b: Optional[torch.Tensor] = None,
+    n_real: int = 0,
+    ln_eps: float = 1e-5,
+    res_scale: float = 1.0,
+    resid: Optional[torch.Tensor] = None,
+    add2: Optional[torch.Tensor] = None,
+    pool: Optional[Tuple[int, int, int]] = None,
+    M: Optional[int] = None,
+) -> torch.Tensor:
+    """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
+    stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
+    _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2)
+    assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.bfloat16
+    assert a.dtype in (torch.float32, torch.bfloat16) and bias.dtype == torch.float32
+    Npad, Kpad = w.shape
+    assert a.shape[1] >= Kpad and bias.numel() == Npad
+    if pool is not None:
+        df, H, W = pool
+        assert a.dtype == torch.float32 and a.shape[0] % (H * W) == 0
+        rows = a.shape[0] // (df * df)
+    else:
+        df, H, W = 1, 0, 0
+        rows = a.shape[0]
+    M = rows if M is None else M
+    if out is None:
+        out = torch.empty(M, Npad, dtype=out_dtype, device=a.device)
+    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= Npad
+    args = L.GrlLinearArgs(
+        a=_ptr(a), a_is_bf16=int(a.dtype == torch.bfloat16), lda=a.stride(0),
+        pool_df=df, pool_H=H, pool_W=W,
+        w=_ptr(w), bias=_ptr(bias), M=M, Npad=Npad, Kpad=Kpad, epi=epi,
+        gscale=_ptr(gscale), ln_g=_ptr(ln_g), ln_b=_ptr(ln_b), n_real=n_real, ln_eps=ln_eps,
+        res_scale=res_scale, resid=_ptr(resid), ldr=resid.stride(0) if resid is not None else 0,
+        add2=_ptr(add2), add2_is_bf16=int(add2 is not None and add2.dtype == torch.bfloat16),
+        ldadd2=add2.stride(0) if add2 is not None else 0,
+        out=_ptr(out), out_is_bf16=int(out.dtype == torch.bfloat16), ldo=out.stride(0),
+    )
+    if epi == L.EPI_GROUPNORM:
+        assert gscale is not None and gscale.dtype == torch.float32 and gscale.numel() == Npad // 32
+    if epi == L.EPI_LN_RES:
+        assert resid is not None and resid.dtype == torch.float32 and ln_g.numel() == Npad and ln_b.numel() == Npad
+        assert out.dtype == torch.float32
+    L.check(L.lib().grl_linear_fwd(L.stream_ptr(), C.byref(args)), "grl_linear_fwd")
+    return out
+
+
+@dataclass
+class TokenGrid:
+    """A bf16 token matrix viewed as windows: mirrors GrlTokenGrid."""
+
+    t: torch.Tensor          # [B*Himg*Wimg, ld] bf16
+    col0: int                # column of head 0's 32-wide slot
+    Himg: int
+    Wimg: int
+    wh: int
+    ww: int
+    shy: int = 0
+    shx: int = 0
+
+    def c(self) -> L.GrlTokenGrid:
+        assert self.t.dtype == torch.bfloat16 and self.t.dim() == 2 and self.t.stride(1) == 1
+        return L.GrlTokenGrid(ptr=_ptr(self.t), ld=self.t.stride(0), col0=self.col0, Himg=self.Himg, Wimg=self.Wimg,
+                              wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx)
+
+
+def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int, nh: int, table: torch.Tensor,
+              masked: bool, fixed_max: bool, ones_col: int, head_dim: int):
+    """softmax(q k^T + bias(+mask)) v over every window of every image; see grl_attention_fwd."""
+    _dev_check(q.t, k.t, v.t, o.t, table)
+    assert table.dtype == torch.float32 and table.is_contiguous() and table.dim() == 2 and table.shape[0] == nh
+    nwy, nwx = q.Himg // q.wh, q.Wimg // q.ww
+    assert q.t.shape[0] >= B * q.Himg * q.Wimg and k.t.shape[0] >= B * k.Himg * k.Wimg
+    args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
+                         trows=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
+                         head_dim=head_dim)
+    L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
+    return o.t
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: int, eps: float = 1e-5,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_check(x, gamma, beta, out)
+    assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
+    if out is None:
+        out = torch.empty_like(x)
+    L.check(
+        L.lib().grl_layernorm_fwd(L.stream_ptr(), _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma),
+                                  _ptr(beta), x.shape[0], n_real, x.shape[1], eps),
+        "grl_layernorm_fwd",
+    )
+    return out

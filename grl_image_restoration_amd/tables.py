@@ -1,0 +1,60 @@
+"""Input-independent attention tables, computed once per (weights, geometry) on the device.
+
+The reference recomputes ``16*sigmoid(cpb_mlp(coords_table))`` and gathers it through an
+(N1 x N2) index tensor for every block on every call (mixed_attn_block_efficient.py:41-47).
+At inference the table depends only on the weights, so it is built once here and handed to the
+attention kernel, which performs the gather as index arithmetic on an LDS copy.
+"""
+import math
+from typing import Sequence
+
+import torch
+import torch.nn.functional as F
+
+LOG2E = 1.4426950408889634
+
+
+def coords_table(q_or_window: Sequence[int], df: int = 1, device=None) -> torch.Tensor:
+    """Log-spaced relative coordinate table between a window and its anchor window
+    (closed form of models/common/ops.py:225-271 with pretrained_window_size = [0, 0]):
+    integer offsets from -(a-1)-(s-a)//2 to s-1-(s-a)//2 per axis, divided by the positive
+    extent, times 8, then sign(x)*log2(|x|+1)/log2(8).  Shape (rows, 2), row-major (h, w)."""
+    window = list(q_or_window)
+    aws = [w // df for w in window]
+    pos = [w - 1 - (w - a) // 2 for w, a in zip(window, aws)]
+    neg = [-(a - 1) - (w - a) // 2 for w, a in zip(window, aws)]
+    ch = torch.arange(neg[0], pos[0] + 1, dtype=torch.float32, device=device)
+    cw = torch.arange(neg[1], pos[1] + 1, dtype=torch.float32, device=device)
+    t = torch.stack(torch.meshgrid(ch, cw, indexing="ij"), dim=-1).reshape(-1, 2).contiguous()
+    t[:, 0] /= pos[0]
+    t[:, 1] /= pos[1]
+    t = t * 8
+    return torch.sign(t) * torch.log2(torch.abs(t) + 1.0) / math.log2(8)
+
+
+def clamped_scale(logit_scale: torch.Tensor) -> torch.Tensor:
+    """exp(min(logit_scale, ln 100)) per head (mixed_attn_block_efficient.py:39)."""
+    return torch.clamp(logit_scale.detach().float().reshape(-1), max=math.log(1.0 / 0.01)).exp()
+
+
+def bias_rows(cpb0_w, cpb0_b, cpb2_w, coords: torch.Tensor) -> torch.Tensor:
+    """16*sigmoid(Linear(512->nh, no bias)(ReLU(Linear(2->512)(coords)))) -> (rows, nh)."""
+    h = F.relu(F.linear(coords, cpb0_w.detach().float(), cpb0_b.detach().float()))
+    return 16.0 * torch.sigmoid(F.linear(h, cpb2_w.detach().float()))
+
+
+def kernel_table(bias: torch.Tensor, scale: torch.Tensor, fixed_max: bool) -> torch.Tensor:
+    """(rows, nh) natural-log-domain bias -> (nh, rows) table in the kernel's exp2 domain.
+    With ``fixed_max`` the per-head bound scale_h + max(bias_h) >= every logit is subtracted, so
+    exp2(acc) <= 1 without tracking a running maximum."""
+    t = bias.t().contiguous() * LOG2E
+    if fixed_max:
+        bound = (scale + bias.max(dim=0).values) * LOG2E
+        t = t - bound[:, None]
+    return t.contiguous()
+
+
+def fixed_max_is_safe(scale: torch.Tensor, limit: float = 60.0) -> bool:
+    """The bound is at most 2*scale + 16 above the smallest unmasked logit of a row; keep the
+    largest softmax numerator of every row far above fp32/bf16 underflow."""
+    return bool((2.0 * scale + 16.0).max().item() <= limit)

@@ -1,0 +1,115 @@
+/* grl_hip.h -- C ABI of the MI355X-native GRL hot path (libgrl_hip.so).
+ *
+ * The reference (ofsoundof/GRL-Image-Restoration) is pure Python: its "FFI" for this path is the
+ * list of torch ops issued inside models/networks/grl.py::GRL.forward and the modules under
+ * models/common/.  Each entry point below replaces one fused group of those ops
+ * and is what a ctypes / cpp_extension binding on the reference side would call
+ * (INTEGRATION.md shows the binding).  Conventions:
+ *
+ *   - plain pointers + sizes only; every pointer is a DEVICE pointer owned by the caller;
+ *   - no allocation, no host synchronisation; work is enqueued on `stream` (a hipStream_t,
+ *     passed as void* so the header needs no HIP include; NULL = default stream);
+ *   - return value: 0 on success, a hipError_t (> 0) from the launch, or a GRL_ERR_* (< 0);
+ *   - activations are channels-last token matrices [B*H*W, Cpad] with Cpad = channels rounded
+ *     up to a multiple of 32 and the pad channels held at zero.
+ */
+#ifndef GRL_HIP_H
+#define GRL_HIP_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GRL_ERR_BAD_ARG (-1)
+#define GRL_ERR_UNSUPPORTED (-2)
+#define GRL_ABI_VERSION 1
+
+/* ---------------------------------------------------------------------------------------------
+ * Token-wise linear layer with fused epilogue.
+ *   replaces  QKVProjection.forward        models/common/mixed_attn_block.py:669-676
+ *             AnchorLinear.forward         models/common/mixed_attn_block.py:727-736 (pool_df > 1)
+ *             MixedAttention.proj + norm1  models/common/mixed_attn_block_efficient.py:379,543-548
+ *             Mlp.forward + norm2          models/common/swin_v1_block.py:37-43, efficient.py:554
+ * ------------------------------------------------------------------------------------------- */
+enum { GRL_EPI_PLAIN = 0, GRL_EPI_GELU = 1, GRL_EPI_GROUPNORM = 2, GRL_EPI_LN_RES = 3 };
+
+typedef struct GrlLinearArgs {
+    const void* a;          /* [M, lda] fp32 (a_is_bf16=0) or bf16 activations                      */
+    int32_t a_is_bf16;
+    int64_t lda;            /* elements per A row (multiple of 8, >= Kpad)                          */
+    int32_t pool_df;        /* >1: A row m is the mean of a df x df block of rows of a [B,H,W,lda]  */
+    int32_t pool_H, pool_W; /*     fp32 image (AnchorLinear avg-pool); M = B*(H/df)*(W/df)          */
+    const void* w;          /* bf16 [Npad, Kpad], zero padded (row n = output channel n)            */
+    const float* bias;      /* [Npad]                                                               */
+    int32_t M, Npad, Kpad;
+    int32_t epi;            /* GRL_EPI_*                                                            */
+    const float* gscale;    /* GROUPNORM: [Npad/32]; g!=0: L2-normalise the 32-col group, times g;  */
+                            /*            g==0: pass through                                        */
+    const float* ln_g;      /* LN_RES: gamma/beta [Npad], n_real real channels, eps, residual scale */
+    const float* ln_b;
+    int32_t n_real;
+    float ln_eps;
+    float res_scale;
+    const float* resid;     /* LN_RES: fp32 residual [M, ldr]                                       */
+    int64_t ldr;
+    const void* add2;       /* LN_RES: optional extra branch (CAB output) added after the norm      */
+    int32_t add2_is_bf16;
+    int64_t ldadd2;
+    void* out;              /* [M, ldo] bf16 or fp32                                                */
+    int32_t out_is_bf16;
+    int64_t ldo;
+} GrlLinearArgs;
+
+int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
+
+/* ---------------------------------------------------------------------------------------------
+ * Cosine window / anchored-stripe attention (one call = one softmax(QK^T)V over all windows).
+ *   replaces  WindowAttention.forward        models/common/mixed_attn_block_efficient.py:128-165
+ *             AnchorStripeAttention.forward  models/common/mixed_attn_block_efficient.py:215-270
+ *             (called twice: anchors->window tokens, then window tokens->anchors)
+ *             Attention.attn / AffineTransform  :77-94 / :36-58
+ *             roll / window_partition / window_reverse / masks / relative index
+ *                                            models/common/ops.py:36-157,352-375 (all as index math)
+ * Operands are bf16 token matrices with one 32-wide slot per head:
+ *   q: already L2-normalised and multiplied by logit_scale*log2(e); k: L2-normalised;
+ *   v: raw values, slot column `ones_col` (>= head_dim) holding 1.0 so that the row sum of the
+ *      softmax weights falls out of the PV product (ones_col < 0: summed explicitly).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GrlTokenGrid {
+    const void* ptr;      /* bf16 base                                                              */
+    int64_t ld;           /* elements per token row                                                 */
+    int32_t col0;         /* element offset of head 0's slot inside a token row                     */
+    int32_t Himg, Wimg;   /* token image size                                                       */
+    int32_t wh, ww;       /* window (stripe) size on this grid                                      */
+    int32_t shy, shx;     /* cyclic shift (rolled[y] = orig[(y+sh) % H]); 0 = none                  */
+} GrlTokenGrid;
+
+typedef struct GrlAttnArgs {
+    GrlTokenGrid q, k, v, o; /* v shares k's grid geometry; o shares q's                            */
+    int32_t B, nh;
+    int32_t nwy, nwx;        /* windows per image (same on both grids)                              */
+    const float* table;      /* [nh, trows] fp32: bias*log2e (minus the per-head bound if fixed_max)*/
+    int32_t trows;           /* (q.wh + k.wh - 1) * (q.ww + k.ww - 1)                               */
+    int32_t masked;          /* 1: apply the shifted-window region mask (-100)                      */
+    int32_t fixed_max;       /* 1: table carries -(bound); no running max needed                    */
+    int32_t ones_col;        /* see above                                                           */
+    int32_t head_dim;        /* real head dim (<= 32)                                               */
+} GrlAttnArgs;
+
+int grl_attention_fwd(void* stream, const GrlAttnArgs* args);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row LayerNorm on a padded token matrix (norm_start / norm_end, models/networks/grl.py:494,501).
+ * ------------------------------------------------------------------------------------------- */
+int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                      const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps);
+
+/* Library self-description (used by the loader to refuse a stale build). */
+int grl_abi_version(void);
+const char* grl_build_info(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GRL_HIP_H */

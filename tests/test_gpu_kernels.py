@@ -1,0 +1,223 @@
+"""GPU parity tests of the individual HIP kernels, called through the C ABI (ctypes).
+
+The checker is the oracle's own index / mask / table machinery (pinned to the reference in
+tests/test_oracle_pinned.py) evaluated in float64 on the *same bf16-rounded operands* the kernel
+sees, so the tolerances below only cover bf16 rounding of the softmax weights / outputs:
+  linear      : 2e-2 relative to row scale for bf16 outputs, 1e-3 for fp32 LayerNorm outputs
+  attention   : 1.5e-2 max-abs on outputs of magnitude <= ~1 (bf16 P and bf16 output rounding)
+"""
+import math
+import zlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import grl_oracle as O
+
+pytestmark = pytest.mark.gpu
+
+LOG2E = 1.4426950408889634
+
+
+def _dev():
+    return torch.device("cuda:0")
+
+
+# ------------------------------------------------------------------------------------------------
+# linear
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("M,K,N", [(1000, 192, 576), (513, 64, 384), (300, 128, 64), (777, 384, 192), (256, 192, 96)])
+def test_linear_groupnorm_and_plain(M, K, N):
+    from grl_image_restoration_amd import _lib as L, ops
+
+    g = torch.Generator().manual_seed(0)
+    a = torch.randn(M, K, generator=g)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    b = 0.1 * torch.randn(N, generator=g)
+    gs = torch.rand(N // 32, generator=g) * 10
+    gs[::3] = 0.0  # pass-through groups
+    ref = a.to(torch.bfloat16).double() @ w.double().t() + b.double()
+    out = ops.linear(a.to(_dev()), w.to(_dev()), b.to(_dev()), epi=L.EPI_PLAIN, out_dtype=torch.float32)
+    assert (out.cpu().double() - ref).abs().max() < 2e-3
+    refn = ref.view(M, N // 32, 32)
+    nrm = refn.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    refn = torch.where(gs.view(1, -1, 1) != 0, refn / nrm * gs.view(1, -1, 1).double(), refn).reshape(M, N)
+    outn = ops.linear(a.to(_dev()), w.to(_dev()), b.to(_dev()), epi=L.EPI_GROUPNORM, gscale=gs.to(_dev()))
+    assert outn.dtype == torch.bfloat16
+    err = (outn.cpu().double() - refn).abs().max().item()
+    assert err < 2e-2 * max(1.0, refn.abs().max().item() / 2), err
+
+
+@pytest.mark.parametrize("M,K,N,nreal", [(1000, 192, 192, 180), (300, 384, 192, 180), (513, 128, 128, 128), (300, 128, 64, 64)])
+def test_linear_ln_residual_and_gelu(M, K, N, nreal):
+    from grl_image_restoration_amd import _lib as L, ops
+
+    g = torch.Generator().manual_seed(1)
+    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    w[nreal:] = 0
+    b = 0.1 * torch.randn(N, generator=g)
+    b[nreal:] = 0
+    gam = 1 + 0.1 * torch.randn(N, generator=g)
+    bet = 0.1 * torch.randn(N, generator=g)
+    resid = torch.randn(M, N, generator=g)
+    resid[:, nreal:] = 0
+    add2 = torch.randn(M, N, generator=g)
+    add2[:, nreal:] = 0
+    y = a.double() @ w.double().t() + b.double()
+    ln = F.layer_norm(y[:, :nreal], (nreal,), gam[:nreal].double(), bet[:nreal].double(), 1e-5)
+    ref = torch.zeros(M, N, dtype=torch.float64)
+    ref[:, :nreal] = resid[:, :nreal].double() + 0.5 * ln + add2[:, :nreal].double()
+    d = _dev()
+    out = ops.linear(a.to(d), w.to(d), b.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=gam.to(d), ln_b=bet.to(d),
+                     n_real=nreal, res_scale=0.5, resid=resid.to(d), add2=add2.to(d))
+    assert (out.cpu().double() - ref).abs().max() < 1e-3
+    assert out[:, nreal:].abs().max().item() == 0.0
+    outg = ops.linear(a.to(d), w.to(d), b.to(d), epi=L.EPI_GELU)
+    refg = F.gelu(y)
+    assert (outg.cpu().double() - refg).abs().max() < 2e-2
+
+
+def test_linear_pooled_anchor():
+    """AnchorLinear: avg-pool df x df (mixed_attn_block.py:727-736) fused into the A load."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    B, H, W, CP, df, N = 2, 16, 24, 192, 4, 96
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(B * H * W, CP, generator=g)
+    w = (torch.randn(N, CP, generator=g) / math.sqrt(CP)).to(torch.bfloat16)
+    b = 0.1 * torch.randn(N, generator=g)
+    pooled = F.avg_pool2d(x.view(B, H, W, CP).permute(0, 3, 1, 2), df, df).permute(0, 2, 3, 1).reshape(-1, CP)
+    ref = pooled.to(torch.bfloat16).double() @ w.double().t() + b.double()
+    d = _dev()
+    out = ops.linear(x.to(d), w.to(d), b.to(d), epi=L.EPI_PLAIN, out_dtype=torch.float32, pool=(df, H, W))
+    assert out.shape[0] == B * (H // df) * (W // df)
+    assert (out.cpu().double() - ref).abs().max() < 1e-2  # pooled value may round differently by 1 bf16 ulp
+
+
+def test_layernorm():
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(1001, 192, generator=g) * 3 + 1
+    x[:, 180:] = 0
+    gam, bet = torch.randn(192, generator=g), torch.randn(192, generator=g)
+    ref = F.layer_norm(x[:, :180], (180,), gam[:180], bet[:180], 1e-5)
+    d = _dev()
+    out = ops.layernorm(x.to(d), gam.to(d), bet.to(d), 180).cpu()
+    assert (out[:, :180] - ref).abs().max() < 2e-5
+    assert out[:, 180:].abs().max() == 0
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def _slots(x, d, ones=False):
+    """(..., nh, d) float -> (..., nh*32) bf16 slots (zero padded; optional constant-1 column)."""
+    pad = torch.zeros(*x.shape[:-1], 32)
+    pad[..., :d] = x
+    if ones and d < 32:
+        pad[..., d] = 1.0
+    return pad.reshape(*x.shape[:-2], -1).to(torch.bfloat16)
+
+
+def _windows(t, B, H, W, win, shift, nh):
+    """token matrix (B*H*W, nh*32) -> (B_, nh, N, 32) in the reference's roll+partition order."""
+    x = t.float().view(B, H, W, nh * 32)
+    if shift[0] or shift[1]:
+        x = torch.roll(x, shifts=(-shift[0], -shift[1]), dims=(1, 2))
+    x = O.partition(x, win).reshape(-1, win[0] * win[1], nh, 32)
+    return x.permute(0, 2, 1, 3)
+
+
+CASES = [
+    # name, mode, (H, W), window/stripe, shift, df, nh, d
+    ("win8_shift", "w", (32, 32), (8, 8), (4, 4), 1, 3, 30),
+    ("win8_noshift", "w", (16, 24), (8, 8), (0, 0), 1, 2, 32),
+    ("win32_shift", "w", (64, 64), (32, 32), (16, 16), 1, 3, 30),
+    ("win12_ragged", "w", (24, 36), (12, 12), (6, 6), 1, 3, 30),
+    ("win16_tiny", "w", (32, 32), (16, 16), (8, 8), 1, 2, 16),
+    ("a2w_64_df2", "a2w", (128, 128), (64, 64), (32, 32), 2, 3, 30),
+    ("w2a_64_df2", "w2a", (128, 128), (64, 64), (32, 32), 2, 3, 30),
+    ("a2w_64_noshift", "a2w", (64, 128), (64, 64), (0, 0), 4, 2, 32),
+    ("w2a_8x16_df4", "w2a", (16, 32), (8, 16), (4, 8), 4, 3, 30),     # 8 anchors (< one key tile)
+    ("a2w_8x16_df4", "a2w", (16, 32), (8, 16), (4, 8), 4, 3, 30),
+    ("w2a_16x8_df4", "w2a", (32, 16), (16, 8), (8, 4), 4, 3, 30),     # anchors 4x2 -> generic gather path
+    ("a2w_48x96_df4", "a2w", (96, 96), (48, 96), (24, 48), 4, 3, 30),
+    ("w2a_48x96_df4", "w2a", (96, 96), (48, 96), (24, 48), 4, 3, 30),
+    ("w2a_groups_shift_one_axis", "w2a", (32, 32), (8, 32), (4, 0), 4, 3, 30),
+]
+
+
+@pytest.mark.parametrize("fixed", [True, False])
+@pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
+def test_attention_vs_oracle_indexing(case, fixed):
+    from grl_image_restoration_amd import ops, tables
+
+    name, mode, (H, W), win, shift, df, nh, d = case
+    B = 2
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000)
+    awin, ashift = (win[0] // df, win[1] // df), (shift[0] // df, shift[1] // df)
+    Ha, Wa = H // df, W // df
+    scale = torch.rand(nh, generator=g) * 12 + 4
+    if mode == "w":
+        qg = kg = (H, W, win, shift)
+    elif mode == "a2w":
+        qg, kg = (Ha, Wa, awin, ashift), (H, W, win, shift)
+    else:
+        qg, kg = (H, W, win, shift), (Ha, Wa, awin, ashift)
+
+    def rnd(Hh, Ww):
+        return torch.randn(B * Hh * Ww, nh, d, generator=g)
+
+    qf = F.normalize(rnd(qg[0], qg[1]), dim=-1) * (scale * LOG2E).view(1, nh, 1)
+    kf = F.normalize(rnd(kg[0], kg[1]), dim=-1)
+    vf = rnd(kg[0], kg[1])
+    ones = d < 32
+    qs, ks, vs = _slots(qf, d), _slots(kf, d), _slots(vf, d, ones)
+    rows = (qg[2][0] + kg[2][0] - 1) * (qg[2][1] + kg[2][1] - 1)
+    bias = torch.rand(rows, nh, generator=g) * 16
+    tab = tables.kernel_table(bias, scale, fixed)
+    masked = shift[0] > 0 or shift[1] > 0
+    if mode == "w":
+        index = O.rel_index(win)
+        mask = O.shift_mask((H, W), win, shift, mode="w") if masked else None
+    else:
+        index = O.rel_index(win, df, mode == "w2a")
+        mask = O.shift_mask((H, W), win, shift, df, mode) if masked else None
+    assert int(index.max()) == rows - 1 and int(index.min()) == 0
+
+    qw = _windows(qs, B, qg[0], qg[1], qg[2], qg[3], nh)
+    kw = _windows(ks, B, kg[0], kg[1], kg[2], kg[3], nh)
+    vw = _windows(vs, B, kg[0], kg[1], kg[2], kg[3], nh)
+    s = qw.double() @ kw.double().transpose(-1, -2)
+    s = s + tab.double()[:, index.reshape(-1)].view(nh, *index.shape).unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        s = (s.view(B, nW, nh, *index.shape) + (mask.double() * LOG2E).unsqueeze(1).unsqueeze(0)).view(-1, nh, *index.shape)
+    s = s - s.max(dim=-1, keepdim=True).values
+    p = torch.exp2(s)
+    ref = (p @ vw.double()) / p.sum(-1, keepdim=True)  # (B_, nh, Nq, 32)
+    ref = ref.permute(0, 2, 1, 3).reshape(-1, qg[2][0], qg[2][1], nh * 32)
+    ref = O.unpartition(ref, qg[2], (qg[0], qg[1]))
+    if qg[3][0] or qg[3][1]:
+        ref = torch.roll(ref, shifts=(qg[3][0], qg[3][1]), dims=(1, 2))
+    ref = ref.reshape(B * qg[0] * qg[1], nh, 32)[..., :d]
+
+    dev = _dev()
+    TG = ops.TokenGrid
+    qd, kd, vd = qs.to(dev), ks.to(dev), vs.to(dev)
+    out = torch.zeros(B * qg[0] * qg[1], nh * 32, dtype=torch.bfloat16, device=dev)
+    ops.attention(
+        TG(qd, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
+        TG(kd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
+        TG(vd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
+        TG(out, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
+        B=B, nh=nh, table=tab.to(dev), masked=masked, fixed_max=fixed, ones_col=d if ones else -1, head_dim=d,
+    )
+    torch.cuda.synchronize()
+    got = out.float().cpu().view(-1, nh, 32)[..., :d]
+    err = (got.double() - ref).abs().max().item()
+    print(f"{name} fixed={fixed}: max|err| = {err:.3e} (ref max {ref.abs().max().item():.2f})")
+    assert err < 1.5e-2, err

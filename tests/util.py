@@ -1,0 +1,54 @@
+"""Shared helpers for the parity tests (test infrastructure; may import oracle/)."""
+import json
+import os
+
+import numpy as np
+import torch
+
+from oracle import grl_oracle as O
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def golden_names():
+    return sorted(f[:-4] for f in os.listdir(GOLDEN_DIR) if f.endswith(".npz"))
+
+
+def load_golden(name):
+    z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
+    meta = json.loads(str(z["meta"]))
+    return meta, {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+
+
+def product_shapes(cfg):
+    from grl_image_restoration_amd import GRL
+
+    m = GRL(**cfg)
+    return {k: tuple(v.shape) for k, v in m.state_dict().items()}
+
+
+def ref_attention_slots(q, k, v, table2, index, mask, head_dim):
+    """fp32 reference of what grl_attention_fwd computes from its *already prepared* operands.
+
+    q (B_, nh, Nq, 32) = normalised*scale*log2e, k (B_, nh, Nk, 32) normalised, v raw, all holding
+    the bf16-rounded values the kernel sees; table2 (nh, rows) in the exp2 domain; index (Nq, Nk);
+    mask (nW, Nq, Nk) of 0/-100 or None.  Returns (B_, nh, Nq, 32) float32.
+    """
+    B_, nh, Nq, _ = q.shape
+    Nk = k.shape[2]
+    s = q.double() @ k.double().transpose(-1, -2)
+    bias = table2.double()[:, index.reshape(-1)].view(nh, Nq, Nk)
+    s = s + bias.unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        s = (s.view(B_ // nW, nW, nh, Nq, Nk) + (mask.double() * O.math.log2(math_e())).unsqueeze(1).unsqueeze(0)).view(-1, nh, Nq, Nk)
+    s = s - s.max(dim=-1, keepdim=True).values
+    p = torch.exp2(s)
+    o = (p @ v.double()) / p.sum(-1, keepdim=True)
+    return o.float()
+
+
+def math_e():
+    import math
+
+    return math.e
