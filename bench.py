@@ -1,0 +1,179 @@
+#!/usr/bin/env python3
+"""Throughput benchmark of the GRL hot path on MI355X (contract in the task statement).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+
+Workload (BASELINE.json configs[2], the configuration the metric is quoted on): GRL-Base x4 SR,
+released-checkpoint geometry (window 32, stripes 64x64, anchor /2), batches of 256x256 LQ tiles,
+synthetic uniform-random pixels, random-init weights.  One step = one forward of `--tiles` tiles
+per GPU with the tiles already resident in HBM.  Tiles are independent units: ranks shard them
+with no data-path collective (weak scaling); the only collectives are the timing barrier/max.
+
+Prints ONE JSON line on rank 0 with the contract fields plus
+  roofline     : the dominant kernel (cosine window/stripe attention, MFMA-bound): algorithmic
+                 FLOPs per launch / its mean launch duration measured with HIP events on the
+                 launching stream during the timed steps, against the 2.5 PFLOP/s bf16 dense peak
+  cpu_baseline : the CPU oracle (a torch-fp32 port of the reference forward) timed on this box's
+                 host cores on a bounded sample (one 64x64 LQ tile of the same network).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+
+
+def attention_flops_per_launch(cfg, tiles, hw):
+    """each of the three attention launches of a block (window, anchors->
+    stripe, stripe->anchors) does 2 * L * N_keys * C FLOPs per tile (QK^T + PV over C/2 channels)."""
+    L = hw[0] * hw[1]
+    C = cfg["embed_dim"]
+    ws = cfg["window_size"]
+    df = cfg["anchor_window_down_factor"]
+    n_w = ws * ws
+    n_anchor = (cfg["stripe_size"][0] // df) * (cfg["stripe_size"][1] // df)
+    win = 2 * L * n_w * C
+    a2w = 2 * L * n_anchor * C
+    return tiles * (win + 2 * a2w) / 3.0  # mean over the three launches of a block
+
+
+def cpu_baseline(cfg):
+    """Reference algorithm on the host cores: oracle/grl_oracle.py (kind 'port'), one 64x64 LQ tile."""
+    from oracle import grl_oracle as O
+
+    from grl_image_restoration_amd import GRL
+
+    torch.manual_seed(0)
+    c = dict(cfg)
+    c["img_size"] = 64
+    m = GRL(**c)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(1))
+    t0 = time.time()
+    with torch.no_grad():
+        O.grl_forward(x, c, sd)
+    dt = time.time() - t0
+    return {
+        "value": round(64 * 64 / dt / 1e6, 6),
+        "unit": "LQ megapixels/s",
+        "cores": torch.get_num_threads(),
+        "kind": "port",
+        "sample": f"1 forward of one 64x64 LQ tile, same network/geometry, fp32 torch CPU, {dt:.1f} s "
+                  "(a 256x256 tile is 16x the pixels)",
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tiles", type=int, default=4, help="256x256 LQ tiles per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from grl_image_restoration_amd import GRL, baseline_config, ops
+
+    cfg = baseline_config(3)
+    torch.manual_seed(0)
+    model = GRL(**cfg).eval().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    x = torch.rand(args.tiles, 3, 256, 256, generator=g).to(dev)
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        ops.profile_begin()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            y = model(x)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        prof = ops.profile_end()
+    assert torch.isfinite(y).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    if rank == 0:
+        mp = world * args.tiles * 256 * 256 * args.steps / dt / 1e6
+        att = prof.get("attention", [])
+        att_ms = sum(att) / max(len(att), 1)
+        fl = attention_flops_per_launch(cfg, args.tiles, (256, 256))
+        ach = fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "attention_traffic.json")
+        if os.path.isfile(tpath):
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "LQ megapixels/s, GRL-Base x4 SR, 256x256 LQ tiles",
+            "value": round(mp, 4),
+            "unit": "LQ megapixels/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "BASELINE configs[2]: GRL-Base x4 SR, 256x256 LQ tiles, ckpt geometry "
+                            "(window 32, stripe 64x64, anchor /2), random-init weights",
+                "tiles_per_gpu_per_step": args.tiles,
+                "hr_megapixels_per_s": round(mp * 16, 2),
+                "gflop_per_tile": 5468.5,
+                "model_tflops": round(5468.5e9 * world * args.tiles * args.steps / dt / 1e12, 2),
+                "parallelism": f"tile-sharded x{world}, no data-path collective",
+            },
+            "roofline": {
+                "kernel": "attn_kernel (cosine window / anchored-stripe attention)",
+                "bound": "mfma",
+                "achieved": round(ach, 2),
+                "peak": PEAK_BF16_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "traffic": traffic,
+                "launches_timed": len(att),
+                "mean_launch_ms": round(att_ms, 4),
+                "flops_per_launch": fl,
+                "time_share_of_step": round(sum(att) / (dt * 1e3), 3) if att else None,
+            },
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg)
+        print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

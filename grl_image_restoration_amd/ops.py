@@ -12,6 +12,41 @@ import torch
 from . import _lib as L
 
 
+# ---- optional per-kernel timing with HIP events on the launching stream (used by bench.py) ----
+_PROFILE = None
+
+
+def profile_begin():
+    """Start collecting (start, stop) event pairs around every C-ABI kernel launch."""
+    global _PROFILE
+    _PROFILE = {}
+
+
+def profile_end():
+    """Stop collecting; returns {kernel: [ms, ...]} (synchronises the device)."""
+    global _PROFILE
+    rec, _PROFILE = _PROFILE, None
+    torch.cuda.synchronize()
+    return {k: [a.elapsed_time(b) for a, b in v] for k, v in (rec or {}).items()}
+
+
+class _timed:
+    def __init__(self, name):
+        self.name = name
+
+    def __enter__(self):
+        if _PROFILE is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.b = torch.cuda.Event(enable_timing=True)
+            self.a.record()
+
+    def __exit__(self, *exc):
+        if _PROFILE is not None:
+            self.b.record()
+            _PROFILE.setdefault(self.name, []).append((self.a, self.b))
+        return False
+
+
 def _dev_check(*ts):
     for t in ts:
         if t is None:
@@ -79,7 +114,8 @@ def linear(
     if epi == L.EPI_LN_RES:
         assert resid is not None and resid.dtype == torch.float32 and ln_g.numel() == Npad and ln_b.numel() == Npad
         assert out.dtype == torch.float32
-    L.check(L.lib().grl_linear_fwd(L.stream_ptr(), C.byref(args)), "grl_linear_fwd")
+    with _timed("linear"):
+        L.check(L.lib().grl_linear_fwd(L.stream_ptr(), C.byref(args)), "grl_linear_fwd")
     return out
 
 
@@ -112,7 +148,8 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
     args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
                          trows=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
                          head_dim=head_dim)
-    L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
+    with _timed("attention"):
+        L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
     return o.t
 
 

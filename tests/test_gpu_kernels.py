@@ -4,7 +4,7 @@ The checker is the oracle's own index / mask / table machinery (pinned to the re
 tests/test_oracle_pinned.py) evaluated in float64 on the *same bf16-rounded operands* the kernel
 sees, so the tolerances below only cover bf16 rounding of the softmax weights / outputs:
   linear      : 2e-2 relative to row scale for bf16 outputs, 1e-3 for fp32 LayerNorm outputs
-  attention   : 1.5e-2 max-abs on outputs of magnitude <= ~1 (bf16 P and bf16 output rounding)
+  attention   : 6e-3 x max|output| (bf16 softmax weights and bf16 output rounding, 2^-8 ulp)
 """
 import math
 import zlib
@@ -73,7 +73,8 @@ def test_linear_ln_residual_and_gelu(M, K, N, nreal):
     out = ops.linear(a.to(d), w.to(d), b.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=gam.to(d), ln_b=bet.to(d),
                      n_real=nreal, res_scale=0.5, resid=resid.to(d), add2=add2.to(d))
     assert (out.cpu().double() - ref).abs().max() < 1e-3
-    assert out[:, nreal:].abs().max().item() == 0.0
+    if nreal < N:
+        assert out[:, nreal:].abs().max().item() == 0.0
     outg = ops.linear(a.to(d), w.to(d), b.to(d), epi=L.EPI_GELU)
     refg = F.gelu(y)
     assert (outg.cpu().double() - refg).abs().max() < 2e-2
@@ -220,4 +221,4 @@ def test_attention_vs_oracle_indexing(case, fixed):
     got = out.float().cpu().view(-1, nh, 32)[..., :d]
     err = (got.double() - ref).abs().max().item()
     print(f"{name} fixed={fixed}: max|err| = {err:.3e} (ref max {ref.abs().max().item():.2f})")
-    assert err < 1.5e-2, err
+    assert err < 6e-3 * max(1.0, ref.abs().max().item()), err  # bf16 output: half-ulp 2^-9 relative + bf16 P
