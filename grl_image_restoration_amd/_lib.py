@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
 
@@ -18,6 +18,9 @@ EXPORTS = [
     "grl_linear_fwd",
     "grl_attention_fwd",
     "grl_layernorm_fwd",
+    "grl_conv3x3_fwd",
+    "grl_conv3x3_num_workgroups",
+    "grl_se_scale_fwd",
     "grl_abi_version",
     "grl_build_info",
 ]
@@ -48,6 +51,8 @@ class GrlLinearArgs(C.Structure):
         ("add2", C.c_void_p),
         ("add2_is_bf16", C.c_int32),
         ("ldadd2", C.c_int64),
+        ("add2_scale", C.c_void_p),
+        ("rows_per_image", C.c_int32),
         ("out", C.c_void_p),
         ("out_is_bf16", C.c_int32),
         ("ldo", C.c_int64),
@@ -93,6 +98,7 @@ class GrlConvArgs(C.Structure):
         ("x_is_bf16", C.c_int32),
         ("ldx", C.c_int64),
         ("w", C.c_void_p),
+        ("w_tap_stride", C.c_int64),
         ("bias", C.c_void_p),
         ("B", C.c_int32),
         ("H", C.c_int32),
@@ -100,12 +106,16 @@ class GrlConvArgs(C.Structure):
         ("Cin_pad", C.c_int32),
         ("Cout_pad", C.c_int32),
         ("act", C.c_int32),
+        ("slope", C.c_float),
         ("resid", C.c_void_p),
         ("ldr", C.c_int64),
-        ("pool", C.c_void_p),
+        ("pool_partial", C.c_void_p),
         ("out", C.c_void_p),
         ("out_is_bf16", C.c_int32),
         ("ldo", C.c_int64),
+        ("shuffle_r", C.c_int32),
+        ("shuffle_cg", C.c_int32),
+        ("shuffle_ij0", C.c_int32),
     ]
 
 
@@ -137,9 +147,13 @@ def lib():
         C.c_int32, C.c_int32, C.c_int32, C.c_float,
     ]
     L.grl_layernorm_fwd.restype = C.c_int
-    if hasattr(L, "grl_conv3x3_fwd"):
-        L.grl_conv3x3_fwd.argtypes = [C.c_void_p, C.POINTER(GrlConvArgs)]
-        L.grl_conv3x3_fwd.restype = C.c_int
+    L.grl_conv3x3_fwd.argtypes = [C.c_void_p, C.POINTER(GrlConvArgs)]
+    L.grl_conv3x3_fwd.restype = C.c_int
+    L.grl_conv3x3_num_workgroups.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.grl_conv3x3_num_workgroups.restype = C.c_int
+    L.grl_se_scale_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
+                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.grl_se_scale_fwd.restype = C.c_int
     _lib = L
     return L
 

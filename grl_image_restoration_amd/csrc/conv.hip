@@ -1,0 +1,292 @@
+// 3x3 convolutions of the GRL path as bf16 MFMA implicit GEMM over an LDS halo tile (gfx950).
+//
+// Replaces:
+//   CAB: conv3x3 C->C/4, GELU, conv3x3 C/4->C + the global-average pool of ChannelAttention
+//        (models/common/mixed_attn_block.py:948-983)
+//   TransformerStage.conv / conv_after_body (+ residual)   models/networks/grl.py:137,168,348,516
+//   conv_first, conv_before_upsample(+LeakyReLU), Upsample convs (+PixelShuffle), conv_last
+//        models/networks/grl.py:293,352-379 ; models/common/upsample.py:16-19,45-46
+//
+// Layout: activations are channels-last token matrices [B*H*W, Cpad]; weights are pre-packed to
+// bf16 [9 taps][CoutP][CinP] (K contiguous).  One workgroup (8 waves) produces an 8 x 32 pixel
+// tile for up to 192 output channels.  Input channels are processed in chunks of KC (64/32):
+// the (8+2) x (32+2) halo tile of the chunk is converted to bf16 once and staged in LDS, and for
+// each of the 9 taps the [CoutP][KC] weight slice streams through a double-buffered LDS slot
+// (global loads for tap t+1 are issued before the MFMAs of tap t).  The product is computed
+// transposed (rows = output channel, cols = pixel) exactly like csrc/linear.hip so a lane owns 4
+// consecutive output channels of one pixel.  Epilogue: bias, GELU / LeakyReLU, residual, optional
+// per-workgroup channel sums (deterministic two-stage global average pool for the SE block) and an
+// optional pixel-shuffle store.
+#include "common.h"
+#include "grl_hip_internal.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32;       // output tile (pixels); wave w owns tile row w
+constexpr int CWAVES = 8;
+constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
+
+template <int KC, int NT>
+__global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int ROWB = KC * 2 + 16;                 // padded row (bytes) for pixels and weight rows
+    constexpr int KS = KC / 32;                       // MFMA k-steps per chunk
+    constexpr int IN_BYTES = HALO_H * HALO_W * ROWB;
+    constexpr int WT_BYTES = NT * 16 * ROWB;          // one tap's weight slice
+    constexpr int SEG_ROW = KC / 8;                   // 16-B segments per row
+    constexpr int WSEGS = NT * 16 * SEG_ROW;
+    constexpr int WPT = (WSEGS + CWAVES * 64 - 1) / (CWAVES * 64);  // weight segments per thread
+    char* in_s = smem;
+    char* wt_s = smem + IN_BYTES;                     // 2 buffers
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int x0 = blockIdx.x * TW, y0 = blockIdx.y * TH, b = blockIdx.z;
+    const int nkc = p.CinP / KC;
+
+    f32x4 acc[2][NT];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
+
+    bf16x8 wpre[WPT];
+    auto load_w = [&](int tap, int kc) {
+        const bf16* src = (const bf16*)p.w + (int64_t)tap * p.w_tap_stride + kc * KC;
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int s = tid + i * CWAVES * 64;
+            if (s < WSEGS) {
+                const int rr = s / SEG_ROW, cc = s % SEG_ROW;
+                wpre[i] = *(const bf16x8*)(src + (int64_t)rr * p.CinP + cc * 8);
+            }
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < WPT; ++i) {
+            const int s = tid + i * CWAVES * 64;
+            if (s < WSEGS) {
+                const int rr = s / SEG_ROW, cc = s % SEG_ROW;
+                *(bf16x8*)(wt_s + buf * WT_BYTES + rr * ROWB + cc * 16) = wpre[i];
+            }
+        }
+    };
+
+    for (int kc = 0; kc < nkc; ++kc) {
+        load_w(0, kc);
+        __syncthreads();  // previous chunk's readers are done with in_s / wt_s
+        // ---- stage the halo tile of this channel chunk as bf16 ----
+        for (int s = tid; s < HALO_H * HALO_W * SEG_ROW; s += CWAVES * 64) {
+            const int pix = s / SEG_ROW, cc = s % SEG_ROW;
+            const int hy = pix / HALO_W, hx = pix % HALO_W;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
+                if (p.x_is_bf16) {
+                    v = *(const bf16x8*)((const bf16*)p.x + row * p.ldx + kc * KC + cc * 8);
+                } else {
+                    const float4* q = (const float4*)((const float*)p.x + row * p.ldx + kc * KC + cc * 8);
+                    const float4 a0 = q[0], a1 = q[1];
+                    v[0] = (bf16)a0.x; v[1] = (bf16)a0.y; v[2] = (bf16)a0.z; v[3] = (bf16)a0.w;
+                    v[4] = (bf16)a1.x; v[5] = (bf16)a1.y; v[6] = (bf16)a1.z; v[7] = (bf16)a1.w;
+                }
+            }
+            *(bf16x8*)(in_s + pix * ROWB + cc * 16) = v;
+        }
+        store_w(0);
+        __syncthreads();
+
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_w(tap + 1, kc);  // in flight during the MFMAs below
+            const int dy = tap / 3, dx = tap - dy * 3;
+            const char* wb = wt_s + (tap & 1) * WT_BYTES;
+            bf16x8 af[2][KS];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    af[mt][ks] = *(const bf16x8*)(in_s + ((wave + dy) * HALO_W + (16 * mt + r16 + dx)) * ROWB + (32 * ks + 8 * g4) * 2);
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 wf = *(const bf16x8*)(wb + (nt * 16 + r16) * ROWB + (32 * ks + 8 * g4) * 2);
+                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[0][nt], 0, 0, 0);
+                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[1][nt], 0, 0, 0);
+                }
+            }
+            if (tap < 8) {
+                store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
+                __syncthreads();
+            }
+        }
+    }
+
+    // ---- epilogue: lane owns channels 16*nt + 4*g4 + [0..3] of pixel (y0+wave, x0+16*mt+r16) ----
+    const int gy = y0 + wave;
+    float psum[NT][4];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) psum[nt][e] = 0.f;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int gx = x0 + 16 * mt + r16;
+        const bool valid = gy < p.H && gx < p.W;
+        const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int c = 16 * nt + 4 * g4;
+            const float4 b4 = *(const float4*)(p.bias + c);
+            float v[4] = {acc[mt][nt][0] + b4.x, acc[mt][nt][1] + b4.y, acc[mt][nt][2] + b4.z, acc[mt][nt][3] + b4.w};
+            if (p.act == 1) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+            } else if (p.act == 2) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+            }
+            if (valid) {
+                if (p.pool_partial != nullptr) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) psum[nt][e] += v[e];
+                }
+                if (p.resid != nullptr) {
+                    const float4 r4 = *(const float4*)(p.resid + row * p.ldr + c);
+                    v[0] += r4.x; v[1] += r4.y; v[2] += r4.z; v[3] += r4.w;
+                }
+                int64_t orow = row;
+                int oc = c;
+                bool keep = true;
+                if (p.shuffle_r > 1) {
+                    // PixelShuffle(r) with output channels pre-permuted to (i, j, cc) order at pack time
+                    const int r = p.shuffle_r, cg = p.shuffle_cg;
+                    const int q = c / cg;
+                    const int ij = p.shuffle_ij0 + q;
+                    oc = c - q * cg;
+                    keep = ij < r * r;  // channel slots beyond r*r sub-pixels are padding
+                    orow = ((int64_t)b * p.H * r + (gy * r + ij / r)) * (p.W * r) + (gx * r + ij % r);
+                }
+                if (!keep) {
+                } else if (p.out_is_bf16) {
+                    uint2 pk;
+                    pk.x = pack_bf16(v[0], v[1]);
+                    pk.y = pack_bf16(v[2], v[3]);
+                    *(uint2*)((bf16*)p.out + orow * p.ldo + oc) = pk;
+                } else {
+                    *(float4*)((float*)p.out + orow * p.ldo + oc) = float4{v[0], v[1], v[2], v[3]};
+                }
+            }
+        }
+    }
+    if (p.pool_partial != nullptr) {
+        // deterministic per-workgroup channel sums: lanes (xor 1,2,4,8) -> wave -> LDS -> one row per WG
+        __syncthreads();
+        float* red = (float*)smem;  // [CWAVES][NT*16]
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float s = psum[nt][e];
+                s += __shfl_xor(s, 1, 64);
+                s += __shfl_xor(s, 2, 64);
+                s += __shfl_xor(s, 4, 64);
+                s += __shfl_xor(s, 8, 64);
+                if (r16 == 0) red[wave * (NT * 16) + 16 * nt + 4 * g4 + e] = s;
+            }
+        __syncthreads();
+        const int wg = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
+        for (int c = tid; c < NT * 16; c += CWAVES * 64) {
+            float s = 0.f;
+#pragma unroll
+            for (int w = 0; w < CWAVES; ++w) s += red[w * (NT * 16) + c];
+            p.pool_partial[(int64_t)wg * p.CoutP + c] = s;
+        }
+    }
+}
+
+template <int KC, int NT>
+int launch_conv(const GrlConvArgs& p, hipStream_t st) {
+    const dim3 grid((p.W + TW - 1) / TW, (p.H + TH - 1) / TH, p.B);
+    const size_t lds = (size_t)HALO_H * HALO_W * (KC * 2 + 16) + 2 * (size_t)NT * 16 * (KC * 2 + 16);
+    auto kfn = conv3x3_kernel<KC, NT>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+template <int KC>
+int launch_conv_nt(const GrlConvArgs& p, hipStream_t st) {
+    switch (p.CoutP / 16) {
+        case 1: return launch_conv<KC, 1>(p, st);
+        case 2: return launch_conv<KC, 2>(p, st);
+        case 3: return launch_conv<KC, 3>(p, st);
+        case 4: return launch_conv<KC, 4>(p, st);
+        case 6: return launch_conv<KC, 6>(p, st);
+        case 8: return launch_conv<KC, 8>(p, st);
+        case 12: return launch_conv<KC, 12>(p, st);
+        default: return GRL_ERR_UNSUPPORTED;
+    }
+}
+
+// SE excitation: scale[b][c] = sigmoid(W2 . relu(W1 . mean_b + b1) + b2)   (mixed_attn_block.py:956-963)
+__global__ __launch_bounds__(256) void se_kernel(const float* __restrict__ partial, int wgs_per_image, int CP, int C,
+                                                 int Cmid, float inv_hw, const float* __restrict__ w1,
+                                                 const float* __restrict__ b1, const float* __restrict__ w2,
+                                                 const float* __restrict__ b2, float* __restrict__ scale) {
+    __shared__ float mean[256];
+    __shared__ float mid[64];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid < CP) {
+        float s = 0.f;
+        const float* pp = partial + (int64_t)b * wgs_per_image * CP + tid;
+        for (int i = 0; i < wgs_per_image; ++i) s += pp[(int64_t)i * CP];
+        mean[tid] = s * inv_hw;
+    }
+    __syncthreads();
+    if (tid < Cmid) {
+        float s = b1[tid];
+        for (int c = 0; c < C; ++c) s += w1[tid * C + c] * mean[c];
+        mid[tid] = fmaxf(s, 0.f);
+    }
+    __syncthreads();
+    if (tid < CP) {
+        float o = 0.f;
+        if (tid < C) {
+            float s = b2[tid];
+            for (int j = 0; j < Cmid; ++j) s += w2[tid * Cmid + j] * mid[j];
+            o = 1.0f / (1.0f + __expf(-s));
+        }
+        scale[(int64_t)b * CP + tid] = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
+    const GrlConvArgs& p = *args;
+    if (p.B <= 0 || p.H <= 0 || p.W <= 0) return GRL_ERR_BAD_ARG;
+    if (p.CinP % 32 || p.CoutP % 16 || p.CoutP > 192 || (p.ldx % 8) || (p.ldo % 4)) return GRL_ERR_BAD_ARG;
+    if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (p.CinP % 64 == 0) return launch_conv_nt<64>(p, st);
+    return launch_conv_nt<32>(p, st);
+}
+
+extern "C" int grl_conv3x3_num_workgroups(int32_t B, int32_t H, int32_t W) {
+    return B * ((H + TH - 1) / TH) * ((W + TW - 1) / TW);
+}
+
+extern "C" int grl_se_scale_fwd(void* stream, const float* pool_partial, int32_t B, int32_t wgs_per_image, int32_t CP,
+                                int32_t C, int32_t Cmid, int32_t HW, const float* w1, const float* b1, const float* w2,
+                                const float* b2, float* scale) {
+    if (CP > 256 || Cmid > 64 || C > CP) return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(se_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool_partial, wgs_per_image, CP, C, Cmid,
+                       1.0f / (float)HW, w1, b1, w2, b2, scale);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}

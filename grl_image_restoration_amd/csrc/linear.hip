@@ -197,13 +197,19 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
                     y[2] = res.z + p.res_scale * ((acc[mt][nt][2] - mean) * rstd * g.z + bb.z);
                     y[3] = res.w + p.res_scale * ((acc[mt][nt][3] - mean) * rstd * g.w + bb.w);
                     if (p.add2 != nullptr && valid) {
+                        float t4[4];
                         if (p.add2_is_bf16) {
                             const bf16x4 t = *(const bf16x4*)((const bf16*)p.add2 + (int64_t)m * p.ldadd2 + c);
-                            y[0] += (float)t[0]; y[1] += (float)t[1]; y[2] += (float)t[2]; y[3] += (float)t[3];
+                            t4[0] = (float)t[0]; t4[1] = (float)t[1]; t4[2] = (float)t[2]; t4[3] = (float)t[3];
                         } else {
                             const float4 t = *(const float4*)((const float*)p.add2 + (int64_t)m * p.ldadd2 + c);
-                            y[0] += t.x; y[1] += t.y; y[2] += t.z; y[3] += t.w;
+                            t4[0] = t.x; t4[1] = t.y; t4[2] = t.z; t4[3] = t.w;
                         }
+                        if (p.add2_scale != nullptr) {  // squeeze-excite gate of the CAB branch, per image
+                            const float4 sc = *(const float4*)(p.add2_scale + (int64_t)(m / p.rows_per_image) * p.Npad + c);
+                            t4[0] *= sc.x; t4[1] *= sc.y; t4[2] *= sc.z; t4[3] *= sc.w;
+                        }
+                        y[0] += t4[0]; y[1] += t4[1]; y[2] += t4[2]; y[3] += t4[3];
                     }
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[mt][nt][e] = (c + e) < p.n_real ? y[e] : 0.f;  // keep pad channels 0

@@ -409,19 +409,20 @@ class GRL(nn.Module):
         assert pk["tab_w"].shape[1] == table_rows(geo.window, geo.window)
         assert pk["tab_a2w"].shape[1] == table_rows(geo.anchor_stripe, geo.stripe)
 
-        # --- CAB (convs run through MIOpen for now; weights padded to the channels-last layout) ---
+        # --- CAB: conv3x3 C->C/4 (GELU), conv3x3 C/4->C, squeeze-excite gate (mixed_attn_block.py:948-983) ---
         if self.local_connection:
             c0, c2 = blk.conv.cab[0], blk.conv.cab[2]
             se = blk.conv.cab[3].attention
-            w0 = torch.zeros(c0.weight.shape[0], CP, 3, 3, **f32)
-            w0[:, :C] = c0.weight.detach().float()
-            w2 = torch.zeros(CP, c2.weight.shape[1], 3, 3, **f32)
-            w2[:C] = c2.weight.detach().float()
+            Cm = c0.weight.shape[0]
+            CmO, CmI = (Cm + 15) // 16 * 16, _pad32(Cm)  # conv1 writes CmO channels of a zeroed CmI-wide matrix
             pk.update(
-                cab0_w=w0.contiguous(memory_format=torch.channels_last), cab0_b=c0.bias.detach().float().to(dev),
-                cab2_w=w2.contiguous(memory_format=torch.channels_last), cab2_b=padv(c2.bias),
-                se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).to(dev), se1_b=se[1].bias.detach().float().to(dev),
-                se3_w=se[3].weight.detach().float().reshape(C, -1).to(dev), se3_b=se[3].bias.detach().float().to(dev),
+                cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
+                cab2_w=ops.pack_conv_weight(c2.weight.to(dev), CmI, CP), cab2_b=ops.pack_conv_bias(c2.bias.to(dev), CP),
+                cab_mid=CmI,
+                se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).contiguous().to(dev),
+                se1_b=se[1].bias.detach().float().to(dev),
+                se3_w=se[3].weight.detach().float().reshape(C, -1).contiguous().to(dev),
+                se3_b=se[3].bias.detach().float().to(dev),
             )
         return pk
 
@@ -440,22 +441,40 @@ class GRL(nn.Module):
             out[:C] = v.detach().float()
             return out
 
-        def padconv(conv):
-            w = torch.zeros(CP, CP, 3, 3, **f32)
-            w[:C, :C] = conv.weight.detach().float()
-            return w.contiguous(memory_format=torch.channels_last), padv(conv.bias)
+        def pconv(conv, cin_pad, cout_pad, r=0, cg=0):
+            return (ops.pack_conv_weight(conv.weight.to(dev), cin_pad, cout_pad, r, cg),
+                    ops.pack_conv_bias(conv.bias.to(dev), cout_pad, r, cg))
 
         with torch.no_grad():
             stages = []
             for si, stage in enumerate(self.layers):
                 blocks = [self._pack_block(blk, sched[si][bi], dev) for bi, blk in enumerate(stage.blocks)]
-                cw, cb = padconv(stage.conv)
+                cw, cb = pconv(stage.conv, CP, CP)
                 stages.append(dict(blocks=blocks, conv_w=cw, conv_b=cb))
             plan = dict(
                 sched=sched, stages=stages,
                 ns_g=padv(self.norm_start.weight), ns_b=padv(self.norm_start.bias),
                 ne_g=padv(self.norm_end.weight), ne_b=padv(self.norm_end.bias),
+                first=pconv(self.conv_first, _pad32(self.in_channels), CP), after=pconv(self.conv_after_body, CP, CP),
             )
+            out_p = (self.out_channels + 15) // 16 * 16
+            if self.upsampler == "pixelshuffle":
+                plan["cbu"] = pconv(self.conv_before_upsample[0], CP, 64)
+                r = 3 if self.upscale == 3 else 2
+                plan["ups"] = [pconv(m, 64, (64 * r * r + 15) // 16 * 16, r, 64) for m in self.upsample.up if isinstance(m, nn.Conv2d)]
+                plan["ups_r"] = r
+                plan["last"] = pconv(self.conv_last, 64, out_p)
+            elif self.upsampler == "pixelshuffledirect":
+                r = self.upscale
+                cg = (self.out_channels + 3) // 4 * 4
+                plan["upd"] = pconv(self.upsample.up[0], CP, (cg * r * r + 15) // 16 * 16, r, cg)
+                plan["upd_cg"] = cg
+            elif self.upsampler == "nearest+conv":
+                plan["cbu"] = pconv(self.conv_before_upsample[0], CP, 64)
+                plan["up1"], plan["up2"] = pconv(self.conv_up1, 64, 64), pconv(self.conv_up2, 64, 64)
+                plan["hr"], plan["last"] = pconv(self.conv_hr, 64, 64), pconv(self.conv_last, 64, out_p)
+            else:
+                plan["last"] = pconv(self.conv_last, CP, out_p)
         self._plan_cache = {key: plan}  # one geometry at a time keeps memory bounded
         return plan
 
@@ -472,17 +491,13 @@ class GRL(nn.Module):
         return x
 
     def _cab(self, r, pk, B, H, W, CP):
-        """CAB branch (mixed_attn_block.py:948-983) on the channels-last token matrix."""
-        C = self.embed_dim
-        x4 = r.view(B, H, W, CP).permute(0, 3, 1, 2)
-        y = F.conv2d(x4, pk["cab0_w"], pk["cab0_b"], padding=1)
-        y = F.gelu(y)
-        y = F.conv2d(y, pk["cab2_w"], pk["cab2_b"], padding=1)  # (B, CP, H, W), pad channels 0
-        s = y.mean(dim=(2, 3))[:, :C]
-        s = F.relu(F.linear(s, pk["se1_w"], pk["se1_b"]))
-        s = torch.sigmoid(F.linear(s, pk["se3_w"], pk["se3_b"]))
-        y = y * F.pad(s, (0, CP - C))[:, :, None, None]
-        return y.permute(0, 2, 3, 1).reshape(B * H * W, CP)
+        """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output (bf16) and the
+        per-image squeeze-excite gate; the gate is applied inside the proj+norm1 epilogue."""
+        mid = torch.zeros(B * H * W, pk["cab_mid"], dtype=torch.bfloat16, device=r.device)
+        ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid)
+        raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=torch.bfloat16)
+        gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])
+        return raw, gate
 
     def _block(self, r, pk, geo: BlockGeo, B, H, W):
         C, CP = self.embed_dim, r.shape[1]
@@ -518,32 +533,39 @@ class GRL(nn.Module):
                       fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
         ops.attention(g_q, g_a, g_y, TG(att, nh_w * 32, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
                       table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
-        cab = self._cab(r, pk, B, H, W, CP) if self.local_connection else None
+        cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         # x = x + res_scale * norm1(proj(attn)) + cab(x)   (efficient.py:543-548)
         r1 = ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
-                        ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab)
+                        ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab, add2_scale=gate,
+                        rows_per_image=H * W)
         # x = x + res_scale * norm2(mlp(x))                 (efficient.py:554)
         h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU)
         return ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
                           ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1)
 
-    def forward_features(self, f):
-        """grl.py:491-504.  f: (B, C, H, W) fp32 -> (B, C, H, W)."""
-        B, C, H, W = f.shape
-        CP = _pad32(C)
-        plan = self._plan((H, W), f.device)
-        t0 = torch.zeros(B * H * W, CP, dtype=torch.float32, device=f.device)
-        t0[:, :C] = f.permute(0, 2, 3, 1).reshape(-1, C)
-        t = ops.layernorm(t0, plan["ns_g"], plan["ns_b"], C)
+    def forward_features(self, f, plan, B, H, W):
+        """grl.py:491-504 on the token matrix f [B*H*W, CP] (fp32) -> [B*H*W, CP]."""
+        C = self.embed_dim
+        t = ops.layernorm(f, plan["ns_g"], plan["ns_b"], C)
         for si, st in enumerate(plan["stages"]):
             r = t
             for bi, pk in enumerate(st["blocks"]):
                 r = self._block(r, pk, plan["sched"][si][bi], B, H, W)
             # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
-            c = F.conv2d(r.view(B, H, W, CP).permute(0, 3, 1, 2), st["conv_w"], st["conv_b"], padding=1)
-            t = c.permute(0, 2, 3, 1).reshape(B * H * W, CP) + t
-        t = ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
-        return t.view(B, H, W, CP)[..., :C].permute(0, 3, 1, 2)
+            t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t)
+        return ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
+
+    @staticmethod
+    def _tokens(x, cpad):
+        """(B, C, H, W) -> channels-last token matrix [B*H*W, cpad] (zero padded)."""
+        B, C, H, W = x.shape
+        t = torch.zeros(B * H * W, cpad, dtype=torch.float32, device=x.device)
+        t[:, :C] = x.permute(0, 2, 3, 1).reshape(-1, C)
+        return t
+
+    @staticmethod
+    def _image(t, B, H, W, C):
+        return t.view(B, H, W, -1)[..., :C].permute(0, 3, 1, 2)
 
     def forward(self, x):
         """grl.py:506-551."""
@@ -555,35 +577,41 @@ class GRL(nn.Module):
         if self.training and torch.is_grad_enabled():
             raise NotImplementedError("training (backward) through the HIP path is not available yet")
         L.lib()  # fail loudly if the extension is missing
-        H, W = x.shape[2:]
+        H0, W0 = x.shape[2:]
         x = self.check_image_size(x.float())
         mean = self._mean.to(x.device, x.dtype)
         x = (x - mean) * self.img_range
+        B, _, H, W = x.shape
+        s, oc = self.upscale, self.out_channels
+        plan = self._plan((H, W), x.device)
+        conv = ops.conv3x3
+        bf = torch.bfloat16
 
-        def conv(m, t):
-            return F.conv2d(t, m.weight, m.bias, padding=1)
-
+        f = conv(self._tokens(x, plan["first"][0].shape[2]), *plan["first"], B, H, W)           # conv_first
+        body = conv(self.forward_features(f, plan, B, H, W), *plan["after"], B, H, W, resid=f)  # conv_after_body + f
         if self.upsampler == "pixelshuffle":
-            f = conv(self.conv_first, x)
-            y = conv(self.conv_after_body, self.forward_features(f)) + f
-            y = F.leaky_relu(conv(self.conv_before_upsample[0], y), 0.01)
-            for m in self.upsample.up:
-                y = conv(m, y) if isinstance(m, nn.Conv2d) else m(y)
-            y = conv(self.conv_last, y)
+            y = conv(body, *plan["cbu"], B, H, W, act=2, slope=0.01, out_dtype=bf)
+            h, w, r = H, W, plan["ups_r"]
+            for wt, bs in plan["ups"]:
+                y = conv(y, wt, bs, B, h, w, out_dtype=bf, shuffle_r=r, shuffle_cg=64)         # conv + PixelShuffle
+                h, w = h * r, w * r
+            y = self._image(conv(y, *plan["last"], B, h, w), B, h, w, oc)
         elif self.upsampler == "pixelshuffledirect":
-            f = conv(self.conv_first, x)
-            y = conv(self.conv_after_body, self.forward_features(f)) + f
-            y = F.pixel_shuffle(conv(self.upsample.up[0], y), self.upscale)
+            y = conv(body, *plan["upd"], B, H, W, shuffle_r=s, shuffle_cg=plan["upd_cg"])
+            y = self._image(y, B, H * s, W * s, oc)
         elif self.upsampler == "nearest+conv":
-            f = conv(self.conv_first, x)
-            y = conv(self.conv_after_body, self.forward_features(f)) + f
-            y = F.leaky_relu(conv(self.conv_before_upsample[0], y), 0.01)
-            y = F.leaky_relu(conv(self.conv_up1, F.interpolate(y, scale_factor=2, mode="nearest")), 0.2)
-            y = F.leaky_relu(conv(self.conv_up2, F.interpolate(y, scale_factor=2, mode="nearest")), 0.2)
-            y = conv(self.conv_last, F.leaky_relu(conv(self.conv_hr, y), 0.2))
+            y = conv(body, *plan["cbu"], B, H, W, act=2, slope=0.01, out_dtype=bf)
+
+            def up2(t, h, w):  # nearest x2 on a token matrix
+                return t.view(B, h, 1, w, 1, -1).expand(B, h, 2, w, 2, t.shape[1]).reshape(B * 4 * h * w, -1)
+
+            y = conv(up2(y, H, W), *plan["up1"], B, 2 * H, 2 * W, act=2, slope=0.2, out_dtype=bf)
+            y = conv(up2(y, 2 * H, 2 * W), *plan["up2"], B, 4 * H, 4 * W, act=2, slope=0.2, out_dtype=bf)
+            y = conv(y, *plan["hr"], B, 4 * H, 4 * W, act=2, slope=0.2, out_dtype=bf)
+            y = self._image(conv(y, *plan["last"], B, 4 * H, 4 * W), B, 4 * H, 4 * W, oc)
         else:
-            f = conv(self.conv_first, x)
-            res = conv(self.conv_after_body, self.forward_features(f)) + f
-            y = x + conv(self.conv_last, res) if self.in_channels == self.out_channels else conv(self.conv_last, res)
+            y = self._image(conv(body, *plan["last"], B, H, W), B, H, W, oc)
+            if self.in_channels == self.out_channels:
+                y = x + y
         y = y / self.img_range + mean
-        return y[:, :, : H * self.upscale, : W * self.upscale].contiguous()
+        return y[:, :, : H0 * s, : W0 * s].contiguous()

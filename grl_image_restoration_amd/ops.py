@@ -78,12 +78,16 @@ def linear(
     res_scale: float = 1.0,
     resid: Optional[torch.Tensor] = None,
     add2: Optional[torch.Tensor] = None,
+    add2_scale: Optional[torch.Tensor] = None,
+    rows_per_image: int = 0,
     pool: Optional[Tuple[int, int, int]] = None,
     M: Optional[int] = None,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
-    _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2)
+    _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale)
+    if add2_scale is not None:
+        assert add2 is not None and rows_per_image > 0 and add2_scale.dtype == torch.float32 and add2_scale.is_contiguous()
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.bfloat16
     assert a.dtype in (torch.float32, torch.bfloat16) and bias.dtype == torch.float32
     Npad, Kpad = w.shape
@@ -107,6 +111,7 @@ def linear(
         res_scale=res_scale, resid=_ptr(resid), ldr=resid.stride(0) if resid is not None else 0,
         add2=_ptr(add2), add2_is_bf16=int(add2 is not None and add2.dtype == torch.bfloat16),
         ldadd2=add2.stride(0) if add2 is not None else 0,
+        add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image,
         out=_ptr(out), out_is_bf16=int(out.dtype == torch.bfloat16), ldo=out.stride(0),
     )
     if epi == L.EPI_GROUPNORM:
@@ -165,3 +170,87 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: 
         "grl_layernorm_fwd",
     )
     return out
+
+
+def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: int = 0, shuffle_cg: int = 0) -> torch.Tensor:
+    """torch conv weight [Cout, Cin, 3, 3] -> bf16 [9, cout_pad, cin_pad] (tap = ky*3+kx, K contiguous).
+    With ``shuffle_r`` the output channels are re-ordered from PixelShuffle's (c, i, j) to (i, j, c) with
+    ``shuffle_cg`` (>= c, multiple of 4) slots per sub-pixel so the kernel can store whole channel groups."""
+    cout, cin = w.shape[:2]
+    w9 = w.detach().float().permute(2, 3, 0, 1).reshape(9, cout, cin)
+    out = torch.zeros(9, cout_pad, cin_pad, dtype=torch.float32, device=w.device)
+    if shuffle_r > 1:
+        r2 = shuffle_r * shuffle_r
+        c = cout // r2
+        src = w9.view(9, c, r2, cin).permute(0, 2, 1, 3)  # [9, ij, c, cin]
+        out.view(9, cout_pad // shuffle_cg, shuffle_cg, cin_pad)[:, :r2, :c, :cin] = src
+    else:
+        out[:, :cout, :cin] = w9
+    return out.to(torch.bfloat16).contiguous()
+
+
+def pack_conv_bias(b: torch.Tensor, cout_pad: int, shuffle_r: int = 0, shuffle_cg: int = 0) -> torch.Tensor:
+    out = torch.zeros(cout_pad, dtype=torch.float32, device=b.device)
+    if shuffle_r > 1:
+        r2 = shuffle_r * shuffle_r
+        c = b.numel() // r2
+        out.view(cout_pad // shuffle_cg, shuffle_cg)[:r2, :c] = b.detach().float().view(c, r2).t()
+    else:
+        out[: b.numel()] = b.detach().float()
+    return out
+
+
+def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int, *, act: int = 0,
+            slope: float = 0.0, resid: Optional[torch.Tensor] = None, want_pool: bool = False,
+            out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0):
+    """3x3 conv (stride 1, pad 1) on a channels-last token matrix x[B*H*W, >=CinP]; w packed by
+    pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool)."""
+    _dev_check(x, w, bias, resid, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, torch.bfloat16)
+    assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 3 and w.shape[0] == 9
+    CoutP, CinP = w.shape[1], w.shape[2]
+    assert x.shape[0] >= B * H * W and x.shape[1] >= CinP and bias.numel() == CoutP
+    if shuffle_r > 1:
+        rows, cols = B * H * W * shuffle_r * shuffle_r, shuffle_cg
+    else:
+        rows, cols = B * H * W, CoutP
+    if out is None:
+        out = torch.empty(rows, cols, dtype=out_dtype, device=x.device)
+    pool = None
+    lib = L.lib()
+    if want_pool:
+        nwg = lib.grl_conv3x3_num_workgroups(B, H, W)
+        pool = torch.empty(nwg, CoutP, dtype=torch.float32, device=x.device)
+    # at most 192 output channels per launch; larger layers are split on the channel axis
+    step = CoutP
+    if CoutP > 192:
+        step = max(s for s in (192, 128, 96, 64, 48, 32, 16) if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0))
+        assert not want_pool
+    for c0 in range(0, CoutP, step):
+        args = L.GrlConvArgs(
+            x=_ptr(x), x_is_bf16=int(x.dtype == torch.bfloat16), ldx=x.stride(0),
+            w=C.c_void_p(w.data_ptr() + c0 * CinP * 2), w_tap_stride=CoutP * CinP,
+            bias=C.c_void_p(bias.data_ptr() + c0 * 4),
+            B=B, H=H, W=W, CinP=CinP, CoutP=step, act=act, slope=slope,
+            resid=C.c_void_p(resid.data_ptr() + c0 * 4) if resid is not None else C.c_void_p(0),
+            ldr=resid.stride(0) if resid is not None else 0,
+            pool_partial=_ptr(pool),
+            out=C.c_void_p(out.data_ptr() + (0 if shuffle_r > 1 else c0 * out.element_size())),
+            out_is_bf16=int(out.dtype == torch.bfloat16), ldo=out.stride(0),
+            shuffle_r=shuffle_r, shuffle_cg=shuffle_cg, shuffle_ij0=(c0 // shuffle_cg if shuffle_r > 1 else 0),
+        )
+        with _timed("conv3x3"):
+            L.check(lib.grl_conv3x3_fwd(L.stream_ptr(), C.byref(args)), "grl_conv3x3_fwd")
+    return (out, pool) if want_pool else out
+
+
+def se_scale(pool: torch.Tensor, B: int, CP: int, C_: int, HW: int, w1, b1, w2, b2) -> torch.Tensor:
+    """scale[B, CP] = sigmoid(W2 relu(W1 mean + b1) + b2) from the conv kernel's partial channel sums."""
+    _dev_check(pool, w1, b1, w2, b2)
+    scale = torch.empty(B, CP, dtype=torch.float32, device=pool.device)
+    L.check(
+        L.lib().grl_se_scale_fwd(L.stream_ptr(), _ptr(pool), B, pool.shape[0] // B, CP, C_, w1.shape[0], HW, _ptr(w1),
+                                 _ptr(b1), _ptr(w2), _ptr(b2), _ptr(scale)),
+        "grl_se_scale_fwd",
+    )
+    return scale

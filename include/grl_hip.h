@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 1
+#define GRL_ABI_VERSION 2
 
 /* ---------------------------------------------------------------------------------------------
  * Token-wise linear layer with fused epilogue.
@@ -56,6 +56,8 @@ typedef struct GrlLinearArgs {
     const void* add2;       /* LN_RES: optional extra branch (CAB output) added after the norm      */
     int32_t add2_is_bf16;
     int64_t ldadd2;
+    const float* add2_scale; /* optional [B, Npad] per-image channel scale applied to add2 (SE gate)  */
+    int32_t rows_per_image;  /*          image of row m = m / rows_per_image                          */
     void* out;              /* [M, ldo] bf16 or fp32                                                */
     int32_t out_is_bf16;
     int64_t ldo;
@@ -98,6 +100,46 @@ typedef struct GrlAttnArgs {
 } GrlAttnArgs;
 
 int grl_attention_fwd(void* stream, const GrlAttnArgs* args);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 convolution (stride 1, zero pad 1) on channels-last token matrices, fused epilogue.
+ *   replaces  CAB.cab[0], GELU, CAB.cab[2]          models/common/mixed_attn_block.py:970-983
+ *             TransformerStage.conv (+ residual)     models/networks/grl.py:137,168-170
+ *             conv_first / conv_after_body / conv_before_upsample / Upsample convs + PixelShuffle /
+ *             conv_last                              models/networks/grl.py:293,348,352-379,515-518
+ *                                                    models/common/upsample.py:16-19,45-46
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GrlConvArgs {
+    const void* x;          /* [B*H*W, ldx] fp32 or bf16, channels-last                             */
+    int32_t x_is_bf16;
+    int64_t ldx;
+    const void* w;          /* bf16 [9][*][CinP] (tap = ky*3+kx): first output channel of this call */
+    int64_t w_tap_stride;   /* elements between taps (= full layer Cout_pad * CinP)                  */
+    const float* bias;      /* [CoutP]                                                              */
+    int32_t B, H, W;
+    int32_t CinP, CoutP;    /* CinP % 32 == 0, CoutP % 16 == 0, CoutP <= 192 per call               */
+    int32_t act;            /* 0 none, 1 exact GELU, 2 LeakyReLU(slope)                             */
+    float slope;
+    const float* resid;     /* optional fp32 [B*H*W, ldr] added after the activation                */
+    int64_t ldr;
+    float* pool_partial;    /* optional [grl_conv3x3_num_workgroups(B,H,W), CoutP]: per-workgroup    */
+                            /* channel sums of the output (two-stage global average pool)           */
+    void* out;              /* [rows, ldo] fp32 or bf16                                             */
+    int32_t out_is_bf16;
+    int64_t ldo;
+    int32_t shuffle_r;      /* >1: PixelShuffle(r) store into a [B, H*r, W*r, shuffle_cg] matrix;    */
+    int32_t shuffle_cg;     /*     output channels are packed in (i, j, c) order, this call's        */
+    int32_t shuffle_ij0;    /*     channel 0 belongs to sub-pixel group shuffle_ij0                  */
+} GrlConvArgs;
+
+int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args);
+int grl_conv3x3_num_workgroups(int32_t B, int32_t H, int32_t W);
+
+/* Squeeze-excite gate from the pooled sums: scale[b,c] = sigmoid(W2 relu(W1 mean_b + b1) + b2)
+ *   replaces  ChannelAttention.attention   models/common/mixed_attn_block.py:956-967            */
+int grl_se_scale_fwd(void* stream, const float* pool_partial, int32_t B, int32_t wgs_per_image, int32_t CP, int32_t C,
+                     int32_t Cmid, int32_t HW, const float* w1, const float* b1, const float* w2, const float* b2,
+                     float* scale);
 
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm on a padded token matrix (norm_start / norm_end, models/networks/grl.py:494,501).

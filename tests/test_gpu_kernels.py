@@ -222,3 +222,82 @@ def test_attention_vs_oracle_indexing(case, fixed):
     err = (got.double() - ref).abs().max().item()
     print(f"{name} fixed={fixed}: max|err| = {err:.3e} (ref max {ref.abs().max().item():.2f})")
     assert err < 6e-3 * max(1.0, ref.abs().max().item()), err  # bf16 output: half-ulp 2^-9 relative + bf16 P
+
+
+# ------------------------------------------------------------------------------------------------
+# 3x3 convolution (+ activation, residual, pooled sums, pixel shuffle) and the SE gate
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,H,W,Cin,Cout,act,src_bf16", [
+    (2, 20, 45, 180, 180, 0, False),   # stage conv: ragged tile edges, residual
+    (1, 16, 32, 180, 45, 1, False),    # CAB conv1 + exact GELU
+    (2, 24, 40, 45, 180, 0, True),     # CAB conv2 (bf16 source) + pooled sums
+    (1, 17, 33, 3, 180, 0, False),     # conv_first (3 input channels -> one 32-wide chunk)
+    (1, 16, 16, 64, 3, 0, True),       # conv_last (3 output channels -> one 16-wide tile)
+    (1, 12, 20, 128, 64, 2, False),    # conv_before_upsample + LeakyReLU
+])
+def test_conv3x3(B, H, W, Cin, Cout, act, src_bf16):
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(7)
+    CinP = (Cin + 31) // 32 * 32
+    CoutP = (Cout + 15) // 16 * 16
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    xt = torch.zeros(B * H * W, CinP)
+    xt[:, :Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin)
+    if src_bf16:
+        xt = xt.to(torch.bfloat16)
+    xr = xt.float()[:, :Cin].view(B, H, W, Cin).permute(0, 3, 1, 2).to(torch.bfloat16).double()
+    ref = F.conv2d(xr, w.to(torch.bfloat16).double(), b.double(), padding=1)
+    if act == 1:
+        ref = F.gelu(ref)
+    elif act == 2:
+        ref = F.leaky_relu(ref, 0.01)
+    pooled = ref.sum(dim=(2, 3))
+    resid = torch.randn(B * H * W, CoutP, generator=g)
+    d = _dev()
+    wp, bp = ops.pack_conv_weight(w.to(d), CinP, CoutP), ops.pack_conv_bias(b.to(d), CoutP)
+    out, pool = ops.conv3x3(xt.to(d), wp, bp, B, H, W, act=act, slope=0.01, resid=resid.to(d), want_pool=True)
+    got = out.cpu().double().view(B, H, W, CoutP)
+    want = ref.permute(0, 2, 3, 1) + resid.double().view(B, H, W, CoutP)[..., :Cout]
+    assert (got[..., :Cout] - want).abs().max().item() < 2e-3
+    assert (got[..., Cout:] - resid.double().view(B, H, W, CoutP)[..., Cout:]).abs().max().item() == 0 if CoutP > Cout else True
+    sums = pool.cpu().double().view(B, -1, CoutP).sum(1)[:, :Cout]
+    assert (sums - pooled).abs().max().item() < 2e-3 * max(1.0, pooled.abs().max().item())
+
+
+@pytest.mark.parametrize("r,c,Cin", [(2, 64, 64), (3, 64, 64), (2, 3, 64), (4, 3, 96)])
+def test_conv3x3_pixel_shuffle(r, c, Cin):
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(8)
+    B, H, W = 2, 12, 20
+    Cout = c * r * r
+    cg = (c + 3) // 4 * 4
+    CoutP = (cg * r * r + 15) // 16 * 16
+    x = torch.randn(B, Cin, H, W, generator=g).to(torch.bfloat16)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.to(torch.bfloat16).double(), b.double(), padding=1), r)
+    d = _dev()
+    xt = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(d)
+    out = ops.conv3x3(xt, ops.pack_conv_weight(w.to(d), Cin, CoutP, r, cg), ops.pack_conv_bias(b.to(d), CoutP, r, cg),
+                      B, H, W, shuffle_r=r, shuffle_cg=cg)
+    got = out.cpu().double().view(B, H * r, W * r, cg)[..., :c].permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() < 2e-3
+
+
+def test_se_gate():
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(9)
+    B, nwg, CP, C, Cm, HW = 3, 7, 192, 180, 10, 1000
+    pool = torch.randn(B * nwg, CP, generator=g) * 30
+    w1, b1 = torch.randn(Cm, C, generator=g) / 10, torch.randn(Cm, generator=g) / 10
+    w2, b2 = torch.randn(C, Cm, generator=g) / 3, torch.randn(C, generator=g) / 10
+    mean = pool.view(B, nwg, CP).sum(1)[:, :C] / HW
+    ref = torch.sigmoid(F.linear(F.relu(F.linear(mean, w1, b1)), w2, b2))
+    d = _dev()
+    got = ops.se_scale(pool.to(d), B, CP, C, HW, w1.to(d), b1.to(d), w2.to(d), b2.to(d)).cpu()
+    assert (got[:, :C] - ref).abs().max().item() < 1e-5 and got[:, C:].abs().max().item() == 0
