@@ -26,7 +26,18 @@ EXPORTS = [
 ]
 
 
-class GrlLinearArgs(C.Structure):
+class _Strict(C.Structure):
+    """ctypes silently turns unknown keyword arguments into plain attributes (leaving the C field
+    zero); refuse them instead."""
+
+    def __init__(self, **kw):
+        bad = set(kw) - {f[0] for f in self._fields_}
+        if bad:
+            raise TypeError(f"{type(self).__name__}: unknown field(s) {sorted(bad)}")
+        super().__init__(**kw)
+
+
+class GrlLinearArgs(_Strict):
     _fields_ = [
         ("a", C.c_void_p),
         ("a_is_bf16", C.c_int32),
@@ -59,7 +70,7 @@ class GrlLinearArgs(C.Structure):
     ]
 
 
-class GrlTokenGrid(C.Structure):
+class GrlTokenGrid(_Strict):
     _fields_ = [
         ("ptr", C.c_void_p),
         ("ld", C.c_int64),
@@ -73,7 +84,7 @@ class GrlTokenGrid(C.Structure):
     ]
 
 
-class GrlAttnArgs(C.Structure):
+class GrlAttnArgs(_Strict):
     _fields_ = [
         ("q", GrlTokenGrid),
         ("k", GrlTokenGrid),
@@ -92,7 +103,7 @@ class GrlAttnArgs(C.Structure):
     ]
 
 
-class GrlConvArgs(C.Structure):
+class GrlConvArgs(_Strict):
     _fields_ = [
         ("x", C.c_void_p),
         ("x_is_bf16", C.c_int32),
@@ -103,8 +114,8 @@ class GrlConvArgs(C.Structure):
         ("B", C.c_int32),
         ("H", C.c_int32),
         ("W", C.c_int32),
-        ("Cin_pad", C.c_int32),
-        ("Cout_pad", C.c_int32),
+        ("CinP", C.c_int32),
+        ("CoutP", C.c_int32),
         ("act", C.c_int32),
         ("slope", C.c_float),
         ("resid", C.c_void_p),

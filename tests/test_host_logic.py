@@ -116,3 +116,11 @@ def test_fixed_max_policy_and_table():
     bias = torch.rand(50, 2) * 16
     t = tables.kernel_table(bias, scale, True)
     assert t.shape == (2, 50) and t.max().item() <= -scale.min().item() * tables.LOG2E + 1e-4
+
+
+def test_ctypes_structs_refuse_unknown_fields():
+    """ctypes would silently ignore a misspelt keyword and leave the C field zero."""
+    with pytest.raises(TypeError):
+        _lib.GrlConvArgs(Cin_pad=3)
+    a = _lib.GrlConvArgs(CinP=64, CoutP=192, w_tap_stride=5)
+    assert a.CinP == 64 and a.CoutP == 192 and a.w_tap_stride == 5
