@@ -234,24 +234,45 @@ int launch_conv_nt(const GrlConvArgs& p, hipStream_t st) {
 }
 
 // SE excitation: scale[b][c] = sigmoid(W2 . relu(W1 . mean_b + b1) + b2)   (mixed_attn_block.py:956-963)
-__global__ __launch_bounds__(256) void se_kernel(const float* __restrict__ partial, int wgs_per_image, int CP, int C,
-                                                 int Cmid, float inv_hw, const float* __restrict__ w1,
-                                                 const float* __restrict__ b1, const float* __restrict__ w2,
-                                                 const float* __restrict__ b2, float* __restrict__ scale) {
+// one 1024-thread workgroup per image: 4 threads per channel split the partial-sum rows (fixed order).
+__global__ __launch_bounds__(1024) void se_kernel(const float* __restrict__ partial, int wgs_per_image, int CP, int C,
+                                                  int Cmid, float inv_hw, const float* __restrict__ w1,
+                                                  const float* __restrict__ b1, const float* __restrict__ w2,
+                                                  const float* __restrict__ b2, float* __restrict__ scale) {
+    __shared__ float part[16][256];
     __shared__ float mean[256];
     __shared__ float mid[64];
     const int b = blockIdx.x, tid = threadIdx.x;
+    {   // 16 row-slices x 64 lanes of float4: partial sums in a fixed order (deterministic)
+        const int c4 = (tid & 63) * 4, q = tid >> 6;
+        if (c4 < CP) {
+            float4 s = float4{0, 0, 0, 0};
+            const float* pp = partial + (int64_t)b * wgs_per_image * CP + c4;
+#pragma unroll 4
+            for (int i = q; i < wgs_per_image; i += 16) {
+                const float4 v = *(const float4*)(pp + (int64_t)i * CP);
+                s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w;
+            }
+            part[q][c4] = s.x; part[q][c4 + 1] = s.y; part[q][c4 + 2] = s.z; part[q][c4 + 3] = s.w;
+        }
+    }
+    __syncthreads();
     if (tid < CP) {
         float s = 0.f;
-        const float* pp = partial + (int64_t)b * wgs_per_image * CP + tid;
-        for (int i = 0; i < wgs_per_image; ++i) s += pp[(int64_t)i * CP];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) s += part[q][tid];
         mean[tid] = s * inv_hw;
     }
     __syncthreads();
-    if (tid < Cmid) {
-        float s = b1[tid];
-        for (int c = 0; c < C; ++c) s += w1[tid * C + c] * mean[c];
-        mid[tid] = fmaxf(s, 0.f);
+    {   // one wave per hidden unit
+        const int lane = tid & 63, wv = tid >> 6;
+        for (int j = wv; j < Cmid; j += 16) {
+            float s = 0.f;
+            for (int k = lane; k < C; k += 64) s += w1[j * C + k] * mean[k];
+#pragma unroll
+            for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+            if (lane == 0) mid[j] = fmaxf(s + b1[j], 0.f);
+        }
     }
     __syncthreads();
     if (tid < CP) {
@@ -285,7 +306,7 @@ extern "C" int grl_se_scale_fwd(void* stream, const float* pool_partial, int32_t
                                 int32_t C, int32_t Cmid, int32_t HW, const float* w1, const float* b1, const float* w2,
                                 const float* b2, float* scale) {
     if (CP > 256 || Cmid > 64 || C > CP) return GRL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(se_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, pool_partial, wgs_per_image, CP, C, Cmid,
+    hipLaunchKernelGGL(se_kernel, dim3(B), dim3(1024), 0, (hipStream_t)stream, pool_partial, wgs_per_image, CP, C, Cmid,
                        1.0f / (float)HW, w1, b1, w2, b2, scale);
     GRL_CHECK_LAUNCH();
     return 0;

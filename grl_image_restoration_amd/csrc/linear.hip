@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int WAVES = 8;             // 512 threads, 2 waves / SIMD
+constexpr int WAVES = 4;             // 256 threads; several workgroups share a CU (occupancy hides the stage/compute/store phases)
 constexpr int ROWS_PER_WAVE = 32;    // 2 MFMA m-tiles
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 
@@ -80,8 +80,113 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
     }
 }
 
-// One workgroup: ROWS_PER_WG token rows x all Npad output channels.
-template <int KSTEPS, int NT, int EPI>
+// Epilogue of one 16-row m-tile over NCH chunks of NT n-tiles held in registers.
+template <int NT, int NCH, int EPI>
+__device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][2][NT], int mt, int m, bool valid, int n0,
+                                         int g4) {
+    if constexpr (EPI == GRL_EPI_GROUPNORM) {
+        // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
+        // gscale == 0 marks a pass-through group (v).  F.normalize eps: efficient.py:85.
+#pragma unroll
+        for (int g = 0; g < NT / 2; ++g) {
+            float ss = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ss += acc[0][mt][2 * g][e] * acc[0][mt][2 * g][e];
+                ss += acc[0][mt][2 * g + 1][e] * acc[0][mt][2 * g + 1][e];
+            }
+            ss += __shfl_xor(ss, 16, 64);
+            ss += __shfl_xor(ss, 32, 64);
+            const float gs = p.gscale[(n0 >> 5) + g];
+            const float f = gs != 0.0f ? gs / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { acc[0][mt][2 * g][e] *= f; acc[0][mt][2 * g + 1][e] *= f; }
+        }
+    } else if constexpr (EPI == GRL_EPI_GELU) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc[0][mt][nt][e] = gelu_erf(acc[0][mt][nt][e]);
+    } else if constexpr (EPI == GRL_EPI_LN_RES) {
+        // LayerNorm over the n_real real channels (eps 1e-5), then residual (+ optional gated extra branch)
+        float s1 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1 += (16 * (c * NT + nt) + 4 * g4 + e) < p.n_real ? acc[c][mt][nt][e] : 0.f;
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 / (float)p.n_real;
+        float s2 = 0.f;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = acc[c][mt][nt][e] - mean;
+                    s2 += (16 * (c * NT + nt) + 4 * g4 + e) < p.n_real ? d * d : 0.f;
+                }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = 16 * (c * NT + nt) + 4 * g4;
+                const float4 g = *(const float4*)(p.ln_g + col);
+                const float4 bb = *(const float4*)(p.ln_b + col);
+                float4 res = float4{0, 0, 0, 0};
+                if (valid) res = *(const float4*)(p.resid + (int64_t)m * p.ldr + col);
+                float y[4];
+                y[0] = res.x + p.res_scale * ((acc[c][mt][nt][0] - mean) * rstd * g.x + bb.x);
+                y[1] = res.y + p.res_scale * ((acc[c][mt][nt][1] - mean) * rstd * g.y + bb.y);
+                y[2] = res.z + p.res_scale * ((acc[c][mt][nt][2] - mean) * rstd * g.z + bb.z);
+                y[3] = res.w + p.res_scale * ((acc[c][mt][nt][3] - mean) * rstd * g.w + bb.w);
+                if (p.add2 != nullptr && valid) {
+                    float t4[4];
+                    if (p.add2_is_bf16) {
+                        const bf16x4 t = *(const bf16x4*)((const bf16*)p.add2 + (int64_t)m * p.ldadd2 + col);
+                        t4[0] = (float)t[0]; t4[1] = (float)t[1]; t4[2] = (float)t[2]; t4[3] = (float)t[3];
+                    } else {
+                        const float4 t = *(const float4*)((const float*)p.add2 + (int64_t)m * p.ldadd2 + col);
+                        t4[0] = t.x; t4[1] = t.y; t4[2] = t.z; t4[3] = t.w;
+                    }
+                    if (p.add2_scale != nullptr) {  // squeeze-excite gate of the CAB branch, per image
+                        const float4 sc = *(const float4*)(p.add2_scale + (int64_t)(m / p.rows_per_image) * p.Npad + col);
+                        t4[0] *= sc.x; t4[1] *= sc.y; t4[2] *= sc.z; t4[3] *= sc.w;
+                    }
+                    y[0] += t4[0]; y[1] += t4[1]; y[2] += t4[2]; y[3] += t4[3];
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[c][mt][nt][e] = (col + e) < p.n_real ? y[e] : 0.f;  // keep pad channels 0
+            }
+    }
+    if (!valid) return;
+#pragma unroll
+    for (int c = 0; c < NCH; ++c)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + 16 * (c * NT + nt) + 4 * g4;
+            if (p.out_is_bf16) {
+                uint2 pk;
+                pk.x = pack_bf16(acc[c][mt][nt][0], acc[c][mt][nt][1]);
+                pk.y = pack_bf16(acc[c][mt][nt][2], acc[c][mt][nt][3]);
+                *(uint2*)((bf16*)p.out + (int64_t)m * p.ldo + col) = pk;
+            } else {
+                *(float4*)((float*)p.out + (int64_t)m * p.ldo + col) =
+                    float4{acc[c][mt][nt][0], acc[c][mt][nt][1], acc[c][mt][nt][2], acc[c][mt][nt][3]};
+            }
+        }
+}
+
+// One workgroup: ROWS_PER_WG token rows x all Npad output channels, NT n-tiles per weight chunk.
+// NCH > 1 (LayerNorm epilogue only): the accumulators of all NCH chunks stay in registers so the
+// row statistics see the whole row while only one NT*16-row weight chunk occupies LDS.
+template <int KSTEPS, int NT, int NCH, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KPAD = KSTEPS * 32;
@@ -93,180 +198,100 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
     bf16x8 a[2][KSTEPS];
     load_a_slab<KSTEPS>(p, row0, lane, a);
 
-    const int nchunks = p.Npad / (NT * 16);
-    for (int ch = 0; ch < nchunks; ++ch) {
-        const int n0 = ch * NT * 16;
-        // ---- stage the weight chunk [NT*16][KPAD] into LDS (16 B per thread-iteration) ----
-        __syncthreads();
-        {
-            constexpr int SEGS_PER_ROW = KPAD / 8;
-            constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
-            const bf16* wsrc = (const bf16*)p.w + (int64_t)n0 * KPAD;
-            for (int i = tid; i < SEGS; i += WAVES * 64) {
-                const int rr = i / SEGS_PER_ROW, cc = i % SEGS_PER_ROW;
-                *(bf16x8*)(smem + rr * ROWB + cc * 16) = *(const bf16x8*)(wsrc + (int64_t)rr * KPAD + cc * 8);
+    const int ngroups = p.Npad / (NT * 16 * NCH);
+    for (int gch = 0; gch < ngroups; ++gch) {
+        f32x4 acc[NCH][2][NT];
+#pragma unroll
+        for (int c = 0; c < NCH; ++c) {
+            const int n0 = (gch * NCH + c) * NT * 16;
+            // ---- stage the weight chunk [NT*16][KPAD] into LDS (16 B per thread-iteration) ----
+            __syncthreads();
+            {
+                constexpr int SEGS_PER_ROW = KPAD / 8;
+                constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
+                const bf16* wsrc = (const bf16*)p.w + (int64_t)n0 * KPAD;
+                for (int i = tid; i < SEGS; i += WAVES * 64) {
+                    const int rr = i / SEGS_PER_ROW, cc = i % SEGS_PER_ROW;
+                    *(bf16x8*)(smem + rr * ROWB + cc * 16) = *(const bf16x8*)(wsrc + (int64_t)rr * KPAD + cc * 8);
+                }
             }
-        }
-        __syncthreads();
-
-        f32x4 acc[2][NT];
+            __syncthreads();
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
+            for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
-
+                for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = f32x4{0, 0, 0, 0};
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
+            for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const bf16x8 w = *(const bf16x8*)(smem + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
+                    // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
+                    acc[c][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[0][s], acc[c][0][nt], 0, 0, 0);
+                    acc[c][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[1][s], acc[c][1][nt], 0, 0, 0);
+                }
+            }
+            // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
-                const bf16x8 w = *(const bf16x8*)(smem + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
-                // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
-                acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[0][s], acc[0][nt], 0, 0, 0);
-                acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[1][s], acc[1][nt], 0, 0, 0);
+                const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    acc[c][mt][nt][0] += b4.x; acc[c][mt][nt][1] += b4.y; acc[c][mt][nt][2] += b4.z; acc[c][mt][nt][3] += b4.w;
+                }
             }
         }
-
-        // ---- epilogue: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16 ----
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-            const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4);
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                acc[mt][nt][0] += b4.x; acc[mt][nt][1] += b4.y; acc[mt][nt][2] += b4.z; acc[mt][nt][3] += b4.w;
-            }
-        }
-
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int m = row0 + 16 * mt + r16;
-            const bool valid = m < p.M;
-            if constexpr (EPI == GRL_EPI_GROUPNORM) {
-                // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
-                // gscale == 0 marks a pass-through group (v).  F.normalize eps: efficient.py:85.
-#pragma unroll
-                for (int g = 0; g < NT / 2; ++g) {
-                    float ss = 0.f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        ss += acc[mt][2 * g][e] * acc[mt][2 * g][e];
-                        ss += acc[mt][2 * g + 1][e] * acc[mt][2 * g + 1][e];
-                    }
-                    ss += __shfl_xor(ss, 16, 64);
-                    ss += __shfl_xor(ss, 32, 64);
-                    const float gs = p.gscale[(n0 >> 5) + g];
-                    const float f = gs != 0.0f ? gs / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) { acc[mt][2 * g][e] *= f; acc[mt][2 * g + 1][e] *= f; }
-                }
-            } else if constexpr (EPI == GRL_EPI_GELU) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mt][nt][e] = gelu_erf(acc[mt][nt][e]);
-            } else if constexpr (EPI == GRL_EPI_LN_RES) {
-                // LayerNorm over the n_real real channels (eps 1e-5), then residual (+ optional extra branch)
-                float s1 = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) s1 += (16 * nt + 4 * g4 + e) < p.n_real ? acc[mt][nt][e] : 0.f;
-                s1 += __shfl_xor(s1, 16, 64);
-                s1 += __shfl_xor(s1, 32, 64);
-                const float mean = s1 / (float)p.n_real;
-                float s2 = 0.f;
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const float d = acc[mt][nt][e] - mean;
-                        s2 += (16 * nt + 4 * g4 + e) < p.n_real ? d * d : 0.f;
-                    }
-                s2 += __shfl_xor(s2, 16, 64);
-                s2 += __shfl_xor(s2, 32, 64);
-                const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const int c = 16 * nt + 4 * g4;
-                    const float4 g = *(const float4*)(p.ln_g + c);
-                    const float4 bb = *(const float4*)(p.ln_b + c);
-                    float4 res = float4{0, 0, 0, 0};
-                    if (valid) res = *(const float4*)(p.resid + (int64_t)m * p.ldr + c);
-                    float y[4];
-                    y[0] = res.x + p.res_scale * ((acc[mt][nt][0] - mean) * rstd * g.x + bb.x);
-                    y[1] = res.y + p.res_scale * ((acc[mt][nt][1] - mean) * rstd * g.y + bb.y);
-                    y[2] = res.z + p.res_scale * ((acc[mt][nt][2] - mean) * rstd * g.z + bb.z);
-                    y[3] = res.w + p.res_scale * ((acc[mt][nt][3] - mean) * rstd * g.w + bb.w);
-                    if (p.add2 != nullptr && valid) {
-                        float t4[4];
-                        if (p.add2_is_bf16) {
-                            const bf16x4 t = *(const bf16x4*)((const bf16*)p.add2 + (int64_t)m * p.ldadd2 + c);
-                            t4[0] = (float)t[0]; t4[1] = (float)t[1]; t4[2] = (float)t[2]; t4[3] = (float)t[3];
-                        } else {
-                            const float4 t = *(const float4*)((const float*)p.add2 + (int64_t)m * p.ldadd2 + c);
-                            t4[0] = t.x; t4[1] = t.y; t4[2] = t.z; t4[3] = t.w;
-                        }
-                        if (p.add2_scale != nullptr) {  // squeeze-excite gate of the CAB branch, per image
-                            const float4 sc = *(const float4*)(p.add2_scale + (int64_t)(m / p.rows_per_image) * p.Npad + c);
-                            t4[0] *= sc.x; t4[1] *= sc.y; t4[2] *= sc.z; t4[3] *= sc.w;
-                        }
-                        y[0] += t4[0]; y[1] += t4[1]; y[2] += t4[2]; y[3] += t4[3];
-                    }
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) acc[mt][nt][e] = (c + e) < p.n_real ? y[e] : 0.f;  // keep pad channels 0
-                }
-            }
-            if (!valid) continue;
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int c = n0 + 16 * nt + 4 * g4;
-                if (p.out_is_bf16) {
-                    uint2 pk;
-                    pk.x = pack_bf16(acc[mt][nt][0], acc[mt][nt][1]);
-                    pk.y = pack_bf16(acc[mt][nt][2], acc[mt][nt][3]);
-                    *(uint2*)((bf16*)p.out + (int64_t)m * p.ldo + c) = pk;
-                } else {
-                    *(float4*)((float*)p.out + (int64_t)m * p.ldo + c) =
-                        float4{acc[mt][nt][0], acc[mt][nt][1], acc[mt][nt][2], acc[mt][nt][3]};
-                }
-            }
+            epilogue<NT, NCH, EPI>(p, acc, mt, m, m < p.M, gch * NCH * NT * 16, g4);
         }
     }
 }
 
-template <int KSTEPS, int NT>
-int launch_epi(const GrlLinearArgs& p, hipStream_t st) {
+template <int KSTEPS, int NT, int NCH, int EPI>
+int launch_one(const GrlLinearArgs& p, hipStream_t st) {
     const int grid = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const size_t lds = (size_t)NT * 16 * (KSTEPS * 64 + 16);
-#define GRL_LAUNCH_EPI(E)                                                                                   \
-    case E: {                                                                                               \
-        auto kfn = linear_kernel<KSTEPS, NT, E>;                                                            \
-        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                           (int)lds);                                                       \
-        if (e != hipSuccess) return (int)e;                                                                 \
-        hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, st, p);                                  \
-        break;                                                                                              \
-    }
-    switch (p.epi) {
-        GRL_LAUNCH_EPI(GRL_EPI_PLAIN)
-        GRL_LAUNCH_EPI(GRL_EPI_GELU)
-        GRL_LAUNCH_EPI(GRL_EPI_GROUPNORM)
-        GRL_LAUNCH_EPI(GRL_EPI_LN_RES)
-        default: return GRL_ERR_UNSUPPORTED;
-    }
-#undef GRL_LAUNCH_EPI
+    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, st, p);
     GRL_CHECK_LAUNCH();
     return 0;
 }
 
+// chunk = NT n-tiles (NT*16 output channels) of weights in LDS; small chunks keep several
+// workgroups resident per CU.  LayerNorm needs the whole row: NCH = Npad / (NT*16) chunks in registers.
 template <int KSTEPS>
-int launch_nt(const GrlLinearArgs& p, int nt, hipStream_t st) {
+int launch_k(const GrlLinearArgs& p, hipStream_t st) {
+    const int tiles = p.Npad / 16;
+    if (p.epi == GRL_EPI_LN_RES) {
+        switch (tiles) {
+            case 12: return launch_one<KSTEPS, 6, 2, GRL_EPI_LN_RES>(p, st);
+            case 8: return launch_one<KSTEPS, 4, 2, GRL_EPI_LN_RES>(p, st);
+            case 4: return launch_one<KSTEPS, 4, 1, GRL_EPI_LN_RES>(p, st);
+            default: return GRL_ERR_UNSUPPORTED;
+        }
+    }
+    int nt = 0;
+    const int cand[3] = {6, 4, 8};
+    for (int i = 0; i < 3; ++i)
+        if (tiles % cand[i] == 0) { nt = cand[i]; break; }
+#define GRL_LIN_CASE(NTV)                                                                         \
+    case NTV:                                                                                     \
+        switch (p.epi) {                                                                          \
+            case GRL_EPI_PLAIN: return launch_one<KSTEPS, NTV, 1, GRL_EPI_PLAIN>(p, st);          \
+            case GRL_EPI_GELU: return launch_one<KSTEPS, NTV, 1, GRL_EPI_GELU>(p, st);            \
+            case GRL_EPI_GROUPNORM: return launch_one<KSTEPS, NTV, 1, GRL_EPI_GROUPNORM>(p, st);  \
+            default: return GRL_ERR_UNSUPPORTED;                                                  \
+        }
     switch (nt) {
-        case 4: return launch_epi<KSTEPS, 4>(p, st);
-        case 6: return launch_epi<KSTEPS, 6>(p, st);
-        case 8: return launch_epi<KSTEPS, 8>(p, st);
-        case 12: return launch_epi<KSTEPS, 12>(p, st);
+        GRL_LIN_CASE(6)
+        GRL_LIN_CASE(4)
+        GRL_LIN_CASE(8)
         default: return GRL_ERR_UNSUPPORTED;
     }
+#undef GRL_LIN_CASE
 }
 
 }  // namespace
@@ -276,22 +301,14 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.M <= 0) return 0;
     if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % 8 != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
-    // widest chunk (<= 12 n-tiles) that divides Npad
-    int nt = 0;
-    const int tiles = p.Npad / 16;
-    const int cand[4] = {12, 8, 6, 4};
-    for (int i = 0; i < 4; ++i)
-        if (tiles % cand[i] == 0) { nt = cand[i]; break; }
-    if (tiles == 2) return GRL_ERR_UNSUPPORTED;
-    if (nt == 0) return GRL_ERR_UNSUPPORTED;
-    if (p.epi == GRL_EPI_LN_RES && nt * 16 != p.Npad) return GRL_ERR_BAD_ARG;
+    if (p.add2_scale != nullptr && p.rows_per_image <= 0) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (p.Kpad / 32) {
-        case 2: return launch_nt<2>(p, nt, st);
-        case 4: return launch_nt<4>(p, nt, st);
-        case 6: return launch_nt<6>(p, nt, st);
-        case 8: return launch_nt<8>(p, nt, st);
-        case 12: return launch_nt<12>(p, nt, st);
+        case 2: return launch_k<2>(p, st);
+        case 4: return launch_k<4>(p, st);
+        case 6: return launch_k<6>(p, st);
+        case 8: return launch_k<8>(p, st);
+        case 12: return launch_k<12>(p, st);
         default: return GRL_ERR_UNSUPPORTED;
     }
 }
