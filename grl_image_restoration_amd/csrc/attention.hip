@@ -24,6 +24,7 @@
 // K (XOR-swizzled rows) and V^T chunks of 256 keys are staged in LDS and shared by the waves.
 #include "common.h"
 #include "grl_hip_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -280,6 +281,189 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------
+// Fast path: 32-aligned windows (q.ww % 32 == 0, k.ww % 32 == 0, q.wh even, k.wh % 8 == 0), fixed
+// softmax bound, ones column.  Covers the released-checkpoint geometries (window 32; stripes
+// 64x64 / 64x128 and their anchor grids) -- the MFMA-bound regime of SURVEY 8(d).
+//
+//   * 8 waves per workgroup share one K / V^T chunk and the bias table (2 workgroups per CU);
+//   * a wave owns two query tiles: the SAME 32-wide column segment of two consecutive window
+//     rows (hq, hq+1).  Keys are visited strip by strip: key tile = 32-wide segment sk of key row
+//     hk, rows innermost.  The relative-position bias depends only on (hq - hk, wq - wk), so the
+//     bias fragment of (row hq+1, key row hk+1) equals that of (row hq, key row hk): the second
+//     query tile re-uses the fragment the first one gathered one key tile earlier, and only the
+//     first key row of a strip is gathered twice -> LDS bias reads per MFMA are halved;
+//   * the bias fragment is the MFMA C operand (kept intact for the re-use), S^T = mfma(K, Q, bias)
+//     is the log2-domain logit, P = exp2(S^T) goes to bf16 in the PV operand order,
+//     O^T += V^T P^T.  Softmax needs no running maximum (fixed bound) so key order is free.
+// ------------------------------------------------------------------------------------------------
+constexpr int FW = 6;       // waves per workgroup (2 workgroups = 12 waves = 3 per SIMD at <= 168 VGPRs)
+constexpr int FROWS = 8;    // key rows per LDS chunk (chunk = FROWS x 32 keys of one strip = KC)
+
+__global__ __launch_bounds__(FW * 64, 3) void attn_fast_kernel(GrlAttnArgs p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int qseg = p.q.ww >> 5;                      // 32-wide segments per query row
+    const int units = (p.q.wh >> 1) * qseg;            // (row pair, segment) units per window
+    const int upw = min(FW, units);                    // units (= active waves) per workgroup
+    const int nqs = (units + upw - 1) / upw;
+    int bid = blockIdx.x;
+    const int qs = bid % nqs; bid /= nqs;
+    const int head = bid % p.nh; bid /= p.nh;
+    const int wx = bid % p.nwx; bid /= p.nwx;
+    const int wy = bid % p.nwy;
+    const int b = bid / p.nwy;
+    const int D = p.q.ww + p.k.ww - 1;
+
+    float* tab = (float*)smem;
+    char* Ks = smem + (((size_t)p.trows * 4 + 15) & ~(size_t)15);
+    char* Vt = Ks + KC * 64;
+    unsigned char* kreg = (unsigned char*)(Vt + 32 * VROW);
+
+    for (int i = tid; i < p.trows; i += FW * 64) tab[i] = p.table[(int64_t)head * p.trows + i];
+    const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+
+    // ---- this wave's unit: query rows (2*pr, 2*pr+1), segment sg ----
+    int unit = qs * upw + wave;
+    const bool active = wave < upw && unit < units;
+    if (!active) unit = 0;
+    const int pr = unit / qseg, sg = unit - pr * qseg;
+    int Ub[2], idq[2];
+    int64_t qrow[2];
+    bf16x8 qf[2][2];
+    f32x16 O[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int hq = 2 * pr + t, wq = 32 * sg + l31;
+        locate(p.q, b, wy, wx, hq * p.q.ww + wq, qrow[t], idq[t]);
+        // table index of (query, key (hk, wk)) = Ub - hk*D - wk; lane's key rows i = (r&3)+8*(r>>2)+4*half
+        Ub[t] = hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1) - 4 * half - 27;
+        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * 32 + 8 * half;
+        qf[t][0] = *(const bf16x8*)(src);
+        qf[t][1] = *(const bf16x8*)(src + 16);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
+    }
+    f32x16 hist;  // bias fragment of (query tile 0, previous key row) == (query tile 1, this key row)
+
+    const int kseg = p.k.ww >> 5;
+    const int nrc = p.k.wh / FROWS;  // chunks per strip
+#pragma unroll 1
+    for (int ch = 0; ch < kseg * nrc; ++ch) {
+        const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
+        __syncthreads();
+        // stage keys (hk0 + kk/32, 32*sk + kk%32): K rows with XOR-swizzled 16-B slots, V transposed
+        for (int i = tid; i < KC * 4; i += FW * 64) {
+            const int kk = i >> 2, seg = i & 3;
+            int64_t row; int rid;
+            locate(p.k, b, wy, wx, (hk0 + (kk >> 5)) * p.k.ww + 32 * sk + (kk & 31), row, rid);
+            const bf16x8 kv = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
+            const bf16x8 vv = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
+            *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
+            if (seg == 0) kreg[kk] = (unsigned char)rid;
+        }
+        __syncthreads();
+        if (!active) continue;
+
+#pragma unroll 1
+        for (int kt = 0; kt < FROWS; ++kt) {
+            const int kb = kt * 32, hk = hk0 + kt;
+            bf16x8 kf[2], vf[2];
+            {
+                const int kk = kb + l31;
+                const int sw = (kk >> 2) & 3;
+                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
+                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
+            }
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const char* vp = Vt + l31 * VROW + (kb + 16 * s2 + 4 * half) * 2;
+                const bf16x4 lo = *(const bf16x4*)(vp);
+                const bf16x4 hi = *(const bf16x4*)(vp + 16);
+                vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            }
+            uint32_t ids[4] = {0, 0, 0, 0};
+            if (border) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
+            }
+            if (hk == 0) {  // first key row of a strip: query tile 1 has no predecessor fragment
+                const float* tp = tab + (Ub[1] - 32 * sk);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) hist[r] = tp[27 - ((r & 3) + 8 * (r >> 2))];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int t = 1 - tt;  // tile 1 first: it consumes the fragment gathered for tile 0 one row earlier
+                if (t == 0) {
+                    const float* tp = tab + (Ub[0] - hk * D - 32 * sk);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) hist[r] = tp[27 - ((r & 3) + 8 * (r >> 2))];
+                }
+                f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], hist, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S, 0, 0, 0);
+                if (border) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
+                        S[r] += idk != idq[t] ? MASK_L2 : 0.f;
+                    }
+                }
+                bf16x8 pb[2];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[r]);
+                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t], 0, 0, 0);
+                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t], 0, 0, 0);
+            }
+        }
+    }
+    if (!active) return;
+
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        const int oc = p.ones_col;
+        const int base_row = oc & ~4;
+        float cand = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r)
+            if (mfma32_row(r, 0) == base_row) cand = O[t][r];
+        const float other = xhalf(cand);
+        const float l = (half == ((oc >> 2) & 1)) ? cand : other;
+        const float inv = 1.0f / l;
+        bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * 32 + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_bf16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv);
+            pk.y = pack_bf16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv);
+            *(uint2*)(dst + 8 * g) = pk;
+        }
+    }
+}
+
+size_t fast_lds_bytes(const GrlAttnArgs& p) {
+    return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC;
+}
+
+int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
+    const int units = (p.q.wh >> 1) * (p.q.ww >> 5);
+    const int upw = min(FW, units);
+    const int nqs = (units + upw - 1) / upw;
+    const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
+    if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
+    const size_t lds = fast_lds_bytes(p);
+    auto kfn = attn_fast_kernel;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
@@ -293,6 +477,12 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 4) || (p.q.col0 % 8) || (p.k.col0 % 8) ||
         (p.v.col0 % 8) || (p.o.col0 % 4))
         return GRL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    // fast path: 32-aligned geometry with the fixed softmax bound and the ones column
+    static_assert(KC == FROWS * 32, "one chunk = FROWS key rows of one 32-wide strip");
+    if (p.fixed_max && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
+        (p.k.wh % FROWS) == 0 && fast_lds_bytes(p) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
+        return launch_fast(p, st);
     const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
     const int qblk = waves * QT * 32;
     const int nqs = (Nq + qblk - 1) / qblk;
@@ -300,7 +490,6 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
     const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC * 4 + KC;
     if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
-    hipStream_t st = (hipStream_t)stream;
     const bool ones = p.ones_col >= 0;
     if (p.fixed_max) return ones ? launch_kw<true, true>(p, (int)grid, waves * 64, lds, st)
                                  : launch_kw<true, false>(p, (int)grid, waves * 64, lds, st);
