@@ -298,10 +298,11 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 //     is the log2-domain logit, P = exp2(S^T) goes to bf16 in the PV operand order,
 //     O^T += V^T P^T.  Softmax needs no running maximum (fixed bound) so key order is free.
 // ------------------------------------------------------------------------------------------------
-constexpr int FW = 6;       // waves per workgroup (2 workgroups = 12 waves = 3 per SIMD at <= 168 VGPRs)
 constexpr int FROWS = 8;    // key rows per LDS chunk (chunk = FROWS x 32 keys of one strip = KC)
 
-__global__ __launch_bounds__(FW * 64, 3) void attn_fast_kernel(GrlAttnArgs p) {
+// FW = waves per workgroup; PREFETCH = register-staged prefetch of the next K/V chunk
+template <int FW, bool PREFETCH>
+__global__ __launch_bounds__(FW * 64, (FW == 4 ? 2 : (FW == 6 ? 3 : 4))) void attn_fast_kernel(GrlAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -322,7 +323,8 @@ __global__ __launch_bounds__(FW * 64, 3) void attn_fast_kernel(GrlAttnArgs p) {
     char* Vt = Ks + KC * 64;
     unsigned char* kreg = (unsigned char*)(Vt + 32 * VROW);
 
-    for (int i = tid; i < p.trows; i += FW * 64) tab[i] = p.table[(int64_t)head * p.trows + i];
+    // the table is stored REVERSED so that a lane's 16 key rows read ascending addresses
+    for (int i = tid; i < p.trows; i += FW * 64) tab[p.trows - 1 - i] = p.table[(int64_t)head * p.trows + i];
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
 
     // ---- this wave's unit: query rows (2*pr, 2*pr+1), segment sg ----
@@ -338,8 +340,9 @@ __global__ __launch_bounds__(FW * 64, 3) void attn_fast_kernel(GrlAttnArgs p) {
     for (int t = 0; t < 2; ++t) {
         const int hq = 2 * pr + t, wq = 32 * sg + l31;
         locate(p.q, b, wy, wx, hq * p.q.ww + wq, qrow[t], idq[t]);
-        // table index of (query, key (hk, wk)) = Ub - hk*D - wk; lane's key rows i = (r&3)+8*(r>>2)+4*half
-        Ub[t] = hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1) - 4 * half - 27;
+        // table index of (query, key (hk, wk)) = U - hk*D - wk, reversed: (trows-1-U) + hk*D + wk;
+        // lane's key rows are wk = 32*sk + i, i = (r&3) + 8*(r>>2) + 4*half
+        Ub[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1)) + 4 * half;
         const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * 32 + 8 * half;
         qf[t][0] = *(const bf16x8*)(src);
         qf[t][1] = *(const bf16x8*)(src + 16);
@@ -350,23 +353,55 @@ __global__ __launch_bounds__(FW * 64, 3) void attn_fast_kernel(GrlAttnArgs p) {
 
     const int kseg = p.k.ww >> 5;
     const int nrc = p.k.wh / FROWS;  // chunks per strip
-#pragma unroll 1
-    for (int ch = 0; ch < kseg * nrc; ++ch) {
+    const int nch = kseg * nrc;
+
+    // ---- K / V staging: each thread owns up to SPT fixed (key, 16-B segment) slots of a chunk; the
+    // global loads of chunk c+1 are issued before the MFMA loop of chunk c and land in registers ----
+    constexpr int SPT = (KC * 4 + FW * 64 - 1) / (FW * 64);
+    bf16x8 pk_[SPT], pv_[SPT];
+    int prid[SPT];
+    auto issue = [&](int ch) {
         const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
-        __syncthreads();
-        // stage keys (hk0 + kk/32, 32*sk + kk%32): K rows with XOR-swizzled 16-B slots, V transposed
-        for (int i = tid; i < KC * 4; i += FW * 64) {
-            const int kk = i >> 2, seg = i & 3;
-            int64_t row; int rid;
-            locate(p.k, b, wy, wx, (hk0 + (kk >> 5)) * p.k.ww + 32 * sk + (kk & 31), row, rid);
-            const bf16x8 kv = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
-            const bf16x8 vv = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
-            *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
-            if (seg == 0) kreg[kk] = (unsigned char)rid;
+        for (int j = 0; j < SPT; ++j) {
+            const int i = tid + j * FW * 64;
+            if (i < KC * 4) {
+                const int kk = i >> 2, seg = i & 3;
+                const int ry = wy * p.k.wh + hk0 + (kk >> 5), rx = wx * p.k.ww + 32 * sk + (kk & 31);
+                int oy = ry + p.k.shy; if (oy >= p.k.Himg) oy -= p.k.Himg;
+                int ox = rx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
+                const int64_t row = ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
+                pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
+                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
+                prid[j] = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
+            }
         }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int i = tid + j * FW * 64;
+            if (i < KC * 4) {
+                const int kk = i >> 2, seg = i & 3;
+                *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = pv_[j][e];
+                if (seg == 0) kreg[kk] = (unsigned char)prid[j];
+            }
+        }
+    };
+
+    if constexpr (PREFETCH) issue(0);
+#pragma unroll 1
+    for (int ch = 0; ch < nch; ++ch) {
+        const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
+        if constexpr (!PREFETCH) issue(ch);
+        __syncthreads();   // everyone is done reading the previous chunk
+        commit();
         __syncthreads();
+        if constexpr (PREFETCH) {
+            if (ch + 1 < nch) issue(ch + 1);   // in flight during the MFMA loop below
+        }
         if (!active) continue;
 
 #pragma unroll 1
@@ -392,17 +427,17 @@ __global__ __launch_bounds__(FW * 64, 3) void attn_fast_kernel(GrlAttnArgs p) {
                 for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
             }
             if (hk == 0) {  // first key row of a strip: query tile 1 has no predecessor fragment
-                const float* tp = tab + (Ub[1] - 32 * sk);
+                const float* tp = tab + (Ub[1] + 32 * sk);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hist[r] = tp[27 - ((r & 3) + 8 * (r >> 2))];
+                for (int r = 0; r < 16; ++r) hist[r] = tp[(r & 3) + 8 * (r >> 2)];
             }
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) {
                 const int t = 1 - tt;  // tile 1 first: it consumes the fragment gathered for tile 0 one row earlier
                 if (t == 0) {
-                    const float* tp = tab + (Ub[0] - hk * D - 32 * sk);
+                    const float* tp = tab + (Ub[0] + hk * D + 32 * sk);
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) hist[r] = tp[27 - ((r & 3) + 8 * (r >> 2))];
+                    for (int r = 0; r < 16; ++r) hist[r] = tp[(r & 3) + 8 * (r >> 2)];
                 }
                 f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], hist, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S, 0, 0, 0);
@@ -449,19 +484,30 @@ size_t fast_lds_bytes(const GrlAttnArgs& p) {
     return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC;
 }
 
-int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
+template <int FW, bool PREFETCH>
+int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     const int units = (p.q.wh >> 1) * (p.q.ww >> 5);
     const int upw = min(FW, units);
     const int nqs = (units + upw - 1) / upw;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
     const size_t lds = fast_lds_bytes(p);
-    auto kfn = attn_fast_kernel;
+    auto kfn = attn_fast_kernel<FW, PREFETCH>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p);
     GRL_CHECK_LAUNCH();
     return 0;
+}
+
+int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
+    static const int variant = getenv("GRL_ATTN_VARIANT") ? atoi(getenv("GRL_ATTN_VARIANT")) : 0;
+    switch (variant) {
+        case 1: return launch_fast_v<6, false>(p, st);
+        case 2: return launch_fast_v<8, false>(p, st);
+        case 3: return launch_fast_v<4, false>(p, st);
+        default: return launch_fast_v<4, true>(p, st);
+    }
 }
 
 }  // namespace
