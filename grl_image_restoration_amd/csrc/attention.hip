@@ -283,31 +283,29 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 
 
 // ------------------------------------------------------------------------------------------------
-// Fast path: 32-aligned windows (q.ww % 32 == 0, k.ww % 32 == 0, q.wh even, k.wh % 8 == 0), fixed
-// softmax bound, ones column.  Covers the released-checkpoint geometries (window 32; stripes
-// 64x64 / 64x128 and their anchor grids) -- the MFMA-bound regime of SURVEY 8(d).
+// Fast path: 32-aligned windows (q.ww % 32 == 0, k.ww % 32 == 0, q.wh % QTN == 0, k.wh % 8 == 0),
+// fixed softmax bound, ones column.  Covers the released-checkpoint geometries (window 32;
+// stripes 64x64 / 64x128 and their anchor grids) -- the MFMA-bound regime of SURVEY 8(d).
 //
-//   * 8 waves per workgroup share one K / V^T chunk and the bias table (2 workgroups per CU);
-//   * a wave owns two query tiles: the SAME 32-wide column segment of two consecutive window
-//     rows (hq, hq+1).  Keys are visited strip by strip: key tile = 32-wide segment sk of key row
-//     hk, rows innermost.  The relative-position bias depends only on (hq - hk, wq - wk), so the
-//     bias fragment of (row hq+1, key row hk+1) equals that of (row hq, key row hk): the second
-//     query tile re-uses the fragment the first one gathered one key tile earlier, and only the
-//     first key row of a strip is gathered twice -> LDS bias reads per MFMA are halved;
-//   * the bias fragment is the MFMA C operand (kept intact for the re-use), S^T = mfma(K, Q, bias)
-//     is the log2-domain logit, P = exp2(S^T) goes to bf16 in the PV operand order,
-//     O^T += V^T P^T.  Softmax needs no running maximum (fixed bound) so key order is free.
+//   * FW waves per workgroup share one K / V^T chunk (8 key rows x 32 keys of one 32-wide strip)
+//     and the bias table; loads of a chunk are issued back to back, then committed to LDS;
+//   * a wave owns QTN query tiles: the same 32-wide column segment of QTN consecutive window rows,
+//     so K / V^T fragments are read once per QTN tiles and QTN independent MFMA chains are in
+//     flight per wave;
+//   * a key tile is a 32-wide segment of one key row: the bias of (query lane, key row i) is
+//     tab[U + i] with the table stored reversed, i.e. plain ascending LDS reads that initialise the
+//     accumulator; S^T = mfma(K, Q, bias) is the log2-domain logit, P = exp2(S^T) goes to bf16 in
+//     the PV operand order, O^T += V^T P^T.  No running maximum (fixed bound) -> key order is free.
 // ------------------------------------------------------------------------------------------------
 constexpr int FROWS = 8;    // key rows per LDS chunk (chunk = FROWS x 32 keys of one strip = KC)
 
-// FW = waves per workgroup; PREFETCH = register-staged prefetch of the next K/V chunk
-template <int FW, bool PREFETCH>
-__global__ __launch_bounds__(FW * 64, (FW == 4 ? 2 : (FW == 6 ? 3 : 4))) void attn_fast_kernel(GrlAttnArgs p) {
+template <int FW, int QTN>
+__global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
     const int qseg = p.q.ww >> 5;                      // 32-wide segments per query row
-    const int units = (p.q.wh >> 1) * qseg;            // (row pair, segment) units per window
+    const int units = (p.q.wh / QTN) * qseg;           // (row group, segment) units per window
     const int upw = min(FW, units);                    // units (= active waves) per workgroup
     const int nqs = (units + upw - 1) / upw;
     int bid = blockIdx.x;
@@ -327,18 +325,18 @@ __global__ __launch_bounds__(FW * 64, (FW == 4 ? 2 : (FW == 6 ? 3 : 4))) void at
     for (int i = tid; i < p.trows; i += FW * 64) tab[p.trows - 1 - i] = p.table[(int64_t)head * p.trows + i];
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
 
-    // ---- this wave's unit: query rows (2*pr, 2*pr+1), segment sg ----
+    // ---- this wave's unit: query rows QTN*pr .. QTN*pr+QTN-1, segment sg ----
     int unit = qs * upw + wave;
     const bool active = wave < upw && unit < units;
     if (!active) unit = 0;
     const int pr = unit / qseg, sg = unit - pr * qseg;
-    int Ub[2], idq[2];
-    int64_t qrow[2];
-    bf16x8 qf[2][2];
-    f32x16 O[2];
+    int Ub[QTN], idq[QTN];
+    int64_t qrow[QTN];
+    bf16x8 qf[QTN][2];
+    f32x16 O[QTN];
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
-        const int hq = 2 * pr + t, wq = 32 * sg + l31;
+    for (int t = 0; t < QTN; ++t) {
+        const int hq = QTN * pr + t, wq = 32 * sg + l31;
         locate(p.q, b, wy, wx, hq * p.q.ww + wq, qrow[t], idq[t]);
         // table index of (query, key (hk, wk)) = U - hk*D - wk, reversed: (trows-1-U) + hk*D + wk;
         // lane's key rows are wk = 32*sk + i, i = (r&3) + 8*(r>>2) + 4*half
@@ -349,64 +347,49 @@ __global__ __launch_bounds__(FW * 64, (FW == 4 ? 2 : (FW == 6 ? 3 : 4))) void at
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
     }
-    f32x16 hist;  // bias fragment of (query tile 0, previous key row) == (query tile 1, this key row)
 
     const int kseg = p.k.ww >> 5;
     const int nrc = p.k.wh / FROWS;  // chunks per strip
     const int nch = kseg * nrc;
 
-    // ---- K / V staging: each thread owns up to SPT fixed (key, 16-B segment) slots of a chunk; the
-    // global loads of chunk c+1 are issued before the MFMA loop of chunk c and land in registers ----
-    constexpr int SPT = (KC * 4 + FW * 64 - 1) / (FW * 64);
-    bf16x8 pk_[SPT], pv_[SPT];
-    int prid[SPT];
-    auto issue = [&](int ch) {
-        const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int i = tid + j * FW * 64;
-            if (i < KC * 4) {
-                const int kk = i >> 2, seg = i & 3;
-                const int ry = wy * p.k.wh + hk0 + (kk >> 5), rx = wx * p.k.ww + 32 * sk + (kk & 31);
-                int oy = ry + p.k.shy; if (oy >= p.k.Himg) oy -= p.k.Himg;
-                int ox = rx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
-                const int64_t row = ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
-                pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
-                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
-                prid[j] = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
-            }
-        }
-    };
-    auto commit = [&]() {
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int i = tid + j * FW * 64;
-            if (i < KC * 4) {
-                const int kk = i >> 2, seg = i & 3;
-                *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = pv_[j][e];
-                if (seg == 0) kreg[kk] = (unsigned char)prid[j];
-            }
-        }
-    };
+    // ---- K / V staging: each thread owns SPT fixed (key, 16-B segment) slots of a chunk ----
+    constexpr int SPT = (KC * 4) / (FW * 64);
+    static_assert(SPT * FW * 64 == KC * 4, "chunk must divide evenly over the workgroup");
 
-    if constexpr (PREFETCH) issue(0);
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
-        if constexpr (!PREFETCH) issue(ch);
-        __syncthreads();   // everyone is done reading the previous chunk
-        commit();
-        __syncthreads();
-        if constexpr (PREFETCH) {
-            if (ch + 1 < nch) issue(ch + 1);   // in flight during the MFMA loop below
+        bf16x8 pk_[SPT], pv_[SPT];
+        int prid[SPT];
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int i = tid + j * FW * 64;
+            const int kk = i >> 2, seg = i & 3;
+            const int ry = wy * p.k.wh + hk0 + (kk >> 5), rx = wx * p.k.ww + 32 * sk + (kk & 31);
+            int oy = ry + p.k.shy; if (oy >= p.k.Himg) oy -= p.k.Himg;
+            int ox = rx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
+            const int64_t row = ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
+            pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
+            pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
+            prid[j] = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
         }
+        __syncthreads();   // everyone is done reading the previous chunk
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const int i = tid + j * FW * 64;
+            const int kk = i >> 2, seg = i & 3;
+            *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = pv_[j][e];
+            if (seg == 0) kreg[kk] = (unsigned char)prid[j];
+        }
+        __syncthreads();
         if (!active) continue;
 
 #pragma unroll 1
         for (int kt = 0; kt < FROWS; ++kt) {
-            const int kb = kt * 32, hk = hk0 + kt;
+            const int kb = kt * 32;
+            const int toff = (hk0 + kt) * D + 32 * sk;
             bf16x8 kf[2], vf[2];
             {
                 const int kk = kb + l31;
@@ -426,20 +409,15 @@ __global__ __launch_bounds__(FW * 64, (FW == 4 ? 2 : (FW == 6 ? 3 : 4))) void at
 #pragma unroll
                 for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
             }
-            if (hk == 0) {  // first key row of a strip: query tile 1 has no predecessor fragment
-                const float* tp = tab + (Ub[1] + 32 * sk);
 #pragma unroll
-                for (int r = 0; r < 16; ++r) hist[r] = tp[(r & 3) + 8 * (r >> 2)];
-            }
+            for (int t = 0; t < QTN; ++t) {
+                f32x16 S;
+                {
+                    const float* tp = tab + (Ub[t] + toff);
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int t = 1 - tt;  // tile 1 first: it consumes the fragment gathered for tile 0 one row earlier
-                if (t == 0) {
-                    const float* tp = tab + (Ub[0] + hk * D + 32 * sk);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) hist[r] = tp[(r & 3) + 8 * (r >> 2)];
+                    for (int r = 0; r < 16; ++r) S[r] = tp[(r & 3) + 8 * (r >> 2)];
                 }
-                f32x16 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], hist, 0, 0, 0);
+                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], S, 0, 0, 0);
                 S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S, 0, 0, 0);
                 if (border) {
 #pragma unroll
@@ -459,7 +437,7 @@ __global__ __launch_bounds__(FW * 64, (FW == 4 ? 2 : (FW == 6 ? 3 : 4))) void at
     if (!active) return;
 
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < QTN; ++t) {
         const int oc = p.ones_col;
         const int base_row = oc & ~4;
         float cand = 0.f;
@@ -484,15 +462,15 @@ size_t fast_lds_bytes(const GrlAttnArgs& p) {
     return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC;
 }
 
-template <int FW, bool PREFETCH>
+template <int FW, int QTN>
 int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
-    const int units = (p.q.wh >> 1) * (p.q.ww >> 5);
+    const int units = (p.q.wh / QTN) * (p.q.ww >> 5);
     const int upw = min(FW, units);
     const int nqs = (units + upw - 1) / upw;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
     const size_t lds = fast_lds_bytes(p);
-    auto kfn = attn_fast_kernel<FW, PREFETCH>;
+    auto kfn = attn_fast_kernel<FW, QTN>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p);
@@ -502,12 +480,8 @@ int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
 
 int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     static const int variant = getenv("GRL_ATTN_VARIANT") ? atoi(getenv("GRL_ATTN_VARIANT")) : 0;
-    switch (variant) {
-        case 1: return launch_fast_v<6, false>(p, st);
-        case 2: return launch_fast_v<8, false>(p, st);
-        case 3: return launch_fast_v<4, false>(p, st);
-        default: return launch_fast_v<4, true>(p, st);
-    }
+    if (variant == 1 || (p.q.wh % 4) != 0) return launch_fast_v<4, 2>(p, st);
+    return launch_fast_v<4, 4>(p, st);
 }
 
 }  // namespace
