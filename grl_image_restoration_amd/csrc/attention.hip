@@ -297,10 +297,12 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 //     accumulator; S^T = mfma(K, Q, bias) is the log2-domain logit, P = exp2(S^T) goes to bf16 in
 //     the PV operand order, O^T += V^T P^T.  No running maximum (fixed bound) -> key order is free.
 // ------------------------------------------------------------------------------------------------
-constexpr int FROWS = 8;    // key rows per LDS chunk (chunk = FROWS x 32 keys of one strip = KC)
 
-template <int FW, int QTN>
-__global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
+// FROWS = key rows per LDS chunk (chunk = FROWS x 32 keys of one strip); WPS = waves per SIMD to allocate for
+template <int FW, int QTN, int FROWS, int WPS, bool PIPE>
+__global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) {
+    constexpr int FKC = FROWS * 32;
+    constexpr int FVROW = FKC * 2 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -318,8 +320,8 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
 
     float* tab = (float*)smem;
     char* Ks = smem + (((size_t)p.trows * 4 + 15) & ~(size_t)15);
-    char* Vt = Ks + KC * 64;
-    unsigned char* kreg = (unsigned char*)(Vt + 32 * VROW);
+    char* Vt = Ks + FKC * 64;
+    unsigned char* kreg = (unsigned char*)(Vt + 32 * FVROW);
 
     // the table is stored REVERSED so that a lane's 16 key rows read ascending addresses
     for (int i = tid; i < p.trows; i += FW * 64) tab[p.trows - 1 - i] = p.table[(int64_t)head * p.trows + i];
@@ -353,8 +355,8 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
     const int nch = kseg * nrc;
 
     // ---- K / V staging: each thread owns SPT fixed (key, 16-B segment) slots of a chunk ----
-    constexpr int SPT = (KC * 4) / (FW * 64);
-    static_assert(SPT * FW * 64 == KC * 4, "chunk must divide evenly over the workgroup");
+    constexpr int SPT = (FKC * 4) / (FW * 64);
+    static_assert(SPT * FW * 64 == FKC * 4, "chunk must divide evenly over the workgroup");
 
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
@@ -380,17 +382,16 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
             const int kk = i >> 2, seg = i & 3;
             *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = pv_[j][e];
+            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * FVROW + kk * 2) = pv_[j][e];
             if (seg == 0) kreg[kk] = (unsigned char)prid[j];
         }
         __syncthreads();
         if (!active) continue;
 
-#pragma unroll 1
-        for (int kt = 0; kt < FROWS; ++kt) {
+        // LDS reads of one key tile: K fragments, V^T fragments, bias fragments (accumulator init), key region ids
+        auto lds_tile = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], f32x16 (&S)[QTN], uint32_t (&ids)[4]) {
             const int kb = kt * 32;
             const int toff = (hk0 + kt) * D + 32 * sk;
-            bf16x8 kf[2], vf[2];
             {
                 const int kk = kb + l31;
                 const int sw = (kk >> 2) & 3;
@@ -399,38 +400,64 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
             }
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
-                const char* vp = Vt + l31 * VROW + (kb + 16 * s2 + 4 * half) * 2;
+                const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
                 const bf16x4 lo = *(const bf16x4*)(vp);
                 const bf16x4 hi = *(const bf16x4*)(vp + 16);
                 vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
-            uint32_t ids[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int t = 0; t < QTN; ++t) {
+                const float* tp = tab + (Ub[t] + toff);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) S[t][r] = tp[(r & 3) + 8 * (r >> 2)];
+            }
             if (border) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
             }
+        };
+        auto compute_tile = [&](bf16x8 (&kf)[2], bf16x8 (&vf)[2], f32x16 (&S)[QTN], uint32_t (&ids)[4]) {
+#pragma unroll
+            for (int t = 0; t < QTN; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], S[t], 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < QTN; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S[t], 0, 0, 0);
 #pragma unroll
             for (int t = 0; t < QTN; ++t) {
-                f32x16 S;
-                {
-                    const float* tp = tab + (Ub[t] + toff);
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[r] = tp[(r & 3) + 8 * (r >> 2)];
-                }
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], S, 0, 0, 0);
-                S = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S, 0, 0, 0);
                 if (border) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
-                        S[r] += idk != idq[t] ? MASK_L2 : 0.f;
+                        S[t][r] += idk != idq[t] ? MASK_L2 : 0.f;
                     }
                 }
                 bf16x8 pb[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[r]);
+                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[t][r]);
                 O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t], 0, 0, 0);
                 O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t], 0, 0, 0);
+            }
+        };
+        if constexpr (PIPE) {
+            // two register sets (A, B): while one key tile is in the matrix core the next one's LDS reads are in flight
+            bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
+            f32x16 SA[QTN], SB[QTN];
+            uint32_t idA[4] = {0, 0, 0, 0}, idB[4] = {0, 0, 0, 0};
+            lds_tile(0, kfA, vfA, SA, idA);
+#pragma unroll 1
+            for (int kt = 0; kt < FROWS; kt += 2) {
+                lds_tile(kt + 1, kfB, vfB, SB, idB);
+                compute_tile(kfA, vfA, SA, idA);
+                if (kt + 2 < FROWS) lds_tile(kt + 2, kfA, vfA, SA, idA);
+                compute_tile(kfB, vfB, SB, idB);
+            }
+        } else {
+#pragma unroll 1
+            for (int kt = 0; kt < FROWS; ++kt) {
+                bf16x8 kf[2], vf[2];
+                f32x16 S[QTN];
+                uint32_t ids[4] = {0, 0, 0, 0};
+                lds_tile(kt, kf, vf, S, ids);
+                compute_tile(kf, vf, S, ids);
             }
         }
     }
@@ -458,19 +485,20 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
     }
 }
 
-size_t fast_lds_bytes(const GrlAttnArgs& p) {
-    return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC;
+size_t fast_lds_bytes(const GrlAttnArgs& p, int frows) {
+    const size_t kc = (size_t)frows * 32;
+    return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + kc * 64 + 32 * (kc * 2 + 8) + kc;
 }
 
-template <int FW, int QTN>
+template <int FW, int QTN, int FROWS, int WPS, bool PIPE>
 int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     const int units = (p.q.wh / QTN) * (p.q.ww >> 5);
     const int upw = min(FW, units);
     const int nqs = (units + upw - 1) / upw;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
-    const size_t lds = fast_lds_bytes(p);
-    auto kfn = attn_fast_kernel<FW, QTN>;
+    const size_t lds = fast_lds_bytes(p, FROWS);
+    auto kfn = attn_fast_kernel<FW, QTN, FROWS, WPS, PIPE>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p);
@@ -480,8 +508,10 @@ int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
 
 int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     static const int variant = getenv("GRL_ATTN_VARIANT") ? atoi(getenv("GRL_ATTN_VARIANT")) : 0;
-    if (variant == 1 || (p.q.wh % 4) != 0) return launch_fast_v<4, 2>(p, st);
-    return launch_fast_v<4, 4>(p, st);
+    if (variant == 1) return launch_fast_v<4, 2, 8, 2, false>(p, st);
+    if (variant == 2) return launch_fast_v<4, 2, 4, 3, false>(p, st);   // 3 workgroups per CU
+    if (variant == 3 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, false>(p, st);
+    return launch_fast_v<4, 2, 8, 2, true>(p, st);
 }
 
 }  // namespace
@@ -499,9 +529,8 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
         return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     // fast path: 32-aligned geometry with the fixed softmax bound and the ones column
-    static_assert(KC == FROWS * 32, "one chunk = FROWS key rows of one 32-wide strip");
     if (p.fixed_max && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
-        (p.k.wh % FROWS) == 0 && fast_lds_bytes(p) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
+        (p.k.wh % 8) == 0 && fast_lds_bytes(p, 8) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
         return launch_fast(p, st);
     const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
     const int qblk = waves * QT * 32;

@@ -1,0 +1,118 @@
+// Micro-benchmarks of the instruction mix the attention kernel depends on (gfx950).
+// Build: hipcc --offload-arch=gfx950 -O3 ubench.hip -o ubench ; run on the GPU box.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <vector>
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k(float* out, int iters) {
+    float x[16];
+    for (int i = 0; i < 16; ++i) x[i] = -0.001f * (threadIdx.x + i);
+    f32x16 acc = {0}, acc2 = {0};
+    bf16x8 a = {1, 1, 1, 1, 1, 1, 1, 1}, b = {1, 1, 1, 1, 1, 1, 1, 1};
+    for (int it = 0; it < iters; ++it) {
+        if constexpr (MODE == 0) {  // 16 independent v_exp_f32
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]) - 1.0f;
+        } else if constexpr (MODE == 1) {  // 16 independent v_fma_f32
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_fmaf(x[i], 0.999f, -0.5f);
+        } else if constexpr (MODE == 2) {  // 4 MFMA 32x32x16 (one accumulator chain)
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+        } else if constexpr (MODE == 3) {  // attention-like: 4 MFMA + 16 exp + 8 cvt
+            f32x16 s = {0};
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p0[i] = (__bf16)__builtin_amdgcn_exp2f(s[i] + x[i]); p1[i] = (__bf16)__builtin_amdgcn_exp2f(s[8 + i] + x[8 + i]); }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p1, acc, 0, 0, 0);
+        } else if constexpr (MODE == 5) {  // co-issue, no data dependency: 4 MFMA || 16 exp + 16 sub
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_amdgcn_exp2f(x[i]) - 1.0f;
+        } else if constexpr (MODE == 6) {  // co-issue, no dependency: 4 MFMA || 32 fma
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] = __builtin_fmaf(__builtin_fmaf(x[i], 0.999f, -0.5f), 1.001f, 0.25f);
+        } else if constexpr (MODE == 7) {  // dependent like attention but 2 independent tiles interleaved in source
+            f32x16 s0 = {0}, s1 = {0};
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(b, a, s1, 0, 0, 0);
+            bf16x8 p0, p1, q0, q1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p0[i] = (__bf16)__builtin_amdgcn_exp2f(s0[i]); p1[i] = (__bf16)__builtin_amdgcn_exp2f(s0[8 + i]); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { q0[i] = (__bf16)__builtin_amdgcn_exp2f(s1[i]); q1[i] = (__bf16)__builtin_amdgcn_exp2f(s1[8 + i]); }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q0, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p1, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q1, acc2, 0, 0, 0);
+        } else if constexpr (MODE == 8) {  // like 3 without exp: fma instead
+            f32x16 s = {0};
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
+            s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p0[i] = (__bf16)(s[i] * 0.5f + x[i]); p1[i] = (__bf16)(s[8 + i] * 0.5f + x[8 + i]); }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p0, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p1, acc, 0, 0, 0);
+        } else if constexpr (MODE == 4) {  // 8 cvt_pk
+            bf16x8 p0, p1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p0[i] = (__bf16)x[i]; p1[i] = (__bf16)x[8 + i]; }
+            asm volatile("" ::"v"(p0), "v"(p1));
+#pragma unroll
+            for (int i = 0; i < 16; ++i) x[i] += 1.0f;
+        }
+    }
+    float s = 0;
+    for (int i = 0; i < 16; ++i) s += x[i] + acc[i] + acc2[i];
+    out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+
+template <int MODE>
+void run(const char* name, int waves_per_simd, double ops_per_iter) {
+    float* out;
+    const int blocks = 256 * waves_per_simd;  // 256 CUs x (4 waves per block = 1 per SIMD) x waves_per_simd
+    hipMalloc(&out, blocks * 256 * 4);
+    const int iters = 20000;
+    k<MODE><<<blocks, 256>>>(out, 100);
+    hipDeviceSynchronize();
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    hipEventRecord(e0);
+    k<MODE><<<blocks, 256>>>(out, iters);
+    hipEventRecord(e1);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    // per SIMD: waves_per_simd waves x iters x ops wave-instructions
+    const double instr_per_simd = (double)waves_per_simd * iters * ops_per_iter;
+    printf("%-28s waves/SIMD=%d  %.3f ms  -> %.2f cycles per wave-instruction per SIMD (at 2.4 GHz)\n", name, waves_per_simd, ms,
+           ms * 1e-3 * 2.4e9 / instr_per_simd);
+    hipFree(out);
+}
+
+int main() {
+    for (int w : {1, 2, 4}) {
+        run<0>("v_exp_f32 (+v_sub)", w, 32);
+        run<1>("v_fma_f32", w, 16);
+        run<2>("mfma_32x32x16_bf16", w, 4);
+        run<4>("cvt_pk_bf16 (8)+16 add", w, 24);
+        run<3>("attn mix 4mfma+16exp+8cvt+16add", w, 1);
+        run<5>("indep 4mfma || 16exp+16sub", w, 1);
+        run<6>("indep 4mfma || 32fma", w, 1);
+        run<7>("attn 2 tiles: 8mfma+32exp+16cvt", w, 1);
+        run<8>("attn-like fma: 4mfma+16fma+8cvt", w, 1);
+    }
+    return 0;
+}
