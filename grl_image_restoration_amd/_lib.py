@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
 
@@ -67,6 +67,7 @@ class GrlLinearArgs(_Strict):
         ("out", C.c_void_p),
         ("out_is_bf16", C.c_int32),
         ("ldo", C.c_int64),
+        ("out_plane_stride", C.c_int64),
     ]
 
 
@@ -74,6 +75,7 @@ class GrlTokenGrid(_Strict):
     _fields_ = [
         ("ptr", C.c_void_p),
         ("ld", C.c_int64),
+        ("hstride", C.c_int64),
         ("col0", C.c_int32),
         ("Himg", C.c_int32),
         ("Wimg", C.c_int32),

@@ -38,6 +38,14 @@ struct GridGeo {
     int Himg, Wimg, wh, ww, shy, shx;
 };
 
+// Workgroup -> work item map that keeps consecutive work items (the query blocks of one window and
+// head, which share K/V) on ONE XCD: the dispatcher places block b on XCD b % 8 and every XCD has a
+// private L2 (MI355X guide, T1).  Bijective for any grid size; affects speed only.
+__device__ __forceinline__ int xcd_remap(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 __device__ __forceinline__ int region1d(int p, int n, int s, int sh) {
     // ops.py:76-100: labels 0 | 1 | 2 split at n-s and n-sh; a zero shift labels the whole axis alike
     if (sh == 0) return 0;
@@ -62,7 +70,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
     const int qblk = (nthreads >> 6) * (QT * 32);
     const int nqs = (Nq + qblk - 1) / qblk;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qs = bid % nqs; bid /= nqs;
     const int head = bid % p.nh; bid /= p.nh;
     const int wx = bid % p.nwx; bid /= p.nwx;
@@ -98,7 +106,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         locate(p.q, b, wy, wx, n, qrow[t], idq[t]);
         const int hq = n / p.q.ww, wq = n - hq * p.q.ww;
         U[t] = hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1);
-        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * 32 + 8 * half;
+        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
         qf[t][0] = *(const bf16x8*)(src);
         qf[t][1] = *(const bf16x8*)(src + 16);
 #pragma unroll
@@ -122,8 +130,8 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
             bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (valid) {
-                kv = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
-                vv = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
+                kv = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
+                vv = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
             }
             *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
 #pragma unroll
@@ -252,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         }
         const float inv = 1.0f / l;
         if (qvalid[t]) {
-            bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * 32 + 4 * half;
+            bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pk;
@@ -300,7 +308,7 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 
 // FROWS = key rows per LDS chunk (chunk = FROWS x 32 keys of one strip); WPS = waves per SIMD to allocate for
 template <int FW, int QTN, int FROWS, int WPS, bool PIPE>
-__global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) {
+__global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, int dbg) {
     constexpr int FKC = FROWS * 32;
     constexpr int FVROW = FKC * 2 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -310,7 +318,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) 
     const int units = (p.q.wh / QTN) * qseg;           // (row group, segment) units per window
     const int upw = min(FW, units);                    // units (= active waves) per workgroup
     const int nqs = (units + upw - 1) / upw;
-    int bid = blockIdx.x;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
     const int qs = bid % nqs; bid /= nqs;
     const int head = bid % p.nh; bid /= p.nh;
     const int wx = bid % p.nwx; bid /= p.nwx;
@@ -343,7 +351,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) 
         // table index of (query, key (hk, wk)) = U - hk*D - wk, reversed: (trows-1-U) + hk*D + wk;
         // lane's key rows are wk = 32*sk + i, i = (r&3) + 8*(r>>2) + 4*half
         Ub[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1)) + 4 * half;
-        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * 32 + 8 * half;
+        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
         qf[t][0] = *(const bf16x8*)(src);
         qf[t][1] = *(const bf16x8*)(src + 16);
 #pragma unroll
@@ -371,11 +379,12 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) 
             int oy = ry + p.k.shy; if (oy >= p.k.Himg) oy -= p.k.Himg;
             int ox = rx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
             const int64_t row = ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
-            pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * 32 + seg * 8);
-            pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * 32 + seg * 8);
+            pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
+            pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
             prid[j] = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
         }
         __syncthreads();   // everyone is done reading the previous chunk
+        if (!(dbg & 1) || ch == 0)
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int i = tid + j * FW * 64;
@@ -408,8 +417,13 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) 
 #pragma unroll
             for (int t = 0; t < QTN; ++t) {
                 const float* tp = tab + (Ub[t] + toff);
+                if (dbg & 2) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) S[t][r] = tp[(r & 3) + 8 * (r >> 2)];
+                    for (int r = 0; r < 16; ++r) S[t][r] = -1.0f;
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) S[t][r] = tp[(r & 3) + 8 * (r >> 2)];
+                }
             }
             if (border) {
 #pragma unroll
@@ -432,9 +446,13 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) 
                 }
                 bf16x8 pb[2];
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[t][r]);
-                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t], 0, 0, 0);
-                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t], 0, 0, 0);
+                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)((dbg & 4) ? S[t][r] : __builtin_amdgcn_exp2f(S[t][r]));
+                if (dbg & 8) {
+                    asm volatile("" ::"v"(pb[0]), "v"(pb[1]));
+                } else {
+                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t], 0, 0, 0);
+                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t], 0, 0, 0);
+                }
             }
         };
         if constexpr (PIPE) {
@@ -474,7 +492,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p) 
         const float other = xhalf(cand);
         const float l = (half == ((oc >> 2) & 1)) ? cand : other;
         const float inv = 1.0f / l;
-        bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * 32 + 4 * half;
+        bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 pk;
@@ -501,7 +519,8 @@ int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     auto kfn = attn_fast_kernel<FW, QTN, FROWS, WPS, PIPE>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p);
+    static const int dbg = getenv("GRL_ATTN_DEBUG") ? atoi(getenv("GRL_ATTN_DEBUG")) : 0;  // timing ablations only
+    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p, dbg);
     GRL_CHECK_LAUNCH();
     return 0;
 }
@@ -525,7 +544,7 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1)) return GRL_ERR_BAD_ARG;
     if (p.head_dim > 32 || p.ones_col >= 32) return GRL_ERR_BAD_ARG;
     if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 4) || (p.q.col0 % 8) || (p.k.col0 % 8) ||
-        (p.v.col0 % 8) || (p.o.col0 % 4))
+        (p.v.col0 % 8) || (p.o.col0 % 4) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 4))
         return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     // fast path: 32-aligned geometry with the fixed softmax bound and the ones column

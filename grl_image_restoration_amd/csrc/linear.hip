@@ -175,7 +175,9 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
                 uint2 pk;
                 pk.x = pack_bf16(acc[c][mt][nt][0], acc[c][mt][nt][1]);
                 pk.y = pack_bf16(acc[c][mt][nt][2], acc[c][mt][nt][3]);
-                *(uint2*)((bf16*)p.out + (int64_t)m * p.ldo + col) = pk;
+                const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
+                                                           : (int64_t)m * p.ldo + col;
+                *(uint2*)((bf16*)p.out + off) = pk;
             } else {
                 *(float4*)((float*)p.out + (int64_t)m * p.ldo + col) =
                     float4{acc[c][mt][nt][0], acc[c][mt][nt][1], acc[c][mt][nt][2], acc[c][mt][nt][3]};

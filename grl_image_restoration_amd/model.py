@@ -506,32 +506,34 @@ class GRL(nn.Module):
         d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
         Ha, Wa = H // df, W // df
         dev = r.device
-        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"])
-        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W))
+        # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
+        # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
+        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
         att = torch.empty(M, (nh_w + nh_s) * 32, dtype=torch.bfloat16, device=dev)
-        y = torch.empty(B * Ha * Wa, nh_s * 32, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=torch.bfloat16, device=dev)
         ws, sh = geo.window, geo.window_shift
         TG = ops.TokenGrid
         # window attention (mixed_attn_block_efficient.py:128-165)
         ops.attention(
-            TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w * 32, H, W, ws[0], ws[1], sh, sh),
-            TG(qkv, 2 * nh_w * 32, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
+            TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w, H, W, ws[0], ws[1], sh, sh),
+            TG(qkv, 2 * nh_w, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
             B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0, fixed_max=pk["fixed"],
             ones_col=d_w if d_w < 32 else -1, head_dim=d_w,
         )
         # anchored stripe attention (mixed_attn_block_efficient.py:215-270)
-        s0 = 3 * nh_w * 32
+        s0 = 3 * nh_w
         st, ss = geo.stripe, geo.stripe_shift_size
         ast, ass = geo.anchor_stripe, geo.anchor_shift_size
         g_q = TG(qkv, s0, H, W, st[0], st[1], ss[0], ss[1])
-        g_k = TG(qkv, s0 + nh_s * 32, H, W, st[0], st[1], ss[0], ss[1])
-        g_v = TG(qkv, s0 + 2 * nh_s * 32, H, W, st[0], st[1], ss[0], ss[1])
+        g_k = TG(qkv, s0 + nh_s, H, W, st[0], st[1], ss[0], ss[1])
+        g_v = TG(qkv, s0 + 2 * nh_s, H, W, st[0], st[1], ss[0], ss[1])
         g_a = TG(anc, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         oc = d_s if d_s < 32 else -1
         ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
                       fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
-        ops.attention(g_q, g_a, g_y, TG(att, nh_w * 32, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
+        ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
                       table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         # x = x + res_scale * norm1(proj(attn)) + cab(x)   (efficient.py:543-548)

@@ -82,6 +82,7 @@ def linear(
     rows_per_image: int = 0,
     pool: Optional[Tuple[int, int, int]] = None,
     M: Optional[int] = None,
+    planes: bool = False,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
@@ -100,9 +101,17 @@ def linear(
         df, H, W = 1, 0, 0
         rows = a.shape[0]
     M = rows if M is None else M
-    if out is None:
-        out = torch.empty(M, Npad, dtype=out_dtype, device=a.device)
-    assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= Npad
+    if planes:
+        # head-plane layout [Npad/32, M, 32] (bf16): what the attention kernel stages fastest
+        if out is None:
+            out = torch.empty(Npad // 32, M, 32, dtype=torch.bfloat16, device=a.device)
+        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (Npad // 32, M, 32)
+        ldo, plane_stride = 32, M * 32
+    else:
+        if out is None:
+            out = torch.empty(M, Npad, dtype=out_dtype, device=a.device)
+        assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= Npad
+        ldo, plane_stride = out.stride(0), 0
     args = L.GrlLinearArgs(
         a=_ptr(a), a_is_bf16=int(a.dtype == torch.bfloat16), lda=a.stride(0),
         pool_df=df, pool_H=H, pool_W=W,
@@ -112,7 +121,7 @@ def linear(
         add2=_ptr(add2), add2_is_bf16=int(add2 is not None and add2.dtype == torch.bfloat16),
         ldadd2=add2.stride(0) if add2 is not None else 0,
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image,
-        out=_ptr(out), out_is_bf16=int(out.dtype == torch.bfloat16), ldo=out.stride(0),
+        out=_ptr(out), out_is_bf16=int(out.dtype == torch.bfloat16), ldo=ldo, out_plane_stride=plane_stride,
     )
     if epi == L.EPI_GROUPNORM:
         assert gscale is not None and gscale.dtype == torch.float32 and gscale.numel() == Npad // 32
@@ -126,10 +135,13 @@ def linear(
 
 @dataclass
 class TokenGrid:
-    """A bf16 token matrix viewed as windows: mirrors GrlTokenGrid."""
+    """A bf16 token tensor viewed as windows: mirrors GrlTokenGrid.
 
-    t: torch.Tensor          # [B*Himg*Wimg, ld] bf16
-    col0: int                # column of head 0's 32-wide slot
+    ``t`` is either a token-major matrix [tokens, heads*32 (+...)] (``slot`` = first 32-wide column
+    group of head 0) or a stack of head planes [slots, tokens, 32] (``slot`` = plane of head 0)."""
+
+    t: torch.Tensor
+    slot: int
     Himg: int
     Wimg: int
     wh: int
@@ -138,9 +150,19 @@ class TokenGrid:
     shx: int = 0
 
     def c(self) -> L.GrlTokenGrid:
-        assert self.t.dtype == torch.bfloat16 and self.t.dim() == 2 and self.t.stride(1) == 1
-        return L.GrlTokenGrid(ptr=_ptr(self.t), ld=self.t.stride(0), col0=self.col0, Himg=self.Himg, Wimg=self.Wimg,
+        t = self.t
+        assert t.dtype == torch.bfloat16 and t.stride(-1) == 1
+        if t.dim() == 3:  # head planes
+            assert t.shape[2] == 32 and t.is_contiguous()
+            return L.GrlTokenGrid(ptr=C.c_void_p(t.data_ptr() + self.slot * t.stride(0) * 2), ld=32, hstride=t.stride(0),
+                                  col0=0, Himg=self.Himg, Wimg=self.Wimg, wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx)
+        assert t.dim() == 2
+        return L.GrlTokenGrid(ptr=_ptr(t), ld=t.stride(0), hstride=32, col0=self.slot * 32, Himg=self.Himg, Wimg=self.Wimg,
                               wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx)
+
+    @property
+    def tokens(self) -> int:
+        return self.t.shape[-2] if self.t.dim() == 3 else self.t.shape[0]
 
 
 def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int, nh: int, table: torch.Tensor,
@@ -149,7 +171,7 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
     _dev_check(q.t, k.t, v.t, o.t, table)
     assert table.dtype == torch.float32 and table.is_contiguous() and table.dim() == 2 and table.shape[0] == nh
     nwy, nwx = q.Himg // q.wh, q.Wimg // q.ww
-    assert q.t.shape[0] >= B * q.Himg * q.Wimg and k.t.shape[0] >= B * k.Himg * k.Wimg
+    assert q.tokens >= B * q.Himg * q.Wimg and k.tokens >= B * k.Himg * k.Wimg
     args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
                          trows=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
                          head_dim=head_dim)

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 2
+#define GRL_ABI_VERSION 3
 
 /* ---------------------------------------------------------------------------------------------
  * Token-wise linear layer with fused epilogue.
@@ -61,6 +61,8 @@ typedef struct GrlLinearArgs {
     void* out;              /* [M, ldo] bf16 or fp32                                                */
     int32_t out_is_bf16;
     int64_t ldo;
+    int64_t out_plane_stride; /* >0: write 32-column groups as planes: element (m, c) goes to          */
+                              /* out[(c/32)*out_plane_stride + m*32 + c%32]  (ldo ignored)             */
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
@@ -80,8 +82,12 @@ int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlTokenGrid {
     const void* ptr;      /* bf16 base                                                              */
-    int64_t ld;           /* elements per token row                                                 */
-    int32_t col0;         /* element offset of head 0's slot inside a token row                     */
+    int64_t ld;           /* elements between consecutive tokens                                    */
+    int64_t hstride;      /* elements between the 32-wide slots of consecutive heads: 32 for a      */
+                          /* token-major matrix [tokens, heads*32]; tokens*32 for head planes       */
+                          /* [heads][tokens][32] (the layout the QKV projection writes: a key tile  */
+                          /* of 32 consecutive tokens is then 2 KB contiguous)                      */
+    int32_t col0;         /* element offset of head 0's slot                                        */
     int32_t Himg, Wimg;   /* token image size                                                       */
     int32_t wh, ww;       /* window (stripe) size on this grid                                      */
     int32_t shy, shx;     /* cyclic shift (rolled[y] = orig[(y+sh) % H]); 0 = none                  */

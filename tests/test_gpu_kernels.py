@@ -151,9 +151,10 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("planes", [False, True])
 @pytest.mark.parametrize("fixed", [True, False])
 @pytest.mark.parametrize("case", CASES, ids=[c[0] for c in CASES])
-def test_attention_vs_oracle_indexing(case, fixed):
+def test_attention_vs_oracle_indexing(case, fixed, planes):
     from grl_image_restoration_amd import ops, tables
 
     name, mode, (H, W), win, shift, df, nh, d = case
@@ -208,8 +209,12 @@ def test_attention_vs_oracle_indexing(case, fixed):
 
     dev = _dev()
     TG = ops.TokenGrid
-    qd, kd, vd = qs.to(dev), ks.to(dev), vs.to(dev)
-    out = torch.zeros(B * qg[0] * qg[1], nh * 32, dtype=torch.bfloat16, device=dev)
+
+    def lay(t):  # token-major [tokens, nh*32] or head planes [nh, tokens, 32]
+        return t.view(t.shape[0], nh, 32).permute(1, 0, 2).contiguous().to(dev) if planes else t.to(dev)
+
+    qd, kd, vd = lay(qs), lay(ks), lay(vs)
+    out = lay(torch.zeros(B * qg[0] * qg[1], nh * 32, dtype=torch.bfloat16))
     ops.attention(
         TG(qd, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
         TG(kd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
@@ -218,7 +223,7 @@ def test_attention_vs_oracle_indexing(case, fixed):
         B=B, nh=nh, table=tab.to(dev), masked=masked, fixed_max=fixed, ones_col=d if ones else -1, head_dim=d,
     )
     torch.cuda.synchronize()
-    got = out.float().cpu().view(-1, nh, 32)[..., :d]
+    got = (out.permute(1, 0, 2) if planes else out.view(-1, nh, 32)).float().cpu()[..., :d]
     err = (got.double() - ref).abs().max().item()
     print(f"{name} fixed={fixed}: max|err| = {err:.3e} (ref max {ref.abs().max().item():.2f})")
     assert err < 6e-3 * max(1.0, ref.abs().max().item()), err  # bf16 output: half-ulp 2^-9 relative + bf16 P

@@ -37,17 +37,17 @@ def main():
     nh, df = 3, geo.df
     Ha, Wa = H // df, W // df
     TG = ops.TokenGrid
-    qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"])
-    anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W))
+    qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+    anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
     att = torch.zeros(M, 2 * nh * 32, dtype=torch.bfloat16, device="cuda")
-    y = torch.zeros(B * Ha * Wa, nh * 32, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(nh, B * Ha * Wa, 32, dtype=torch.bfloat16, device="cuda")
     ws, sh = geo.window, geo.window_shift
     stp, ss = geo.stripe, geo.stripe_shift_size
     ast, ass = geo.anchor_stripe, geo.anchor_shift_size
-    s0 = 3 * nh * 32
+    s0 = 3 * nh
     g_q = TG(qkv, s0, H, W, stp[0], stp[1], ss[0], ss[1])
-    g_k = TG(qkv, s0 + nh * 32, H, W, stp[0], stp[1], ss[0], ss[1])
-    g_v = TG(qkv, s0 + 2 * nh * 32, H, W, stp[0], stp[1], ss[0], ss[1])
+    g_k = TG(qkv, s0 + nh, H, W, stp[0], stp[1], ss[0], ss[1])
+    g_v = TG(qkv, s0 + 2 * nh, H, W, stp[0], stp[1], ss[0], ss[1])
     g_a = TG(anc, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
     g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
     mid = torch.zeros(M, pk["cab_mid"], dtype=torch.bfloat16, device="cuda")
@@ -60,17 +60,17 @@ def main():
     fl_s = 2 * L_ * N2 * C * B
 
     kernels = {
-        "qkv": (lambda: ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv),
+        "qkv": (lambda: ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv, planes=True),
                 6 * L_ * C * C * B, M * (CP * 4 + 576 * 2)),
-        "anchor": (lambda: ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), out=anc),
+        "anchor": (lambda: ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), out=anc, planes=True),
                    L_ * C * C * B // (df * df), M * CP * 4),
-        "attn_window": (lambda: ops.attention(TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh * 32, H, W, ws[0], ws[1], sh, sh),
-                                              TG(qkv, 2 * nh * 32, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
+        "attn_window": (lambda: ops.attention(TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh, H, W, ws[0], ws[1], sh, sh),
+                                              TG(qkv, 2 * nh, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
                                               B=B, nh=nh, table=pk["tab_w"], masked=sh > 0, fixed_max=pk["fixed"], ones_col=30, head_dim=30),
                         fl_att, M * 4 * 96 * 2),
         "attn_a2w": (lambda: ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh, table=pk["tab_a2w"], masked=geo.stripe_shift,
                                            fixed_max=pk["fixed"], ones_col=30, head_dim=30), fl_s, M * 2 * 96 * 2),
-        "attn_w2a": (lambda: ops.attention(g_q, g_a, g_y, TG(att, nh * 32, H, W, stp[0], stp[1], ss[0], ss[1]), B=B, nh=nh,
+        "attn_w2a": (lambda: ops.attention(g_q, g_a, g_y, TG(att, nh, H, W, stp[0], stp[1], ss[0], ss[1]), B=B, nh=nh,
                                            table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=30,
                                            head_dim=30), fl_s, M * 2 * 96 * 2),
         "cab_conv1": (lambda: ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid), 2 * 9 * L_ * C * 45 * B, M * (CP * 4 + 96)),
