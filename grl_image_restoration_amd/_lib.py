@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
 
@@ -98,6 +98,7 @@ class GrlAttnArgs(_Strict):
         ("nwx", C.c_int32),
         ("table", C.c_void_p),
         ("trows", C.c_int32),
+        ("tstride", C.c_int32),
         ("masked", C.c_int32),
         ("fixed_max", C.c_int32),
         ("ones_col", C.c_int32),

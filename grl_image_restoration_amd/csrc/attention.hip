@@ -46,6 +46,23 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
+// global -> LDS copy of one head's bias table with 4 x 16 B loads in flight per thread (a plain
+// element loop serialises on global-memory latency: 35 round trips for a 95 x 95 table)
+__device__ __forceinline__ void load_table(float* tab, const float* src, int trows, int tid, int nthreads) {
+    const int n4 = (trows + 3) >> 2;  // the per-head stride is padded to a multiple of 4 floats
+    const float4* s4 = (const float4*)src;
+    float4* d4 = (float4*)tab;
+    for (int i0 = tid; i0 < n4; i0 += 4 * nthreads) {
+        float4 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * nthreads < n4) v[j] = s4[i0 + j * nthreads];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * nthreads < n4) d4[i0 + j * nthreads] = v[j];
+    }
+}
+
 __device__ __forceinline__ int region1d(int p, int n, int s, int sh) {
     // ops.py:76-100: labels 0 | 1 | 2 split at n-s and n-sh; a zero shift labels the whole axis alike
     if (sh == 0) return 0;
@@ -85,7 +102,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     int* koff = (int*)(Vt + 32 * VROW);                          // KC
     unsigned char* kreg = (unsigned char*)(koff + KC);           // KC
 
-    for (int i = tid; i < p.trows; i += nthreads) tab[i] = p.table[(int64_t)head * p.trows + i];
+    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
 
     // does this window need the mask path at all?  (window touches the wrapped border, or ragged keys)
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
@@ -105,7 +122,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         if (!qvalid[t]) n = Nq - 1;
         locate(p.q, b, wy, wx, n, qrow[t], idq[t]);
         const int hq = n / p.q.ww, wq = n - hq * p.q.ww;
-        U[t] = hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1);
+        U[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1));  // reversed table: index = U + v
         const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
         qf[t][0] = *(const bf16x8*)(src);
         qf[t][1] = *(const bf16x8*)(src + 16);
@@ -163,9 +180,9 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                     const int v0 = koff[kb + 8 * g + 4 * half];
 #pragma unroll
                     for (int t = 0; t < QT; ++t) {
-                        const float* tp = tab + (U[t] - v0);
+                        const float* tp = tab + (U[t] + v0);
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) S[t][4 * g + e] = *(tp - e);
+                        for (int e = 0; e < 4; ++e) S[t][4 * g + e] = tp[e];
                     }
                 }
             } else {
@@ -173,7 +190,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                 for (int r = 0; r < 16; ++r) {
                     const int v = koff[kb + mfma32_row(r, half)];
 #pragma unroll
-                    for (int t = 0; t < QT; ++t) S[t][r] = tab[U[t] - v];
+                    for (int t = 0; t < QT; ++t) S[t][r] = tab[U[t] + v];
                 }
             }
 #pragma unroll
@@ -331,8 +348,8 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     char* Vt = Ks + FKC * 64;
     unsigned char* kreg = (unsigned char*)(Vt + 32 * FVROW);
 
-    // the table is stored REVERSED so that a lane's 16 key rows read ascending addresses
-    for (int i = tid; i < p.trows; i += FW * 64) tab[p.trows - 1 - i] = p.table[(int64_t)head * p.trows + i];
+    // the table arrives REVERSED (see grl_hip.h) so that a lane's 16 key rows read ascending addresses
+    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, FW * 64);
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
 
     // ---- this wave's unit: query rows QTN*pr .. QTN*pr+QTN-1, segment sg ----
@@ -541,7 +558,7 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (Nq <= 0 || Nk <= 0 || p.B <= 0 || p.nh <= 0) return GRL_ERR_BAD_ARG;
     if (p.q.Himg != p.nwy * p.q.wh || p.q.Wimg != p.nwx * p.q.ww) return GRL_ERR_BAD_ARG;
     if (p.k.Himg != p.nwy * p.k.wh || p.k.Wimg != p.nwx * p.k.ww) return GRL_ERR_BAD_ARG;
-    if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1)) return GRL_ERR_BAD_ARG;
+    if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1) || p.tstride < p.trows || (p.tstride & 3)) return GRL_ERR_BAD_ARG;
     if (p.head_dim > 32 || p.ones_col >= 32) return GRL_ERR_BAD_ARG;
     if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 4) || (p.q.col0 % 8) || (p.k.col0 % 8) ||
         (p.v.col0 % 8) || (p.o.col0 % 4) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 4))

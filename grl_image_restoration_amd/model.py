@@ -406,8 +406,8 @@ class GRL(nn.Module):
         pk["tab_w"] = table(a.window_attn.attn_transform, geo.window, 1, sc_w)
         pk["tab_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df, sc_1)
         pk["tab_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df, sc_2)
-        assert pk["tab_w"].shape[1] == table_rows(geo.window, geo.window)
-        assert pk["tab_a2w"].shape[1] == table_rows(geo.anchor_stripe, geo.stripe)
+        assert pk["tab_w"].shape[1] == (table_rows(geo.window, geo.window) + 3) // 4 * 4
+        assert pk["tab_a2w"].shape[1] == (table_rows(geo.anchor_stripe, geo.stripe) + 3) // 4 * 4
 
         # --- CAB: conv3x3 C->C/4 (GELU), conv3x3 C/4->C, squeeze-excite gate (mixed_attn_block.py:948-983) ---
         if self.local_connection:

@@ -167,13 +167,14 @@ class TokenGrid:
 
 def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int, nh: int, table: torch.Tensor,
               masked: bool, fixed_max: bool, ones_col: int, head_dim: int):
-    """softmax(q k^T + bias(+mask)) v over every window of every image; see grl_attention_fwd."""
+    """softmax(q k^T + bias(+mask)) v over every window of every image; see grl_attention_fwd.
+    ``table``: (nh, rows padded to 4) from tables.kernel_table (reversed rows)."""
     _dev_check(q.t, k.t, v.t, o.t, table)
     assert table.dtype == torch.float32 and table.is_contiguous() and table.dim() == 2 and table.shape[0] == nh
     nwy, nwx = q.Himg // q.wh, q.Wimg // q.ww
     assert q.tokens >= B * q.Himg * q.Wimg and k.tokens >= B * k.Himg * k.Wimg
     args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
-                         trows=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
+                         trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
                          head_dim=head_dim)
     with _timed("attention"):
         L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")

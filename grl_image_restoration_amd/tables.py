@@ -44,13 +44,18 @@ def bias_rows(cpb0_w, cpb0_b, cpb2_w, coords: torch.Tensor) -> torch.Tensor:
 
 
 def kernel_table(bias: torch.Tensor, scale: torch.Tensor, fixed_max: bool) -> torch.Tensor:
-    """(rows, nh) natural-log-domain bias -> (nh, rows) table in the kernel's exp2 domain.
+    """(rows, nh) natural-log-domain bias -> (nh, rows4) table in the kernel's exp2 domain, stored
+    REVERSED along rows (entry rows-1-i = row i) and zero-padded to a multiple of 4 floats per head.
     With ``fixed_max`` the per-head bound scale_h + max(bias_h) >= every logit is subtracted, so
     exp2(acc) <= 1 without tracking a running maximum."""
     t = bias.t().contiguous() * LOG2E
     if fixed_max:
         bound = (scale + bias.max(dim=0).values) * LOG2E
         t = t - bound[:, None]
+    t = torch.flip(t, dims=(1,))
+    pad = (-t.shape[1]) % 4
+    if pad:
+        t = torch.nn.functional.pad(t, (0, pad))
     return t.contiguous()
 
 

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 3
+#define GRL_ABI_VERSION 4
 
 /* ---------------------------------------------------------------------------------------------
  * Token-wise linear layer with fused epilogue.
@@ -97,8 +97,11 @@ typedef struct GrlAttnArgs {
     GrlTokenGrid q, k, v, o; /* v shares k's grid geometry; o shares q's                            */
     int32_t B, nh;
     int32_t nwy, nwx;        /* windows per image (same on both grids)                              */
-    const float* table;      /* [nh, trows] fp32: bias*log2e (minus the per-head bound if fixed_max)*/
+    const float* table;      /* [nh, tstride] fp32: bias*log2e (minus the per-head bound if fixed_max),*/
+                             /* stored REVERSED: entry trows-1-i is row i of the reference's         */
+                             /* relative-position table (keys then read ascending addresses)         */
     int32_t trows;           /* (q.wh + k.wh - 1) * (q.ww + k.ww - 1)                               */
+    int32_t tstride;         /* floats between heads: trows rounded up to a multiple of 4           */
     int32_t masked;          /* 1: apply the shifted-window region mask (-100)                      */
     int32_t fixed_max;       /* 1: table carries -(bound); no running max needed                    */
     int32_t ones_col;        /* see above                                                           */

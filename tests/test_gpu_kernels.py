@@ -180,7 +180,8 @@ def test_attention_vs_oracle_indexing(case, fixed, planes):
     qs, ks, vs = _slots(qf, d), _slots(kf, d), _slots(vf, d, ones)
     rows = (qg[2][0] + kg[2][0] - 1) * (qg[2][1] + kg[2][1] - 1)
     bias = torch.rand(rows, nh, generator=g) * 16
-    tab = tables.kernel_table(bias, scale, fixed)
+    tab_k = tables.kernel_table(bias, scale, fixed)              # what the kernel receives (reversed, padded)
+    tab = torch.flip(tab_k[:, : tab_k.shape[1] - (-rows) % 4], dims=(1,))  # forward order for the reference
     masked = shift[0] > 0 or shift[1] > 0
     if mode == "w":
         index = O.rel_index(win)
@@ -220,7 +221,7 @@ def test_attention_vs_oracle_indexing(case, fixed, planes):
         TG(kd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
         TG(vd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
         TG(out, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
-        B=B, nh=nh, table=tab.to(dev), masked=masked, fixed_max=fixed, ones_col=d if ones else -1, head_dim=d,
+        B=B, nh=nh, table=tab_k.to(dev), masked=masked, fixed_max=fixed, ones_col=d if ones else -1, head_dim=d,
     )
     torch.cuda.synchronize()
     got = (out.permute(1, 0, 2) if planes else out.view(-1, nh, 32)).float().cpu()[..., :d]

@@ -106,7 +106,7 @@ def test_library_exports_every_declared_symbol():
     assert lib.grl_abi_version() == _lib.ABI_VERSION
     assert b"gfx950" in lib.grl_build_info()
     # ctypes struct layouts must match the C structs (sizes for the LP64 ABI)
-    assert ctypes.sizeof(_lib.GrlTokenGrid) == 48 and ctypes.sizeof(_lib.GrlAttnArgs) == 4 * 48 + 16 + 8 + 24
+    assert ctypes.sizeof(_lib.GrlTokenGrid) == 56 and ctypes.sizeof(_lib.GrlAttnArgs) == 4 * 56 + 16 + 8 + 24
 
 
 def test_fixed_max_policy_and_table():
@@ -115,7 +115,9 @@ def test_fixed_max_policy_and_table():
     assert not tables.fixed_max_is_safe(torch.tensor([10.0, 100.0]))
     bias = torch.rand(50, 2) * 16
     t = tables.kernel_table(bias, scale, True)
-    assert t.shape == (2, 50) and t.max().item() <= -scale.min().item() * tables.LOG2E + 1e-4
+    assert t.shape == (2, 52) and t.max().item() <= 1e-4 and torch.equal(t[:, 50:], torch.zeros(2, 2))
+    t0 = tables.kernel_table(bias, scale, False)
+    assert torch.allclose(torch.flip(t0[:, :50], dims=(1,)), bias.t() * tables.LOG2E)
 
 
 def test_ctypes_structs_refuse_unknown_fields():
