@@ -325,7 +325,9 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 
 // FROWS = key rows per LDS chunk (chunk = FROWS x 32 keys of one strip); WPS = waves per SIMD to allocate for
 template <int FW, int QTN, int FROWS, int WPS, bool PIPE>
-__global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, int dbg) {
+__global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, int dbg, long long* tbuf) {
+    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (tbuf) tm[0] = __builtin_amdgcn_s_memtime();
     constexpr int FKC = FROWS * 32;
     constexpr int FVROW = FKC * 2 + 8;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -380,14 +382,19 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     const int nch = kseg * nrc;
 
     // ---- K / V staging: each thread owns SPT fixed (key, 16-B segment) slots of a chunk ----
+    if (tbuf) tm[1] = __builtin_amdgcn_s_memtime();
     constexpr int SPT = (FKC * 4) / (FW * 64);
     static_assert(SPT * FW * 64 == FKC * 4, "chunk must divide evenly over the workgroup");
 
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
+        if ((dbg & 16) && ch > 0) break;
+        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+        if (tbuf) c0 = __builtin_amdgcn_s_memtime();
         bf16x8 pk_[SPT], pv_[SPT];
         int prid[SPT];
+        if (!(dbg & 32) || ch == 0)
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
             const int i = tid + j * FW * 64;
@@ -401,6 +408,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
             prid[j] = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
         }
         __syncthreads();   // everyone is done reading the previous chunk
+        if (tbuf) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = __builtin_amdgcn_s_memtime(); }
         if (!(dbg & 1) || ch == 0)
 #pragma unroll
         for (int j = 0; j < SPT; ++j) {
@@ -412,6 +420,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
             if (seg == 0) kreg[kk] = (unsigned char)prid[j];
         }
         __syncthreads();
+        if (tbuf) c2 = __builtin_amdgcn_s_memtime();
         if (!active) continue;
 
         // LDS reads of one key tile: K fragments, V^T fragments, bias fragments (accumulator init), key region ids
@@ -495,7 +504,9 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 compute_tile(kf, vf, S, ids);
             }
         }
+        if (tbuf) { c3 = __builtin_amdgcn_s_memtime(); tm[2] += c1 - c0; tm[3] += c2 - c1; tm[4] += c3 - c2; }
     }
+    if (tbuf) tm[5] = __builtin_amdgcn_s_memtime();
     if (!active) return;
 
 #pragma unroll
@@ -518,12 +529,20 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
             *(uint2*)(dst + 8 * g) = pk;
         }
     }
+    if (tbuf && tid == 0) {
+        const long long t_end = __builtin_amdgcn_s_memtime();
+        long long* o = tbuf + (long long)blockIdx.x * 8;
+        o[0] = tm[0]; o[1] = tm[1] - tm[0]; o[2] = tm[2]; o[3] = tm[3]; o[4] = tm[4]; o[5] = t_end - tm[5]; o[6] = t_end - tm[0];
+        o[7] = __builtin_amdgcn_s_getreg(((1 - 1) << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+    }
 }
 
 size_t fast_lds_bytes(const GrlAttnArgs& p, int frows) {
     const size_t kc = (size_t)frows * 32;
     return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + kc * 64 + 32 * (kc * 2 + 8) + kc;
 }
+
+long long* g_tbuf = nullptr;  // optional per-workgroup phase timestamps (tools/attn_phases.py)
 
 template <int FW, int QTN, int FROWS, int WPS, bool PIPE>
 int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
@@ -537,7 +556,7 @@ int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     static const int dbg = getenv("GRL_ATTN_DEBUG") ? atoi(getenv("GRL_ATTN_DEBUG")) : 0;  // timing ablations only
-    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p, dbg);
+    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p, dbg, g_tbuf);
     GRL_CHECK_LAUNCH();
     return 0;
 }
@@ -551,6 +570,8 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
 }
 
 }  // namespace
+
+extern "C" void grl_debug_attention_timestamps(long long* buf) { g_tbuf = buf; }
 
 extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     const GrlAttnArgs& p = *args;

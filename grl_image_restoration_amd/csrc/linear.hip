@@ -206,15 +206,24 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
             const int n0 = (gch * NCH + c) * NT * 16;
-            // ---- stage the weight chunk [NT*16][KPAD] into LDS (16 B per thread-iteration) ----
-            __syncthreads();
+            // ---- stage the weight chunk [NT*16][KPAD] into LDS: all global loads of a thread are issued
+            // before the first LDS store (a load->store loop would serialise on L2 latency) ----
             {
                 constexpr int SEGS_PER_ROW = KPAD / 8;
                 constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
+                constexpr int PER_T = (SEGS + WAVES * 64 - 1) / (WAVES * 64);
                 const bf16* wsrc = (const bf16*)p.w + (int64_t)n0 * KPAD;
-                for (int i = tid; i < SEGS; i += WAVES * 64) {
-                    const int rr = i / SEGS_PER_ROW, cc = i % SEGS_PER_ROW;
-                    *(bf16x8*)(smem + rr * ROWB + cc * 16) = *(const bf16x8*)(wsrc + (int64_t)rr * KPAD + cc * 8);
+                bf16x8 wv[PER_T];
+#pragma unroll
+                for (int j = 0; j < PER_T; ++j) {
+                    const int i = tid + j * WAVES * 64;
+                    if (i < SEGS) wv[j] = *(const bf16x8*)(wsrc + (int64_t)(i / SEGS_PER_ROW) * KPAD + (i % SEGS_PER_ROW) * 8);
+                }
+                __syncthreads();  // previous chunk's fragment reads are done
+#pragma unroll
+                for (int j = 0; j < PER_T; ++j) {
+                    const int i = tid + j * WAVES * 64;
+                    if (i < SEGS) *(bf16x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
                 }
             }
             __syncthreads();
