@@ -76,47 +76,25 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
     for (int kc = 0; kc < nkc; ++kc) {
         load_w(0, kc);
         __syncthreads();  // previous chunk's readers are done with in_s / wt_s
-        // ---- stage the halo tile of this channel chunk as bf16: loads of all of a thread's slots are in
-        // flight together (fp32 sources: 2 x 16 B per slot), then converted and written ----
-        {
-            constexpr int SLOTS = HALO_H * HALO_W * SEG_ROW;
-            constexpr int PER_T = (SLOTS + CWAVES * 64 - 1) / (CWAVES * 64);
-            float4 f0[PER_T], f1[PER_T];
-            bf16x8 hv[PER_T];
-#pragma unroll
-            for (int j = 0; j < PER_T; ++j) {
-                const int s_ = tid + j * CWAVES * 64;
-                f0[j] = float4{0, 0, 0, 0};
-                f1[j] = f0[j];
-                hv[j] = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
-                if (s_ < SLOTS) {
-                    const int pix = s_ / SEG_ROW, cc = s_ % SEG_ROW;
-                    const int hy = pix / HALO_W, hx = pix % HALO_W;
-                    const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-                    if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                        const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
-                        if (p.x_is_bf16) {
-                            hv[j] = *(const bf16x8*)((const bf16*)p.x + row * p.ldx + kc * KC + cc * 8);
-                        } else {
-                            const float4* q = (const float4*)((const float*)p.x + row * p.ldx + kc * KC + cc * 8);
-                            f0[j] = q[0];
-                            f1[j] = q[1];
-                        }
-                    }
+        // ---- stage the halo tile of this channel chunk as bf16 ----
+#pragma unroll 2
+        for (int s = tid; s < HALO_H * HALO_W * SEG_ROW; s += CWAVES * 64) {
+            const int pix = s / SEG_ROW, cc = s % SEG_ROW;
+            const int hy = pix / HALO_W, hx = pix % HALO_W;
+            const int gy = y0 + hy - 1, gx = x0 + hx - 1;
+            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
+                if (p.x_is_bf16) {
+                    v = *(const bf16x8*)((const bf16*)p.x + row * p.ldx + kc * KC + cc * 8);
+                } else {
+                    const float4* q = (const float4*)((const float*)p.x + row * p.ldx + kc * KC + cc * 8);
+                    const float4 a0 = q[0], a1 = q[1];
+                    v[0] = (bf16)a0.x; v[1] = (bf16)a0.y; v[2] = (bf16)a0.z; v[3] = (bf16)a0.w;
+                    v[4] = (bf16)a1.x; v[5] = (bf16)a1.y; v[6] = (bf16)a1.z; v[7] = (bf16)a1.w;
                 }
             }
-#pragma unroll
-            for (int j = 0; j < PER_T; ++j) {
-                const int s_ = tid + j * CWAVES * 64;
-                if (s_ < SLOTS) {
-                    bf16x8 v = hv[j];
-                    if (!p.x_is_bf16) {
-                        v[0] = (bf16)f0[j].x; v[1] = (bf16)f0[j].y; v[2] = (bf16)f0[j].z; v[3] = (bf16)f0[j].w;
-                        v[4] = (bf16)f1[j].x; v[5] = (bf16)f1[j].y; v[6] = (bf16)f1[j].z; v[7] = (bf16)f1[j].w;
-                    }
-                    *(bf16x8*)(in_s + (s_ / SEG_ROW) * ROWB + (s_ % SEG_ROW) * 16) = v;
-                }
-            }
+            *(bf16x8*)(in_s + pix * ROWB + cc * 16) = v;
         }
         store_w(0);
         __syncthreads();

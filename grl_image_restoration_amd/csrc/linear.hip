@@ -211,19 +211,21 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
             {
                 constexpr int SEGS_PER_ROW = KPAD / 8;
                 constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
-                constexpr int PER_T = (SEGS + WAVES * 64 - 1) / (WAVES * 64);
+                constexpr int GRP = 4;  // loads in flight per thread
                 const bf16* wsrc = (const bf16*)p.w + (int64_t)n0 * KPAD;
-                bf16x8 wv[PER_T];
-#pragma unroll
-                for (int j = 0; j < PER_T; ++j) {
-                    const int i = tid + j * WAVES * 64;
-                    if (i < SEGS) wv[j] = *(const bf16x8*)(wsrc + (int64_t)(i / SEGS_PER_ROW) * KPAD + (i % SEGS_PER_ROW) * 8);
-                }
                 __syncthreads();  // previous chunk's fragment reads are done
+                for (int i0 = tid; i0 < SEGS; i0 += GRP * WAVES * 64) {
+                    bf16x8 wv[GRP];
 #pragma unroll
-                for (int j = 0; j < PER_T; ++j) {
-                    const int i = tid + j * WAVES * 64;
-                    if (i < SEGS) *(bf16x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
+                    for (int j = 0; j < GRP; ++j) {
+                        const int i = i0 + j * WAVES * 64;
+                        if (i < SEGS) wv[j] = *(const bf16x8*)(wsrc + (int64_t)(i / SEGS_PER_ROW) * KPAD + (i % SEGS_PER_ROW) * 8);
+                    }
+#pragma unroll
+                    for (int j = 0; j < GRP; ++j) {
+                        const int i = i0 + j * WAVES * 64;
+                        if (i < SEGS) *(bf16x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
+                    }
                 }
             }
             __syncthreads();
