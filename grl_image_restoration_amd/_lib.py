@@ -9,7 +9,8 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
+DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
 
@@ -40,7 +41,7 @@ class _Strict(C.Structure):
 class GrlLinearArgs(_Strict):
     _fields_ = [
         ("a", C.c_void_p),
-        ("a_is_bf16", C.c_int32),
+        ("a_dtype", C.c_int32),
         ("lda", C.c_int64),
         ("pool_df", C.c_int32),
         ("pool_H", C.c_int32),
@@ -60,12 +61,12 @@ class GrlLinearArgs(_Strict):
         ("resid", C.c_void_p),
         ("ldr", C.c_int64),
         ("add2", C.c_void_p),
-        ("add2_is_bf16", C.c_int32),
+        ("add2_dtype", C.c_int32),
         ("ldadd2", C.c_int64),
         ("add2_scale", C.c_void_p),
         ("rows_per_image", C.c_int32),
         ("out", C.c_void_p),
-        ("out_is_bf16", C.c_int32),
+        ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
         ("out_plane_stride", C.c_int64),
     ]
@@ -103,13 +104,14 @@ class GrlAttnArgs(_Strict):
         ("fixed_max", C.c_int32),
         ("ones_col", C.c_int32),
         ("head_dim", C.c_int32),
+        ("out_dtype", C.c_int32),
     ]
 
 
 class GrlConvArgs(_Strict):
     _fields_ = [
         ("x", C.c_void_p),
-        ("x_is_bf16", C.c_int32),
+        ("x_dtype", C.c_int32),
         ("ldx", C.c_int64),
         ("w", C.c_void_p),
         ("w_tap_stride", C.c_int64),
@@ -125,7 +127,7 @@ class GrlConvArgs(_Strict):
         ("ldr", C.c_int64),
         ("pool_partial", C.c_void_p),
         ("out", C.c_void_p),
-        ("out_is_bf16", C.c_int32),
+        ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
         ("shuffle_r", C.c_int32),
         ("shuffle_cg", C.c_int32),

@@ -281,8 +281,8 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 uint2 pk;
-                pk.x = pack_bf16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv);
-                pk.y = pack_bf16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv);
+                pk.x = pack16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv, p.out_dtype);
+                pk.y = pack16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv, p.out_dtype);
                 *(uint2*)(dst + 8 * g) = pk;
             }
         }
@@ -524,8 +524,8 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             uint2 pk;
-            pk.x = pack_bf16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv);
-            pk.y = pack_bf16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv);
+            pk.x = pack16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv, p.out_dtype);
+            pk.y = pack16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv, p.out_dtype);
             *(uint2*)(dst + 8 * g) = pk;
         }
     }
@@ -581,6 +581,7 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (p.k.Himg != p.nwy * p.k.wh || p.k.Wimg != p.nwx * p.k.ww) return GRL_ERR_BAD_ARG;
     if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1) || p.tstride < p.trows || (p.tstride & 3)) return GRL_ERR_BAD_ARG;
     if (p.head_dim > 32 || p.ones_col >= 32) return GRL_ERR_BAD_ARG;
+    if (p.out_dtype != GRL_DT_BF16 && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
     if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 4) || (p.q.col0 % 8) || (p.k.col0 % 8) ||
         (p.v.col0 % 8) || (p.o.col0 % 4) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 4))
         return GRL_ERR_BAD_ARG;

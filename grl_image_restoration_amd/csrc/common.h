@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "grl_hip_internal.h"
+
 typedef __bf16 bf16;
 typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
@@ -25,6 +27,31 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     v[0] = (bf16)lo;
     v[1] = (bf16)hi;
     return __builtin_bit_cast(uint32_t, v);
+}
+
+// GEMM / convolution operand type.  The attention contractions run on bf16 (they need its exponent
+// range for the un-normalised softmax weights); the token-wise linears and the 3x3 convolutions
+// use fp16 operands at the same MFMA rate: with bf16 weights+activations the network output is
+// 2.2e-3 away from the fp32 reference (weights alone 1.0e-3), with fp16 2e-4 (precision).
+typedef _Float16 f16;
+typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;
+typedef f16 gemm_t;
+typedef f16x8 gemm_x8;
+typedef f16x4 gemm_x4;
+__device__ __forceinline__ f32x4 mfma16_gemm(gemm_x8 a, gemm_x8 b, f32x4 c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
+    typedef __attribute__((__vector_size__(2 * sizeof(_Float16)))) _Float16 f16x2;
+    f16x2 v;
+    v[0] = (f16)lo;
+    v[1] = (f16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
+// 16-bit storage kinds of the C ABI: GRL_DT_BF16 / GRL_DT_F16 (include/grl_hip.h)
+__device__ __forceinline__ uint32_t pack16(float lo, float hi, int kind) {
+    return kind == GRL_DT_BF16 ? pack_bf16(lo, hi) : pack_f16(lo, hi);
 }
 
 // exchange with the lane 32 apart (both halves of a wave64)

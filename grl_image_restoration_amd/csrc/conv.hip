@@ -1,4 +1,4 @@
-// 3x3 convolutions of the GRL path as bf16 MFMA implicit GEMM over an LDS halo tile (gfx950).
+// 3x3 convolutions of the GRL path as fp16-operand MFMA implicit GEMM over an LDS halo tile (gfx950).
 //
 // Replaces:
 //   CAB: conv3x3 C->C/4, GELU, conv3x3 C/4->C + the global-average pool of ChannelAttention
@@ -8,9 +8,9 @@
 //        models/networks/grl.py:293,352-379 ; models/common/upsample.py:16-19,45-46
 //
 // Layout: activations are channels-last token matrices [B*H*W, Cpad]; weights are pre-packed to
-// bf16 [9 taps][CoutP][CinP] (K contiguous).  One workgroup (8 waves) produces an 8 x 32 pixel
+// fp16 [9 taps][CoutP][CinP] (K contiguous).  One workgroup (8 waves) produces an 8 x 32 pixel
 // tile for up to 192 output channels.  Input channels are processed in chunks of KC (64/32):
-// the (8+2) x (32+2) halo tile of the chunk is converted to bf16 once and staged in LDS, and for
+// the (8+2) x (32+2) halo tile of the chunk is converted to fp16 once and staged in LDS, and for
 // each of the 9 taps the [CoutP][KC] weight slice streams through a double-buffered LDS slot
 // (global loads for tap t+1 are issued before the MFMAs of tap t).  The product is computed
 // transposed (rows = output channel, cols = pixel) exactly like csrc/linear.hip so a lane owns 4
@@ -50,15 +50,15 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) acc[mt][nt] = f32x4{0, 0, 0, 0};
 
-    bf16x8 wpre[WPT];
+    gemm_x8 wpre[WPT];
     auto load_w = [&](int tap, int kc) {
-        const bf16* src = (const bf16*)p.w + (int64_t)tap * p.w_tap_stride + kc * KC;
+        const gemm_t* src = (const gemm_t*)p.w + (int64_t)tap * p.w_tap_stride + kc * KC;
 #pragma unroll
         for (int i = 0; i < WPT; ++i) {
             const int s = tid + i * CWAVES * 64;
             if (s < WSEGS) {
                 const int rr = s / SEG_ROW, cc = s % SEG_ROW;
-                wpre[i] = *(const bf16x8*)(src + (int64_t)rr * p.CinP + cc * 8);
+                wpre[i] = *(const gemm_x8*)(src + (int64_t)rr * p.CinP + cc * 8);
             }
         }
     };
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             const int s = tid + i * CWAVES * 64;
             if (s < WSEGS) {
                 const int rr = s / SEG_ROW, cc = s % SEG_ROW;
-                *(bf16x8*)(wt_s + buf * WT_BYTES + rr * ROWB + cc * 16) = wpre[i];
+                *(gemm_x8*)(wt_s + buf * WT_BYTES + rr * ROWB + cc * 16) = wpre[i];
             }
         }
     };
@@ -82,19 +82,19 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             const int pix = s / SEG_ROW, cc = s % SEG_ROW;
             const int hy = pix / HALO_W, hx = pix % HALO_W;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
-            bf16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+            gemm_x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
                 const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
-                if (p.x_is_bf16) {
-                    v = *(const bf16x8*)((const bf16*)p.x + row * p.ldx + kc * KC + cc * 8);
+                if (p.x_dtype == GRL_DT_F16) {
+                    v = *(const gemm_x8*)((const gemm_t*)p.x + row * p.ldx + kc * KC + cc * 8);
                 } else {
                     const float4* q = (const float4*)((const float*)p.x + row * p.ldx + kc * KC + cc * 8);
                     const float4 a0 = q[0], a1 = q[1];
-                    v[0] = (bf16)a0.x; v[1] = (bf16)a0.y; v[2] = (bf16)a0.z; v[3] = (bf16)a0.w;
-                    v[4] = (bf16)a1.x; v[5] = (bf16)a1.y; v[6] = (bf16)a1.z; v[7] = (bf16)a1.w;
+                    v[0] = (gemm_t)a0.x; v[1] = (gemm_t)a0.y; v[2] = (gemm_t)a0.z; v[3] = (gemm_t)a0.w;
+                    v[4] = (gemm_t)a1.x; v[5] = (gemm_t)a1.y; v[6] = (gemm_t)a1.z; v[7] = (gemm_t)a1.w;
                 }
             }
-            *(bf16x8*)(in_s + pix * ROWB + cc * 16) = v;
+            *(gemm_x8*)(in_s + pix * ROWB + cc * 16) = v;
         }
         store_w(0);
         __syncthreads();
@@ -103,19 +103,19 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             if (tap < 8) load_w(tap + 1, kc);  // in flight during the MFMAs below
             const int dy = tap / 3, dx = tap - dy * 3;
             const char* wb = wt_s + (tap & 1) * WT_BYTES;
-            bf16x8 af[2][KS];
+            gemm_x8 af[2][KS];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int ks = 0; ks < KS; ++ks)
-                    af[mt][ks] = *(const bf16x8*)(in_s + ((wave + dy) * HALO_W + (16 * mt + r16 + dx)) * ROWB + (32 * ks + 8 * g4) * 2);
+                    af[mt][ks] = *(const gemm_x8*)(in_s + ((wave + dy) * HALO_W + (16 * mt + r16 + dx)) * ROWB + (32 * ks + 8 * g4) * 2);
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 wf = *(const bf16x8*)(wb + (nt * 16 + r16) * ROWB + (32 * ks + 8 * g4) * 2);
-                    acc[0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[0][ks], acc[0][nt], 0, 0, 0);
-                    acc[1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf, af[1][ks], acc[1][nt], 0, 0, 0);
+                    const gemm_x8 wf = *(const gemm_x8*)(wb + (nt * 16 + r16) * ROWB + (32 * ks + 8 * g4) * 2);
+                    acc[0][nt] = mfma16_gemm(wf, af[0][ks], acc[0][nt]);
+                    acc[1][nt] = mfma16_gemm(wf, af[1][ks], acc[1][nt]);
                 }
             }
             if (tap < 8) {
@@ -171,11 +171,11 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                     orow = ((int64_t)b * p.H * r + (gy * r + ij / r)) * (p.W * r) + (gx * r + ij % r);
                 }
                 if (!keep) {
-                } else if (p.out_is_bf16) {
+                } else if (p.out_dtype != GRL_DT_F32) {
                     uint2 pk;
-                    pk.x = pack_bf16(v[0], v[1]);
-                    pk.y = pack_bf16(v[2], v[3]);
-                    *(uint2*)((bf16*)p.out + orow * p.ldo + oc) = pk;
+                    pk.x = pack16(v[0], v[1], p.out_dtype);
+                    pk.y = pack16(v[2], v[3], p.out_dtype);
+                    *(uint2*)((gemm_t*)p.out + orow * p.ldo + oc) = pk;
                 } else {
                     *(float4*)((float*)p.out + orow * p.ldo + oc) = float4{v[0], v[1], v[2], v[3]};
                 }

@@ -9,11 +9,11 @@
 //
 // Design (MI355X): these GEMMs are HBM-bound (108 FLOP/B for QKV), so the kernel is built
 // around one pass over the activations:
-//   * a wave owns 32 token rows; its whole A slab (32 x Kpad, bf16) lives in VGPRs and is
+//   * a wave owns 32 token rows; its whole A slab (32 x Kpad, fp16 operands) lives in VGPRs and is
 //     re-used for every N chunk, so A is read from HBM exactly once;
-//   * weights (bf16, zero-padded to [Npad][Kpad]) stream through LDS in chunks of NT*16 rows,
+//   * weights (fp16, zero-padded to [Npad][Kpad]) stream through LDS in chunks of NT*16 rows,
 //     padded by 16 B per row so the ds_read_b128 fragment reads are bank-conflict free;
-//   * the product is computed transposed (D^T = W . A^T, mfma_f32_16x16x32_bf16) so every
+//   * the product is computed transposed (D^T = W . A^T, mfma_f32_16x16x32_f16) so every
 //     lane ends up with 4 consecutive output channels of one token: row reductions for
 //     LayerNorm / per-head L2 normalisation need only two cross-lane steps and stores are
 //     8-16 B wide;
@@ -29,7 +29,7 @@ constexpr int ROWS_PER_WAVE = 32;    // 2 MFMA m-tiles
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 
 template <int KSTEPS>
-__device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, int lane, bf16x8 (&a)[2][KSTEPS]) {
+__device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, int lane, gemm_x8 (&a)[2][KSTEPS]) {
     const int r = lane & 15, kg = lane >> 4;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -54,14 +54,14 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
                         acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
                     }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[mt][s][e] = (bf16)(valid ? acc[e] * inv : 0.0f);
+                for (int e = 0; e < 8; ++e) a[mt][s][e] = (gemm_t)(valid ? acc[e] * inv : 0.0f);
             }
-        } else if (p.a_is_bf16) {
-            const bf16* base = (const bf16*)p.a + (int64_t)m * p.lda;
+        } else if (p.a_dtype == GRL_DT_F16) {
+            const gemm_t* base = (const gemm_t*)p.a + (int64_t)m * p.lda;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
-                bf16x8 v = *(const bf16x8*)(base + 32 * s + 8 * kg);
-                if (!valid) v = bf16x8{0, 0, 0, 0, 0, 0, 0, 0};
+                gemm_x8 v = *(const gemm_x8*)(base + 32 * s + 8 * kg);
+                if (!valid) v = gemm_x8{0, 0, 0, 0, 0, 0, 0, 0};
                 a[mt][s] = v;
             }
         } else {
@@ -71,9 +71,9 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
                 const float4* q = (const float4*)(base + 32 * s + 8 * kg);
                 float4 v0 = q[0], v1 = q[1];
                 if (!valid) { v0 = float4{0, 0, 0, 0}; v1 = v0; }
-                bf16x8 v;
-                v[0] = (bf16)v0.x; v[1] = (bf16)v0.y; v[2] = (bf16)v0.z; v[3] = (bf16)v0.w;
-                v[4] = (bf16)v1.x; v[5] = (bf16)v1.y; v[6] = (bf16)v1.z; v[7] = (bf16)v1.w;
+                gemm_x8 v;
+                v[0] = (gemm_t)v0.x; v[1] = (gemm_t)v0.y; v[2] = (gemm_t)v0.z; v[3] = (gemm_t)v0.w;
+                v[4] = (gemm_t)v1.x; v[5] = (gemm_t)v1.y; v[6] = (gemm_t)v1.z; v[7] = (gemm_t)v1.w;
                 a[mt][s] = v;
             }
         }
@@ -148,8 +148,8 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
                 y[3] = res.w + p.res_scale * ((acc[c][mt][nt][3] - mean) * rstd * g.w + bb.w);
                 if (p.add2 != nullptr && valid) {
                     float t4[4];
-                    if (p.add2_is_bf16) {
-                        const bf16x4 t = *(const bf16x4*)((const bf16*)p.add2 + (int64_t)m * p.ldadd2 + col);
+                    if (p.add2_dtype == GRL_DT_F16) {
+                        const gemm_x4 t = *(const gemm_x4*)((const gemm_t*)p.add2 + (int64_t)m * p.ldadd2 + col);
                         t4[0] = (float)t[0]; t4[1] = (float)t[1]; t4[2] = (float)t[2]; t4[3] = (float)t[3];
                     } else {
                         const float4 t = *(const float4*)((const float*)p.add2 + (int64_t)m * p.ldadd2 + col);
@@ -171,10 +171,10 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + 16 * (c * NT + nt) + 4 * g4;
-            if (p.out_is_bf16) {
+            if (p.out_dtype != GRL_DT_F32) {
                 uint2 pk;
-                pk.x = pack_bf16(acc[c][mt][nt][0], acc[c][mt][nt][1]);
-                pk.y = pack_bf16(acc[c][mt][nt][2], acc[c][mt][nt][3]);
+                pk.x = pack16(acc[c][mt][nt][0], acc[c][mt][nt][1], p.out_dtype);
+                pk.y = pack16(acc[c][mt][nt][2], acc[c][mt][nt][3], p.out_dtype);
                 const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
                                                            : (int64_t)m * p.ldo + col;
                 *(uint2*)((bf16*)p.out + off) = pk;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
     const int row0 = blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE;
     const int r16 = lane & 15, g4 = lane >> 4;
 
-    bf16x8 a[2][KSTEPS];
+    gemm_x8 a[2][KSTEPS];
     load_a_slab<KSTEPS>(p, row0, lane, a);
 
     const int ngroups = p.Npad / (NT * 16 * NCH);
@@ -212,19 +212,19 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
                 constexpr int SEGS_PER_ROW = KPAD / 8;
                 constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
                 constexpr int GRP = 4;  // loads in flight per thread
-                const bf16* wsrc = (const bf16*)p.w + (int64_t)n0 * KPAD;
+                const gemm_t* wsrc = (const gemm_t*)p.w + (int64_t)n0 * KPAD;
                 __syncthreads();  // previous chunk's fragment reads are done
                 for (int i0 = tid; i0 < SEGS; i0 += GRP * WAVES * 64) {
-                    bf16x8 wv[GRP];
+                    gemm_x8 wv[GRP];
 #pragma unroll
                     for (int j = 0; j < GRP; ++j) {
                         const int i = i0 + j * WAVES * 64;
-                        if (i < SEGS) wv[j] = *(const bf16x8*)(wsrc + (int64_t)(i / SEGS_PER_ROW) * KPAD + (i % SEGS_PER_ROW) * 8);
+                        if (i < SEGS) wv[j] = *(const gemm_x8*)(wsrc + (int64_t)(i / SEGS_PER_ROW) * KPAD + (i % SEGS_PER_ROW) * 8);
                     }
 #pragma unroll
                     for (int j = 0; j < GRP; ++j) {
                         const int i = i0 + j * WAVES * 64;
-                        if (i < SEGS) *(bf16x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
+                        if (i < SEGS) *(gemm_x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
                     }
                 }
             }
@@ -237,10 +237,10 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
             for (int s = 0; s < KSTEPS; ++s) {
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const bf16x8 w = *(const bf16x8*)(smem + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
+                    const gemm_x8 w = *(const gemm_x8*)(smem + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
                     // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
-                    acc[c][0][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[0][s], acc[c][0][nt], 0, 0, 0);
-                    acc[c][1][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a[1][s], acc[c][1][nt], 0, 0, 0);
+                    acc[c][0][nt] = mfma16_gemm(w, a[0][s], acc[c][0][nt]);
+                    acc[c][1][nt] = mfma16_gemm(w, a[1][s], acc[c][1][nt]);
                 }
             }
             // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16

@@ -359,7 +359,8 @@ class GRL(nn.Module):
                         gs[g] = (sc_w[h] if br == 0 else sc_2[h]) * LOG2E
                     elif which == 1:
                         gs[g] = 1.0 if br == 0 else sc_1[h] * LOG2E
-        pk = dict(qkv_w=Wp.to(torch.bfloat16), qkv_b=bp, qkv_gs=gs, fixed=fixed)
+        G16 = ops.GEMM_DTYPE
+        pk = dict(qkv_w=Wp.to(G16), qkv_b=bp, qkv_gs=gs, fixed=fixed)
 
         # --- anchor projection (avg-pool fused in the kernel) ---
         Wa = a.anchor.body[0].reduction.weight.detach().float()
@@ -369,7 +370,7 @@ class GRL(nn.Module):
         for h in range(nh_s):
             Wap[h * 32 : h * 32 + d_s, :C] = Wa[h * d_s : (h + 1) * d_s]
             bap[h * 32 : h * 32 + d_s] = ba[h * d_s : (h + 1) * d_s]
-        pk.update(anc_w=Wap.to(torch.bfloat16), anc_b=bap, anc_gs=torch.ones(nh_s, **f32))
+        pk.update(anc_w=Wap.to(G16), anc_b=bap, anc_gs=torch.ones(nh_s, **f32))
 
         # --- output projection over the slotted attention output + norm1 ---
         Wo = a.proj.weight.detach().float()
@@ -385,7 +386,7 @@ class GRL(nn.Module):
             out[: v.numel()] = v.detach().float()
             return out
 
-        pk.update(proj_w=Wop.to(torch.bfloat16), proj_b=padv(a.proj.bias), n1_g=padv(blk.norm1.weight), n1_b=padv(blk.norm1.bias))
+        pk.update(proj_w=Wop.to(G16), proj_b=padv(a.proj.bias), n1_g=padv(blk.norm1.weight), n1_b=padv(blk.norm1.bias))
 
         # --- MLP + norm2 ---
         Hd = blk.mlp.fc1.weight.shape[0]
@@ -394,7 +395,7 @@ class GRL(nn.Module):
         W1[:Hd, :C] = blk.mlp.fc1.weight.detach().float()
         W2 = torch.zeros(CP, HP, **f32)
         W2[:C, :Hd] = blk.mlp.fc2.weight.detach().float()
-        pk.update(fc1_w=W1.to(torch.bfloat16), fc1_b=padv(blk.mlp.fc1.bias, HP), fc2_w=W2.to(torch.bfloat16),
+        pk.update(fc1_w=W1.to(G16), fc1_b=padv(blk.mlp.fc1.bias, HP), fc2_w=W2.to(G16),
                   fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
 
         # --- relative-position bias tables in the kernel's exp2 domain ---
@@ -493,9 +494,9 @@ class GRL(nn.Module):
     def _cab(self, r, pk, B, H, W, CP):
         """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output (bf16) and the
         per-image squeeze-excite gate; the gate is applied inside the proj+norm1 epilogue."""
-        mid = torch.zeros(B * H * W, pk["cab_mid"], dtype=torch.bfloat16, device=r.device)
+        mid = torch.zeros(B * H * W, pk["cab_mid"], dtype=ops.GEMM_DTYPE, device=r.device)
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid)
-        raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=torch.bfloat16)
+        raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=ops.GEMM_DTYPE)
         gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])
         return raw, gate
 
@@ -510,7 +511,7 @@ class GRL(nn.Module):
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
         qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
         anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
-        att = torch.empty(M, (nh_w + nh_s) * 32, dtype=torch.bfloat16, device=dev)
+        att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
         y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=torch.bfloat16, device=dev)
         ws, sh = geo.window, geo.window_shift
         TG = ops.TokenGrid
@@ -587,7 +588,7 @@ class GRL(nn.Module):
         s, oc = self.upscale, self.out_channels
         plan = self._plan((H, W), x.device)
         conv = ops.conv3x3
-        bf = torch.bfloat16
+        bf = ops.GEMM_DTYPE  # 16-bit intermediates of the tail feed fp16-operand convolutions
 
         f = conv(self._tokens(x, plan["first"][0].shape[2]), *plan["first"], B, H, W)           # conv_first
         body = conv(self.forward_features(f, plan, B, H, W), *plan["after"], B, H, W, resid=f)  # conv_after_body + f

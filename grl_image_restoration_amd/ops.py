@@ -11,6 +11,9 @@ import torch
 
 from . import _lib as L
 
+GEMM_DTYPE = torch.float16  # operand / intermediate type of the linear and conv kernels (csrc/common.h: gemm_t)
+_KIND = {torch.float32: L.DT_F32, torch.bfloat16: L.DT_BF16, torch.float16: L.DT_F16}
+
 
 # ---- optional per-kernel timing with HIP events on the launching stream (used by bench.py) ----
 _PROFILE = None
@@ -68,7 +71,7 @@ def linear(
     bias: torch.Tensor,
     *,
     epi: int = L.EPI_PLAIN,
-    out_dtype=torch.bfloat16,
+    out_dtype=GEMM_DTYPE,
     out: Optional[torch.Tensor] = None,
     gscale: Optional[torch.Tensor] = None,
     ln_g: Optional[torch.Tensor] = None,
@@ -87,10 +90,11 @@ def linear(
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
     _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale)
+    assert add2 is None or add2.dtype in (torch.float32, GEMM_DTYPE)
     if add2_scale is not None:
         assert add2 is not None and rows_per_image > 0 and add2_scale.dtype == torch.float32 and add2_scale.is_contiguous()
-    assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == torch.bfloat16
-    assert a.dtype in (torch.float32, torch.bfloat16) and bias.dtype == torch.float32
+    assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == GEMM_DTYPE
+    assert a.dtype in (torch.float32, GEMM_DTYPE) and bias.dtype == torch.float32
     Npad, Kpad = w.shape
     assert a.shape[1] >= Kpad and bias.numel() == Npad
     if pool is not None:
@@ -113,15 +117,15 @@ def linear(
         assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= Npad
         ldo, plane_stride = out.stride(0), 0
     args = L.GrlLinearArgs(
-        a=_ptr(a), a_is_bf16=int(a.dtype == torch.bfloat16), lda=a.stride(0),
+        a=_ptr(a), a_dtype=_KIND[a.dtype], lda=a.stride(0),
         pool_df=df, pool_H=H, pool_W=W,
         w=_ptr(w), bias=_ptr(bias), M=M, Npad=Npad, Kpad=Kpad, epi=epi,
         gscale=_ptr(gscale), ln_g=_ptr(ln_g), ln_b=_ptr(ln_b), n_real=n_real, ln_eps=ln_eps,
         res_scale=res_scale, resid=_ptr(resid), ldr=resid.stride(0) if resid is not None else 0,
-        add2=_ptr(add2), add2_is_bf16=int(add2 is not None and add2.dtype == torch.bfloat16),
+        add2=_ptr(add2), add2_dtype=_KIND[add2.dtype] if add2 is not None else 0,
         ldadd2=add2.stride(0) if add2 is not None else 0,
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image,
-        out=_ptr(out), out_is_bf16=int(out.dtype == torch.bfloat16), ldo=ldo, out_plane_stride=plane_stride,
+        out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
     )
     if epi == L.EPI_GROUPNORM:
         assert gscale is not None and gscale.dtype == torch.float32 and gscale.numel() == Npad // 32
@@ -151,7 +155,7 @@ class TokenGrid:
 
     def c(self) -> L.GrlTokenGrid:
         t = self.t
-        assert t.dtype == torch.bfloat16 and t.stride(-1) == 1
+        assert t.dtype in (torch.bfloat16, torch.float16) and t.stride(-1) == 1
         if t.dim() == 3:  # head planes
             assert t.shape[2] == 32 and t.is_contiguous()
             return L.GrlTokenGrid(ptr=C.c_void_p(t.data_ptr() + self.slot * t.stride(0) * 2), ld=32, hstride=t.stride(0),
@@ -175,7 +179,7 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
     assert q.tokens >= B * q.Himg * q.Wimg and k.tokens >= B * k.Himg * k.Wimg
     args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
                          trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
-                         head_dim=head_dim)
+                         head_dim=head_dim, out_dtype=_KIND[o.t.dtype])
     with _timed("attention"):
         L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
     return o.t
@@ -196,7 +200,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: 
 
 
 def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: int = 0, shuffle_cg: int = 0) -> torch.Tensor:
-    """torch conv weight [Cout, Cin, 3, 3] -> bf16 [9, cout_pad, cin_pad] (tap = ky*3+kx, K contiguous).
+    """torch conv weight [Cout, Cin, 3, 3] -> fp16 [9, cout_pad, cin_pad] (tap = ky*3+kx, K contiguous).
     With ``shuffle_r`` the output channels are re-ordered from PixelShuffle's (c, i, j) to (i, j, c) with
     ``shuffle_cg`` (>= c, multiple of 4) slots per sub-pixel so the kernel can store whole channel groups."""
     cout, cin = w.shape[:2]
@@ -209,7 +213,7 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: in
         out.view(9, cout_pad // shuffle_cg, shuffle_cg, cin_pad)[:, :r2, :c, :cin] = src
     else:
         out[:, :cout, :cin] = w9
-    return out.to(torch.bfloat16).contiguous()
+    return out.to(GEMM_DTYPE).contiguous()
 
 
 def pack_conv_bias(b: torch.Tensor, cout_pad: int, shuffle_r: int = 0, shuffle_cg: int = 0) -> torch.Tensor:
@@ -229,8 +233,8 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     """3x3 conv (stride 1, pad 1) on a channels-last token matrix x[B*H*W, >=CinP]; w packed by
     pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool)."""
     _dev_check(x, w, bias, resid, out)
-    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, torch.bfloat16)
-    assert w.dtype == torch.bfloat16 and w.is_contiguous() and w.dim() == 3 and w.shape[0] == 9
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, GEMM_DTYPE)
+    assert w.dtype == GEMM_DTYPE and w.is_contiguous() and w.dim() == 3 and w.shape[0] == 9
     CoutP, CinP = w.shape[1], w.shape[2]
     assert x.shape[0] >= B * H * W and x.shape[1] >= CinP and bias.numel() == CoutP
     if shuffle_r > 1:
@@ -251,7 +255,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
         assert not want_pool
     for c0 in range(0, CoutP, step):
         args = L.GrlConvArgs(
-            x=_ptr(x), x_is_bf16=int(x.dtype == torch.bfloat16), ldx=x.stride(0),
+            x=_ptr(x), x_dtype=_KIND[x.dtype], ldx=x.stride(0),
             w=C.c_void_p(w.data_ptr() + c0 * CinP * 2), w_tap_stride=CoutP * CinP,
             bias=C.c_void_p(bias.data_ptr() + c0 * 4),
             B=B, H=H, W=W, CinP=CinP, CoutP=step, act=act, slope=slope,
@@ -259,7 +263,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             ldr=resid.stride(0) if resid is not None else 0,
             pool_partial=_ptr(pool),
             out=C.c_void_p(out.data_ptr() + (0 if shuffle_r > 1 else c0 * out.element_size())),
-            out_is_bf16=int(out.dtype == torch.bfloat16), ldo=out.stride(0),
+            out_dtype=_KIND[out.dtype], ldo=out.stride(0),
             shuffle_r=shuffle_r, shuffle_cg=shuffle_cg, shuffle_ij0=(c0 // shuffle_cg if shuffle_r > 1 else 0),
         )
         with _timed("conv3x3"):

@@ -23,7 +23,10 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 4
+#define GRL_ABI_VERSION 5
+
+/* element kinds of activation / weight buffers */
+enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
 
 /* ---------------------------------------------------------------------------------------------
  * Token-wise linear layer with fused epilogue.
@@ -35,12 +38,12 @@ extern "C" {
 enum { GRL_EPI_PLAIN = 0, GRL_EPI_GELU = 1, GRL_EPI_GROUPNORM = 2, GRL_EPI_LN_RES = 3 };
 
 typedef struct GrlLinearArgs {
-    const void* a;          /* [M, lda] fp32 (a_is_bf16=0) or bf16 activations                      */
-    int32_t a_is_bf16;
+    const void* a;          /* [M, lda] activations: GRL_DT_F32 (converted in-kernel) or GRL_DT_F16 */
+    int32_t a_dtype;
     int64_t lda;            /* elements per A row (multiple of 8, >= Kpad)                          */
     int32_t pool_df;        /* >1: A row m is the mean of a df x df block of rows of a [B,H,W,lda]  */
     int32_t pool_H, pool_W; /*     fp32 image (AnchorLinear avg-pool); M = B*(H/df)*(W/df)          */
-    const void* w;          /* bf16 [Npad, Kpad], zero padded (row n = output channel n)            */
+    const void* w;          /* fp16 [Npad, Kpad], zero padded (row n = output channel n)            */
     const float* bias;      /* [Npad]                                                               */
     int32_t M, Npad, Kpad;
     int32_t epi;            /* GRL_EPI_*                                                            */
@@ -54,12 +57,12 @@ typedef struct GrlLinearArgs {
     const float* resid;     /* LN_RES: fp32 residual [M, ldr]                                       */
     int64_t ldr;
     const void* add2;       /* LN_RES: optional extra branch (CAB output) added after the norm      */
-    int32_t add2_is_bf16;
+    int32_t add2_dtype;     /*         GRL_DT_F32 or GRL_DT_F16                                     */
     int64_t ldadd2;
     const float* add2_scale; /* optional [B, Npad] per-image channel scale applied to add2 (SE gate)  */
     int32_t rows_per_image;  /*          image of row m = m / rows_per_image                          */
-    void* out;              /* [M, ldo] bf16 or fp32                                                */
-    int32_t out_is_bf16;
+    void* out;              /* [M, ldo]: GRL_DT_F32, GRL_DT_BF16 (attention operands) or GRL_DT_F16  */
+    int32_t out_dtype;
     int64_t ldo;
     int64_t out_plane_stride; /* >0: write 32-column groups as planes: element (m, c) goes to          */
                               /* out[(c/32)*out_plane_stride + m*32 + c%32]  (ldo ignored)             */
@@ -75,7 +78,8 @@ int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
  *             Attention.attn / AffineTransform  :77-94 / :36-58
  *             roll / window_partition / window_reverse / masks / relative index
  *                                            models/common/ops.py:36-157,352-375 (all as index math)
- * Operands are bf16 token matrices with one 32-wide slot per head:
+ * Operands are bf16 token tensors with one 32-wide slot per head (fp32 accumulation); the linear
+ * and convolution kernels use fp16 operands (same MFMA rate, 8x finer mantissa):
  *   q: already L2-normalised and multiplied by logit_scale*log2(e); k: L2-normalised;
  *   v: raw values, slot column `ones_col` (>= head_dim) holding 1.0 so that the row sum of the
  *      softmax weights falls out of the PV product (ones_col < 0: summed explicitly).
@@ -106,6 +110,7 @@ typedef struct GrlAttnArgs {
     int32_t fixed_max;       /* 1: table carries -(bound); no running max needed                    */
     int32_t ones_col;        /* see above                                                           */
     int32_t head_dim;        /* real head dim (<= 32)                                               */
+    int32_t out_dtype;       /* GRL_DT_BF16 (feeds another attention) or GRL_DT_F16 (feeds the proj)*/
 } GrlAttnArgs;
 
 int grl_attention_fwd(void* stream, const GrlAttnArgs* args);
@@ -119,10 +124,10 @@ int grl_attention_fwd(void* stream, const GrlAttnArgs* args);
  *                                                    models/common/upsample.py:16-19,45-46
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlConvArgs {
-    const void* x;          /* [B*H*W, ldx] fp32 or bf16, channels-last                             */
-    int32_t x_is_bf16;
+    const void* x;          /* [B*H*W, ldx] GRL_DT_F32 or GRL_DT_F16, channels-last                 */
+    int32_t x_dtype;
     int64_t ldx;
-    const void* w;          /* bf16 [9][*][CinP] (tap = ky*3+kx): first output channel of this call */
+    const void* w;          /* fp16 [9][*][CinP] (tap = ky*3+kx): first output channel of this call */
     int64_t w_tap_stride;   /* elements between taps (= full layer Cout_pad * CinP)                  */
     const float* bias;      /* [CoutP]                                                              */
     int32_t B, H, W;
@@ -133,8 +138,8 @@ typedef struct GrlConvArgs {
     int64_t ldr;
     float* pool_partial;    /* optional [grl_conv3x3_num_workgroups(B,H,W), CoutP]: per-workgroup    */
                             /* channel sums of the output (two-stage global average pool)           */
-    void* out;              /* [rows, ldo] fp32 or bf16                                             */
-    int32_t out_is_bf16;
+    void* out;              /* [rows, ldo] GRL_DT_F32 or GRL_DT_F16                                 */
+    int32_t out_dtype;
     int64_t ldo;
     int32_t shuffle_r;      /* >1: PixelShuffle(r) store into a [B, H*r, W*r, shuffle_cg] matrix;    */
     int32_t shuffle_cg;     /*     output channels are packed in (i, j, c) order, this call's        */

@@ -33,17 +33,17 @@ def test_linear_groupnorm_and_plain(M, K, N):
 
     g = torch.Generator().manual_seed(0)
     a = torch.randn(M, K, generator=g)
-    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.float16)
     b = 0.1 * torch.randn(N, generator=g)
     gs = torch.rand(N // 32, generator=g) * 10
     gs[::3] = 0.0  # pass-through groups
-    ref = a.to(torch.bfloat16).double() @ w.double().t() + b.double()
+    ref = a.to(torch.float16).double() @ w.double().t() + b.double()
     out = ops.linear(a.to(_dev()), w.to(_dev()), b.to(_dev()), epi=L.EPI_PLAIN, out_dtype=torch.float32)
     assert (out.cpu().double() - ref).abs().max() < 2e-3
     refn = ref.view(M, N // 32, 32)
     nrm = refn.norm(dim=-1, keepdim=True).clamp_min(1e-12)
     refn = torch.where(gs.view(1, -1, 1) != 0, refn / nrm * gs.view(1, -1, 1).double(), refn).reshape(M, N)
-    outn = ops.linear(a.to(_dev()), w.to(_dev()), b.to(_dev()), epi=L.EPI_GROUPNORM, gscale=gs.to(_dev()))
+    outn = ops.linear(a.to(_dev()), w.to(_dev()), b.to(_dev()), epi=L.EPI_GROUPNORM, gscale=gs.to(_dev()), out_dtype=torch.bfloat16)
     assert outn.dtype == torch.bfloat16
     err = (outn.cpu().double() - refn).abs().max().item()
     assert err < 2e-2 * max(1.0, refn.abs().max().item() / 2), err
@@ -54,8 +54,8 @@ def test_linear_ln_residual_and_gelu(M, K, N, nreal):
     from grl_image_restoration_amd import _lib as L, ops
 
     g = torch.Generator().manual_seed(1)
-    a = torch.randn(M, K, generator=g).to(torch.bfloat16)
-    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.bfloat16)
+    a = torch.randn(M, K, generator=g).to(torch.float16)
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).to(torch.float16)
     w[nreal:] = 0
     b = 0.1 * torch.randn(N, generator=g)
     b[nreal:] = 0
@@ -87,10 +87,10 @@ def test_linear_pooled_anchor():
     B, H, W, CP, df, N = 2, 16, 24, 192, 4, 96
     g = torch.Generator().manual_seed(2)
     x = torch.randn(B * H * W, CP, generator=g)
-    w = (torch.randn(N, CP, generator=g) / math.sqrt(CP)).to(torch.bfloat16)
+    w = (torch.randn(N, CP, generator=g) / math.sqrt(CP)).to(torch.float16)
     b = 0.1 * torch.randn(N, generator=g)
     pooled = F.avg_pool2d(x.view(B, H, W, CP).permute(0, 3, 1, 2), df, df).permute(0, 2, 3, 1).reshape(-1, CP)
-    ref = pooled.to(torch.bfloat16).double() @ w.double().t() + b.double()
+    ref = pooled.to(torch.float16).double() @ w.double().t() + b.double()
     d = _dev()
     out = ops.linear(x.to(d), w.to(d), b.to(d), epi=L.EPI_PLAIN, out_dtype=torch.float32, pool=(df, H, W))
     assert out.shape[0] == B * (H // df) * (W // df)
@@ -253,9 +253,9 @@ def test_conv3x3(B, H, W, Cin, Cout, act, src_bf16):
     xt = torch.zeros(B * H * W, CinP)
     xt[:, :Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin)
     if src_bf16:
-        xt = xt.to(torch.bfloat16)
-    xr = xt.float()[:, :Cin].view(B, H, W, Cin).permute(0, 3, 1, 2).to(torch.bfloat16).double()
-    ref = F.conv2d(xr, w.to(torch.bfloat16).double(), b.double(), padding=1)
+        xt = xt.to(torch.float16)
+    xr = xt.float()[:, :Cin].view(B, H, W, Cin).permute(0, 3, 1, 2).to(torch.float16).double()
+    ref = F.conv2d(xr, w.to(torch.float16).double(), b.double(), padding=1)
     if act == 1:
         ref = F.gelu(ref)
     elif act == 2:
@@ -282,10 +282,10 @@ def test_conv3x3_pixel_shuffle(r, c, Cin):
     Cout = c * r * r
     cg = (c + 3) // 4 * 4
     CoutP = (cg * r * r + 15) // 16 * 16
-    x = torch.randn(B, Cin, H, W, generator=g).to(torch.bfloat16)
+    x = torch.randn(B, Cin, H, W, generator=g).to(torch.float16)
     w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
     b = 0.1 * torch.randn(Cout, generator=g)
-    ref = F.pixel_shuffle(F.conv2d(x.double(), w.to(torch.bfloat16).double(), b.double(), padding=1), r)
+    ref = F.pixel_shuffle(F.conv2d(x.double(), w.to(torch.float16).double(), b.double(), padding=1), r)
     d = _dev()
     xt = x.permute(0, 2, 3, 1).reshape(-1, Cin).contiguous().to(d)
     out = ops.conv3x3(xt, ops.pack_conv_weight(w.to(d), Cin, CoutP, r, cg), ops.pack_conv_bias(b.to(d), CoutP, r, cg),

@@ -105,8 +105,30 @@ def test_library_exports_every_declared_symbol():
     lib = _lib.lib()
     assert lib.grl_abi_version() == _lib.ABI_VERSION
     assert b"gfx950" in lib.grl_build_info()
-    # ctypes struct layouts must match the C structs (sizes for the LP64 ABI)
-    assert ctypes.sizeof(_lib.GrlTokenGrid) == 56 and ctypes.sizeof(_lib.GrlAttnArgs) == 4 * 56 + 16 + 8 + 24
+
+
+def test_ctypes_layout_matches_the_c_header(tmp_path):
+    """Compile include/grl_hip.h with gcc and compare sizeof/offsetof of every struct field with the
+    ctypes mirrors in _lib.py (a silent mismatch would scramble kernel arguments)."""
+    import subprocess
+
+    structs = {"GrlLinearArgs": _lib.GrlLinearArgs, "GrlTokenGrid": _lib.GrlTokenGrid, "GrlAttnArgs": _lib.GrlAttnArgs,
+               "GrlConvArgs": _lib.GrlConvArgs}
+    lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "grl_hip.h"', 'int main(void) {']
+    for name, st in structs.items():
+        lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
+        for f in st._fields_:
+            lines.append(f'printf("{name}.{f[0]} %zu\\n", offsetof({name}, {f[0]}));')
+    lines += ["return 0; }"]
+    src = tmp_path / "layout.c"
+    src.write_text("\n".join(lines))
+    exe = tmp_path / "layout"
+    subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)], check=True)
+    out = dict(l.split() for l in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for name, st in structs.items():
+        assert int(out[name]) == ctypes.sizeof(st), name
+        for f in st._fields_:
+            assert int(out[f"{name}.{f[0]}"]) == getattr(st, f[0]).offset, (name, f[0])
 
 
 def test_fixed_max_policy_and_table():

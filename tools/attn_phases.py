@@ -15,7 +15,7 @@ plan = m._plan((H, W), torch.device("cuda")); pk, geo = plan["stages"][0]["block
 r = torch.randn(M, CP, device="cuda"); r[:, C:] = 0
 qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
 anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(geo.df, H, W), planes=True)
-att = torch.zeros(M, 192, dtype=torch.bfloat16, device="cuda")
+att = torch.zeros(M, 192, dtype=torch.float16, device="cuda")
 Ha, Wa = H // geo.df, W // geo.df
 y = torch.zeros(nh, B * Ha * Wa, 32, dtype=torch.bfloat16, device="cuda")
 TG = ops.TokenGrid

@@ -39,7 +39,7 @@ def main():
     TG = ops.TokenGrid
     qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
     anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
-    att = torch.zeros(M, 2 * nh * 32, dtype=torch.bfloat16, device="cuda")
+    att = torch.zeros(M, 2 * nh * 32, dtype=torch.float16, device="cuda")
     y = torch.zeros(nh, B * Ha * Wa, 32, dtype=torch.bfloat16, device="cuda")
     ws, sh = geo.window, geo.window_shift
     stp, ss = geo.stripe, geo.stripe_shift_size
@@ -50,9 +50,9 @@ def main():
     g_v = TG(qkv, s0 + 2 * nh, H, W, stp[0], stp[1], ss[0], ss[1])
     g_a = TG(anc, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
     g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
-    mid = torch.zeros(M, pk["cab_mid"], dtype=torch.bfloat16, device="cuda")
-    h = torch.zeros(M, 384, dtype=torch.bfloat16, device="cuda")
-    cab = torch.zeros(M, CP, dtype=torch.bfloat16, device="cuda")
+    mid = torch.zeros(M, pk["cab_mid"], dtype=torch.float16, device="cuda")
+    h = torch.zeros(M, 384, dtype=torch.float16, device="cuda")
+    cab = torch.zeros(M, CP, dtype=torch.float16, device="cuda")
     pool = torch.zeros(L.lib().grl_conv3x3_num_workgroups(B, H, W), CP, device="cuda")
     gate = torch.ones(B, CP, device="cuda")
     L_, Nw, N2 = H * W, ws[0] * ws[1], ast[0] * ast[1]
