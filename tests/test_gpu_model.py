@@ -1,9 +1,10 @@
 """GPU parity of the whole network through the product module (HIP path) -- needs the MI355X.
 
 Compared against (a) the golden fixtures = outputs of the REAL reference (tests/golden) and (b) the
-CPU oracle on fresh seeded inputs.  Tolerance: BASELINE.json asks for 1e-3 max-abs (bf16 operands)
-on the network output and 0.01 dB PSNR; the assert below uses the measured envelope (printed) and
-DESIGN.md records where it stands against 1e-3.
+CPU oracle on fresh seeded inputs.  Tolerance (floating point path): BASELINE.json asks for 1e-3
+max-abs on the network output and 0.01 dB PSNR-Y.  GRL-Base (the benchmarked model, head_dim 30, 40
+blocks) is asserted at 1e-3 (measured 2.5e-4 .. 3e-4); the Tiny/Small/deblur fixtures are asserted at
+3e-3 (measured 1.0e-3 .. 1.8e-3: their bf16 attention operands dominate; DESIGN.md, precision).
 """
 import pytest
 import torch
@@ -14,7 +15,8 @@ from tests.util import golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
-TOL_MAXABS = 8e-3
+TOL_MAXABS = 3e-3
+TOL_BASE_SR = 1e-3  # north_star bar, GRL-Base x4 SR
 
 
 def _product(cfg, seed):
@@ -36,7 +38,7 @@ def test_hip_forward_matches_reference_golden(name):
     err = (y - z["output"]).abs().max().item()
     rms = (y - z["output"]).pow(2).mean().sqrt().item()
     print(f"{name}: max|hip - reference| = {err:.3e}  rms = {rms:.3e}")
-    assert err < TOL_MAXABS, err
+    assert err < (TOL_BASE_SR if name.startswith("base_sr4") else TOL_MAXABS), err
 
 
 def test_psnr_parity_and_loaded_extension():
@@ -68,6 +70,23 @@ def test_batch_and_ragged_input_consistency():
         y0, y1 = m(lq[:1].cuda()).cpu(), m(lq[1:].cuda()).cpu()
         want = O.grl_forward(lq, cfg, sd)
     assert yb.shape == (2, 3, 100, 140)
-    # the HIP kernels are batch-invariant; the MIOpen convolutions around them may pick another algorithm per batch
-    assert (yb[0] - y0[0]).abs().max().item() < 1e-4 and (yb[1] - y1[0]).abs().max().item() < 1e-4
+    # every kernel on the path is batch-invariant (per-token / per-window / per-tile work, fixed reduction orders)
+    assert torch.equal(yb[0], y0[0]) and torch.equal(yb[1], y1[0])
     assert (yb - want).abs().max().item() < TOL_MAXABS
+
+
+def test_tiled_inference_matches_reference_loop():
+    """BASELINE config 4 in miniature: tiled whole-image inference (engines/base.py:90-116) through the HIP
+    model with batched tiles vs the serial reference loop run on the CPU oracle."""
+    from grl_image_restoration_amd import make_config, tiling
+
+    cfg = make_config("base", "deblur", upscale=1, img_size=96, depths=[2, 2], num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+    m, sd = _product(cfg, 7)
+    lq, _ = O.synthetic_pair("deblur", (120, 200), 1, batch=1, seed=8)
+    with torch.no_grad():
+        want = E.forward_tile(lambda t: O.grl_forward(t, cfg, sd), lq, 96, 16, 1)
+        got = tiling.forward_tiled(m, lq.cuda(), 96, 16, 1, tile_batch=4).cpu()
+    assert got.shape == want.shape == (1, 3, 120, 200)
+    err = (got - want).abs().max().item()
+    print(f"tiled deblur 120x200 (tile 96/overlap 16, 6 tiles): max|hip - oracle| = {err:.3e}")
+    assert err < TOL_MAXABS
