@@ -24,7 +24,7 @@
 
 namespace {
 
-constexpr int WAVES = 4;             // 256 threads; several workgroups share a CU (occupancy hides the stage/compute/store phases)
+constexpr int WAVES = 8;             // 512 threads = 2 waves per SIMD; one persistent workgroup per CU (two if LDS allows)
 constexpr int ROWS_PER_WAVE = 32;    // 2 MFMA m-tiles
 constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
 
@@ -185,86 +185,97 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
         }
 }
 
-// One workgroup: ROWS_PER_WG token rows x all Npad output channels, NT n-tiles per weight chunk.
-// NCH > 1 (LayerNorm epilogue only): the accumulators of all NCH chunks stay in registers so the
-// row statistics see the whole row while only one NT*16-row weight chunk occupies LDS.
+// Persistent, weights-resident kernel.  A workgroup copies the whole [Npad][KPAD] weight matrix into
+// LDS once (rows padded by 16 B: conflict-free ds_read_b128 fragment reads) and then walks row tiles
+// of ROWS_PER_WG tokens with stride gridDim.x.  After the initial barrier the waves never synchronise
+// again: each wave loads the A slab of its 32 rows, sweeps the output channels in chunks of NT n-tiles
+// (accumulators of NCH chunks are kept when the LayerNorm epilogue needs the whole row), runs the
+// epilogue and stores -- so loads, MFMAs and stores of the 8 waves of a CU overlap freely and the
+// weights are fetched from L2 once per CU instead of once per 128 rows.
 template <int KSTEPS, int NT, int NCH, int EPI>
 __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KPAD = KSTEPS * 32;
     constexpr int ROWB = KPAD * 2 + 16;  // padded LDS row (bytes)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int row0 = blockIdx.x * ROWS_PER_WG + wave * ROWS_PER_WAVE;
     const int r16 = lane & 15, g4 = lane >> 4;
 
-    gemm_x8 a[2][KSTEPS];
-    load_a_slab<KSTEPS>(p, row0, lane, a);
-
-    const int ngroups = p.Npad / (NT * 16 * NCH);
-    for (int gch = 0; gch < ngroups; ++gch) {
-        f32x4 acc[NCH][2][NT];
+    {   // ---- weights -> LDS, GRP x 16 B global loads in flight per thread ----
+        constexpr int SEGS_PER_ROW = KPAD / 8;
+        constexpr int GRP = 8;
+        const int segs = p.Npad * SEGS_PER_ROW;
+        const gemm_t* wsrc = (const gemm_t*)p.w;
+        for (int i0 = tid; i0 < segs; i0 += GRP * WAVES * 64) {
+            gemm_x8 wv[GRP];
 #pragma unroll
-        for (int c = 0; c < NCH; ++c) {
-            const int n0 = (gch * NCH + c) * NT * 16;
-            // ---- stage the weight chunk [NT*16][KPAD] into LDS: all global loads of a thread are issued
-            // before the first LDS store (a load->store loop would serialise on L2 latency) ----
-            {
-                constexpr int SEGS_PER_ROW = KPAD / 8;
-                constexpr int SEGS = NT * 16 * SEGS_PER_ROW;
-                constexpr int GRP = 4;  // loads in flight per thread
-                const gemm_t* wsrc = (const gemm_t*)p.w + (int64_t)n0 * KPAD;
-                __syncthreads();  // previous chunk's fragment reads are done
-                for (int i0 = tid; i0 < SEGS; i0 += GRP * WAVES * 64) {
-                    gemm_x8 wv[GRP];
-#pragma unroll
-                    for (int j = 0; j < GRP; ++j) {
-                        const int i = i0 + j * WAVES * 64;
-                        if (i < SEGS) wv[j] = *(const gemm_x8*)(wsrc + (int64_t)(i / SEGS_PER_ROW) * KPAD + (i % SEGS_PER_ROW) * 8);
-                    }
-#pragma unroll
-                    for (int j = 0; j < GRP; ++j) {
-                        const int i = i0 + j * WAVES * 64;
-                        if (i < SEGS) *(gemm_x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
-                    }
-                }
+            for (int j = 0; j < GRP; ++j) {
+                const int i = i0 + j * WAVES * 64;
+                if (i < segs) wv[j] = *(const gemm_x8*)(wsrc + (int64_t)i * 8);
             }
-            __syncthreads();
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = f32x4{0, 0, 0, 0};
-#pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const gemm_x8 w = *(const gemm_x8*)(smem + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
-                    // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
-                    acc[c][0][nt] = mfma16_gemm(w, a[0][s], acc[c][0][nt]);
-                    acc[c][1][nt] = mfma16_gemm(w, a[1][s], acc[c][1][nt]);
-                }
-            }
-            // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4);
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    acc[c][mt][nt][0] += b4.x; acc[c][mt][nt][1] += b4.y; acc[c][mt][nt][2] += b4.z; acc[c][mt][nt][3] += b4.w;
-                }
+            for (int j = 0; j < GRP; ++j) {
+                const int i = i0 + j * WAVES * 64;
+                if (i < segs) *(gemm_x8*)(smem + (i / SEGS_PER_ROW) * ROWB + (i % SEGS_PER_ROW) * 16) = wv[j];
             }
         }
+    }
+    __syncthreads();
+
+    const int ntiles = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int ngroups = p.Npad / (NT * 16 * NCH);
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int row0 = tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
+        if (row0 >= p.M) continue;
+        gemm_x8 a[2][KSTEPS];
+        load_a_slab<KSTEPS>(p, row0, lane, a);
+        for (int gch = 0; gch < ngroups; ++gch) {
+            f32x4 acc[NCH][2][NT];
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            const int m = row0 + 16 * mt + r16;
-            epilogue<NT, NCH, EPI>(p, acc, mt, m, m < p.M, gch * NCH * NT * 16, g4);
+            for (int c = 0; c < NCH; ++c) {
+                const int n0 = (gch * NCH + c) * NT * 16;
+                const char* wbase = smem + n0 * ROWB;
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) {
+                        const gemm_x8 w = *(const gemm_x8*)(wbase + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
+                        // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
+                        acc[c][0][nt] = mfma16_gemm(w, a[0][s], acc[c][0][nt]);
+                        acc[c][1][nt] = mfma16_gemm(w, a[1][s], acc[c][1][nt]);
+                    }
+                }
+                // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4);
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt) {
+                        acc[c][mt][nt][0] += b4.x; acc[c][mt][nt][1] += b4.y; acc[c][mt][nt][2] += b4.z; acc[c][mt][nt][3] += b4.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const int m = row0 + 16 * mt + r16;
+                epilogue<NT, NCH, EPI>(p, acc, mt, m, m < p.M, gch * NCH * NT * 16, g4);
+            }
         }
     }
 }
 
+constexpr size_t LDS_BUDGET = 160 * 1024;
+
 template <int KSTEPS, int NT, int NCH, int EPI>
 int launch_one(const GrlLinearArgs& p, hipStream_t st) {
-    const int grid = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
-    const size_t lds = (size_t)NT * 16 * (KSTEPS * 64 + 16);
+    const size_t lds = (size_t)p.Npad * (KSTEPS * 64 + 16);
+    if (lds > LDS_BUDGET) return GRL_ERR_UNSUPPORTED;
+    const int ntiles = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
+    const int per_cu = (int)(LDS_BUDGET / lds) >= 2 ? 2 : 1;  // 8-wave workgroups: at most 2 per CU by VGPRs
+    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
     auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -273,8 +284,8 @@ int launch_one(const GrlLinearArgs& p, hipStream_t st) {
     return 0;
 }
 
-// chunk = NT n-tiles (NT*16 output channels) of weights in LDS; small chunks keep several
-// workgroups resident per CU.  LayerNorm needs the whole row: NCH = Npad / (NT*16) chunks in registers.
+// chunk = NT n-tiles (NT*16 output channels) swept per pass over the A slab; LayerNorm needs the whole
+// row: NCH = Npad / (NT*16) chunks of accumulators in registers.
 template <int KSTEPS>
 int launch_k(const GrlLinearArgs& p, hipStream_t st) {
     const int tiles = p.Npad / 16;
@@ -307,6 +318,34 @@ int launch_k(const GrlLinearArgs& p, hipStream_t st) {
 #undef GRL_LIN_CASE
 }
 
+template <int KSTEPS>
+int launch_split(const GrlLinearArgs& p0, hipStream_t st) {
+    // weight matrices larger than the LDS budget are processed as several column slabs (whole 32-column
+    // groups, so head planes / group norms stay intact); the activations are re-read per slab
+    const size_t rowb = KSTEPS * 64 + 16;
+    int max_rows = (int)(LDS_BUDGET / rowb) / 96 * 96;
+    if (max_rows <= 0) return GRL_ERR_UNSUPPORTED;
+    if ((size_t)p0.Npad * rowb <= LDS_BUDGET) return launch_k<KSTEPS>(p0, st);
+    if (p0.epi == GRL_EPI_LN_RES) return GRL_ERR_UNSUPPORTED;
+    int nslabs = (p0.Npad + max_rows - 1) / max_rows;
+    while (p0.Npad % nslabs || (p0.Npad / nslabs) % 32) ++nslabs;
+    const int ncol = p0.Npad / nslabs;
+    for (int sidx = 0; sidx < nslabs; ++sidx) {
+        GrlLinearArgs p = p0;
+        const int c0 = sidx * ncol;
+        p.Npad = ncol;
+        p.w = (const char*)p0.w + (size_t)c0 * KSTEPS * 32 * 2;
+        p.bias = p0.bias + c0;
+        if (p0.gscale) p.gscale = p0.gscale + c0 / 32;
+        const size_t esz = p0.out_dtype == GRL_DT_F32 ? 4 : 2;
+        if (p0.out_plane_stride > 0) p.out = (char*)p0.out + (size_t)(c0 / 32) * p0.out_plane_stride * esz;
+        else p.out = (char*)p0.out + (size_t)c0 * esz;
+        const int rc = launch_k<KSTEPS>(p, st);
+        if (rc) return rc;
+    }
+    return 0;
+}
+
 }  // namespace
 
 extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
@@ -317,11 +356,11 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.add2_scale != nullptr && p.rows_per_image <= 0) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (p.Kpad / 32) {
-        case 2: return launch_k<2>(p, st);
-        case 4: return launch_k<4>(p, st);
-        case 6: return launch_k<6>(p, st);
-        case 8: return launch_k<8>(p, st);
-        case 12: return launch_k<12>(p, st);
+        case 2: return launch_split<2>(p, st);
+        case 4: return launch_split<4>(p, st);
+        case 6: return launch_split<6>(p, st);
+        case 8: return launch_split<8>(p, st);
+        case 12: return launch_split<12>(p, st);
         default: return GRL_ERR_UNSUPPORTED;
     }
 }
