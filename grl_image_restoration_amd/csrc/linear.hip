@@ -81,7 +81,7 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
 }
 
 // Epilogue of one 16-row m-tile over NCH chunks of NT n-tiles held in registers.
-template <int NT, int NCH, int EPI>
+template <int NT, int NCH, int EPI, bool ADD2>
 __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][2][NT], int mt, int m, bool valid, int n0,
                                          int g4) {
     if constexpr (EPI == GRL_EPI_GROUPNORM) {
@@ -108,7 +108,9 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[0][mt][nt][e] = gelu_erf(acc[0][mt][nt][e]);
     } else if constexpr (EPI == GRL_EPI_LN_RES) {
-        // LayerNorm over the n_real real channels (eps 1e-5), then residual (+ optional gated extra branch)
+        // LayerNorm over the n_real real channels (eps 1e-5), then residual (+ gated extra branch).
+        // Branch-free and batched: out-of-range rows are clamped (only the store is predicated) and the
+        // residual / extra-branch loads of a whole chunk are issued before they are consumed.
         float s1 = 0.f;
 #pragma unroll
         for (int c = 0; c < NCH; ++c)
@@ -132,38 +134,43 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
         s2 += __shfl_xor(s2, 16, 64);
         s2 += __shfl_xor(s2, 32, 64);
         const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
+        const int64_t mc = valid ? m : (int64_t)p.M - 1;
+        const float* rrow = p.resid + mc * p.ldr;
+        const gemm_t* arow = ADD2 ? (const gemm_t*)p.add2 + mc * p.ldadd2 : nullptr;
+        const float* grow = ADD2 ? p.add2_scale + (mc / p.rows_per_image) * p.Npad : nullptr;
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+        for (int c = 0; c < NCH; ++c) {
+            float4 res[NT], gate[NT];
+            gemm_x4 ext[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int col = 16 * (c * NT + nt) + 4 * g4;
+                res[nt] = *(const float4*)(rrow + col);
+                if constexpr (ADD2) {
+                    ext[nt] = *(const gemm_x4*)(arow + col);
+                    gate[nt] = *(const float4*)(grow + col);
+                }
+            }
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 const int col = 16 * (c * NT + nt) + 4 * g4;
                 const float4 g = *(const float4*)(p.ln_g + col);
                 const float4 bb = *(const float4*)(p.ln_b + col);
-                float4 res = float4{0, 0, 0, 0};
-                if (valid) res = *(const float4*)(p.resid + (int64_t)m * p.ldr + col);
                 float y[4];
-                y[0] = res.x + p.res_scale * ((acc[c][mt][nt][0] - mean) * rstd * g.x + bb.x);
-                y[1] = res.y + p.res_scale * ((acc[c][mt][nt][1] - mean) * rstd * g.y + bb.y);
-                y[2] = res.z + p.res_scale * ((acc[c][mt][nt][2] - mean) * rstd * g.z + bb.z);
-                y[3] = res.w + p.res_scale * ((acc[c][mt][nt][3] - mean) * rstd * g.w + bb.w);
-                if (p.add2 != nullptr && valid) {
-                    float t4[4];
-                    if (p.add2_dtype == GRL_DT_F16) {
-                        const gemm_x4 t = *(const gemm_x4*)((const gemm_t*)p.add2 + (int64_t)m * p.ldadd2 + col);
-                        t4[0] = (float)t[0]; t4[1] = (float)t[1]; t4[2] = (float)t[2]; t4[3] = (float)t[3];
-                    } else {
-                        const float4 t = *(const float4*)((const float*)p.add2 + (int64_t)m * p.ldadd2 + col);
-                        t4[0] = t.x; t4[1] = t.y; t4[2] = t.z; t4[3] = t.w;
-                    }
-                    if (p.add2_scale != nullptr) {  // squeeze-excite gate of the CAB branch, per image
-                        const float4 sc = *(const float4*)(p.add2_scale + (int64_t)(m / p.rows_per_image) * p.Npad + col);
-                        t4[0] *= sc.x; t4[1] *= sc.y; t4[2] *= sc.z; t4[3] *= sc.w;
-                    }
-                    y[0] += t4[0]; y[1] += t4[1]; y[2] += t4[2]; y[3] += t4[3];
+                y[0] = res[nt].x + p.res_scale * ((acc[c][mt][nt][0] - mean) * rstd * g.x + bb.x);
+                y[1] = res[nt].y + p.res_scale * ((acc[c][mt][nt][1] - mean) * rstd * g.y + bb.y);
+                y[2] = res[nt].z + p.res_scale * ((acc[c][mt][nt][2] - mean) * rstd * g.z + bb.z);
+                y[3] = res[nt].w + p.res_scale * ((acc[c][mt][nt][3] - mean) * rstd * g.w + bb.w);
+                if constexpr (ADD2) {  // CAB branch times its squeeze-excite gate (per image)
+                    y[0] += (float)ext[nt][0] * gate[nt].x;
+                    y[1] += (float)ext[nt][1] * gate[nt].y;
+                    y[2] += (float)ext[nt][2] * gate[nt].z;
+                    y[3] += (float)ext[nt][3] * gate[nt].w;
                 }
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[c][mt][nt][e] = (col + e) < p.n_real ? y[e] : 0.f;  // keep pad channels 0
             }
+        }
     }
     if (!valid) return;
 #pragma unroll
@@ -192,7 +199,7 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 // (accumulators of NCH chunks are kept when the LayerNorm epilogue needs the whole row), runs the
 // epilogue and stores -- so loads, MFMAs and stores of the 8 waves of a CU overlap freely and the
 // weights are fetched from L2 once per CU instead of once per 128 rows.
-template <int KSTEPS, int NT, int NCH, int EPI>
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2>
 __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KPAD = KSTEPS * 32;
@@ -261,7 +268,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const int m = row0 + 16 * mt + r16;
-                epilogue<NT, NCH, EPI>(p, acc, mt, m, m < p.M, gch * NCH * NT * 16, g4);
+                epilogue<NT, NCH, EPI, ADD2>(p, acc, mt, m, m < p.M, gch * NCH * NT * 16, g4);
             }
         }
     }
@@ -269,14 +276,14 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
 
 constexpr size_t LDS_BUDGET = 160 * 1024;
 
-template <int KSTEPS, int NT, int NCH, int EPI>
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2 = false>
 int launch_one(const GrlLinearArgs& p, hipStream_t st) {
     const size_t lds = (size_t)p.Npad * (KSTEPS * 64 + 16);
     if (lds > LDS_BUDGET) return GRL_ERR_UNSUPPORTED;
     const int ntiles = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int per_cu = (int)(LDS_BUDGET / lds) >= 2 ? 2 : 1;  // 8-wave workgroups: at most 2 per CU by VGPRs
     const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI>;
+    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI, ADD2>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, st, p);
@@ -291,9 +298,9 @@ int launch_k(const GrlLinearArgs& p, hipStream_t st) {
     const int tiles = p.Npad / 16;
     if (p.epi == GRL_EPI_LN_RES) {
         switch (tiles) {
-            case 12: return launch_one<KSTEPS, 6, 2, GRL_EPI_LN_RES>(p, st);
-            case 8: return launch_one<KSTEPS, 4, 2, GRL_EPI_LN_RES>(p, st);
-            case 4: return launch_one<KSTEPS, 4, 1, GRL_EPI_LN_RES>(p, st);
+            case 12: return p.add2 ? launch_one<KSTEPS, 6, 2, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 6, 2, GRL_EPI_LN_RES>(p, st);
+            case 8: return p.add2 ? launch_one<KSTEPS, 4, 2, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 4, 2, GRL_EPI_LN_RES>(p, st);
+            case 4: return p.add2 ? launch_one<KSTEPS, 4, 1, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 4, 1, GRL_EPI_LN_RES>(p, st);
             default: return GRL_ERR_UNSUPPORTED;
         }
     }
@@ -353,7 +360,7 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.M <= 0) return 0;
     if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % 8 != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
-    if (p.add2_scale != nullptr && p.rows_per_image <= 0) return GRL_ERR_BAD_ARG;
+    if (p.add2 != nullptr && (p.add2_dtype != GRL_DT_F16 || p.add2_scale == nullptr || p.rows_per_image <= 0)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     switch (p.Kpad / 32) {
         case 2: return launch_split<2>(p, st);

@@ -90,9 +90,9 @@ def linear(
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
     _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale)
-    assert add2 is None or add2.dtype in (torch.float32, GEMM_DTYPE)
-    if add2_scale is not None:
-        assert add2 is not None and rows_per_image > 0 and add2_scale.dtype == torch.float32 and add2_scale.is_contiguous()
+    if add2 is not None:
+        assert add2.dtype == GEMM_DTYPE and add2_scale is not None and rows_per_image > 0
+        assert add2_scale.dtype == torch.float32 and add2_scale.is_contiguous()
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == GEMM_DTYPE
     assert a.dtype in (torch.float32, GEMM_DTYPE) and bias.dtype == torch.float32
     Npad, Kpad = w.shape

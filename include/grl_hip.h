@@ -56,10 +56,10 @@ typedef struct GrlLinearArgs {
     float res_scale;
     const float* resid;     /* LN_RES: fp32 residual [M, ldr]                                       */
     int64_t ldr;
-    const void* add2;       /* LN_RES: optional extra branch (CAB output) added after the norm      */
-    int32_t add2_dtype;     /*         GRL_DT_F32 or GRL_DT_F16                                     */
+    const void* add2;       /* LN_RES: optional extra branch (CAB output, GRL_DT_F16) added after   */
+    int32_t add2_dtype;     /*         the norm, multiplied by add2_scale (required with add2)      */
     int64_t ldadd2;
-    const float* add2_scale; /* optional [B, Npad] per-image channel scale applied to add2 (SE gate)  */
+    const float* add2_scale; /* [B, Npad] per-image channel scale applied to add2 (SE gate)           */
     int32_t rows_per_image;  /*          image of row m = m / rows_per_image                          */
     void* out;              /* [M, ldo]: GRL_DT_F32, GRL_DT_BF16 (attention operands) or GRL_DT_F16  */
     int32_t out_dtype;

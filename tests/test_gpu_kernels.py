@@ -63,15 +63,18 @@ def test_linear_ln_residual_and_gelu(M, K, N, nreal):
     bet = 0.1 * torch.randn(N, generator=g)
     resid = torch.randn(M, N, generator=g)
     resid[:, nreal:] = 0
-    add2 = torch.randn(M, N, generator=g)
+    add2 = torch.randn(M, N, generator=g).to(torch.float16)   # CAB branch (fp16) ...
     add2[:, nreal:] = 0
+    rpi = 100                                                    # ... gated per image (rows_per_image)
+    gate = torch.rand((M + rpi - 1) // rpi, N, generator=g)
     y = a.double() @ w.double().t() + b.double()
     ln = F.layer_norm(y[:, :nreal], (nreal,), gam[:nreal].double(), bet[:nreal].double(), 1e-5)
     ref = torch.zeros(M, N, dtype=torch.float64)
-    ref[:, :nreal] = resid[:, :nreal].double() + 0.5 * ln + add2[:, :nreal].double()
+    gate_rows = gate[torch.arange(M) // rpi]
+    ref[:, :nreal] = resid[:, :nreal].double() + 0.5 * ln + (add2.float() * gate_rows)[:, :nreal].double()
     d = _dev()
     out = ops.linear(a.to(d), w.to(d), b.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=gam.to(d), ln_b=bet.to(d),
-                     n_real=nreal, res_scale=0.5, resid=resid.to(d), add2=add2.to(d))
+                     n_real=nreal, res_scale=0.5, resid=resid.to(d), add2=add2.to(d), add2_scale=gate.to(d), rows_per_image=rpi)
     assert (out.cpu().double() - ref).abs().max() < 1e-3
     if nreal < N:
         assert out[:, nreal:].abs().max().item() == 0.0
