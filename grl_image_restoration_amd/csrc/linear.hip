@@ -81,9 +81,8 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
 }
 
 // Epilogue of one 16-row m-tile over NCH chunks of NT n-tiles held in registers.
-template <int NT, int NCH, int EPI, bool ADD2>
-__device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][2][NT], int mt, int m, bool valid, int n0,
-                                         int g4) {
+template <int NT, int NCH, int EPI, bool ADD2, int mt>
+__device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][2][NT], int m, bool valid, int n0, int g4) {
     if constexpr (EPI == GRL_EPI_GROUPNORM) {
         // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
         // gscale == 0 marks a pass-through group (v).  F.normalize eps: efficient.py:85.
@@ -138,39 +137,55 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
         const float* rrow = p.resid + mc * p.ldr;
         const gemm_t* arow = ADD2 ? (const gemm_t*)p.add2 + mc * p.ldadd2 : nullptr;
         const float* grow = ADD2 ? p.add2_scale + (mc / p.rows_per_image) * p.Npad : nullptr;
+        constexpr int SB = 4;  // n-tiles per load batch: 4 x (16 + 16 + 8) B per lane in flight, ~40 VGPRs
 #pragma unroll
         for (int c = 0; c < NCH; ++c) {
-            float4 res[NT], gate[NT];
-            gemm_x4 ext[NT];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = 16 * (c * NT + nt) + 4 * g4;
-                res[nt] = *(const float4*)(rrow + col);
-                if constexpr (ADD2) {
-                    ext[nt] = *(const gemm_x4*)(arow + col);
-                    gate[nt] = *(const float4*)(grow + col);
-                }
-            }
+            for (int nb = 0; nb < NT; nb += SB) {
+                // keep the load batches apart: hoisting all of them would need > 256 VGPRs
+                __builtin_amdgcn_sched_barrier(0);
+                float4 res[SB], gate[SB];
+                gemm_x4 ext[SB];
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt) {
-                const int col = 16 * (c * NT + nt) + 4 * g4;
-                const float4 g = *(const float4*)(p.ln_g + col);
-                const float4 bb = *(const float4*)(p.ln_b + col);
-                float y[4];
-                y[0] = res[nt].x + p.res_scale * ((acc[c][mt][nt][0] - mean) * rstd * g.x + bb.x);
-                y[1] = res[nt].y + p.res_scale * ((acc[c][mt][nt][1] - mean) * rstd * g.y + bb.y);
-                y[2] = res[nt].z + p.res_scale * ((acc[c][mt][nt][2] - mean) * rstd * g.z + bb.z);
-                y[3] = res[nt].w + p.res_scale * ((acc[c][mt][nt][3] - mean) * rstd * g.w + bb.w);
-                if constexpr (ADD2) {  // CAB branch times its squeeze-excite gate (per image)
-                    y[0] += (float)ext[nt][0] * gate[nt].x;
-                    y[1] += (float)ext[nt][1] * gate[nt].y;
-                    y[2] += (float)ext[nt][2] * gate[nt].z;
-                    y[3] += (float)ext[nt][3] * gate[nt].w;
+                for (int j = 0; j < SB; ++j) {
+                    if (nb + j < NT) {
+                        const int col = 16 * (c * NT + nb + j) + 4 * g4;
+                        res[j] = *(const float4*)(rrow + col);
+                        if constexpr (ADD2) {
+                            ext[j] = *(const gemm_x4*)(arow + col);
+                            gate[j] = *(const float4*)(grow + col);
+                        }
+                    }
                 }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) acc[c][mt][nt][e] = (col + e) < p.n_real ? y[e] : 0.f;  // keep pad channels 0
+                for (int j = 0; j < SB; ++j) {
+                    if (nb + j < NT) {
+                        const int nt = nb + j;
+                        const int col = 16 * (c * NT + nt) + 4 * g4;
+                        const float4 g = *(const float4*)(p.ln_g + col);
+                        const float4 bb = *(const float4*)(p.ln_b + col);
+                        float y[4];
+                        y[0] = res[j].x + p.res_scale * ((acc[c][mt][nt][0] - mean) * rstd * g.x + bb.x);
+                        y[1] = res[j].y + p.res_scale * ((acc[c][mt][nt][1] - mean) * rstd * g.y + bb.y);
+                        y[2] = res[j].z + p.res_scale * ((acc[c][mt][nt][2] - mean) * rstd * g.z + bb.z);
+                        y[3] = res[j].w + p.res_scale * ((acc[c][mt][nt][3] - mean) * rstd * g.w + bb.w);
+                        if constexpr (ADD2) {  // CAB branch times its squeeze-excite gate (per image)
+                            y[0] += (float)ext[j][0] * gate[j].x;
+                            y[1] += (float)ext[j][1] * gate[j].y;
+                            y[2] += (float)ext[j][2] * gate[j].z;
+                            y[3] += (float)ext[j][3] * gate[j].w;
+                        }
+                        float4 o4;
+                        o4.x = (col + 0) < p.n_real ? y[0] : 0.f;  // keep pad channels 0
+                        o4.y = (col + 1) < p.n_real ? y[1] : 0.f;
+                        o4.z = (col + 2) < p.n_real ? y[2] : 0.f;
+                        o4.w = (col + 3) < p.n_real ? y[3] : 0.f;
+                        if (valid) *(float4*)((float*)p.out + (int64_t)m * p.ldo + n0 + col) = o4;  // LN output is fp32
+                    }
+                }
             }
         }
+        return;
     }
     if (!valid) return;
 #pragma unroll
@@ -235,6 +250,11 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
         if (row0 >= p.M) continue;
         gemm_x8 a[2][KSTEPS];
         load_a_slab<KSTEPS>(p, row0, lane, a);
+        // opaque per-iteration copy of the lane's column group: keeps the compiler from hoisting the
+        // (tile-invariant) bias / gamma / beta / column addresses out of the persistent loop, where
+        // ~150 live address registers force the accumulators into scratch
+        int g4i = g4;
+        asm volatile("" : "+v"(g4i));
         for (int gch = 0; gch < ngroups; ++gch) {
             f32x4 acc[NCH][2][NT];
 #pragma unroll
@@ -258,18 +278,20 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
                 // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
-                    const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4);
+                    const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4i);
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt) {
                         acc[c][mt][nt][0] += b4.x; acc[c][mt][nt][1] += b4.y; acc[c][mt][nt][2] += b4.z; acc[c][mt][nt][3] += b4.w;
                     }
                 }
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) {
-                const int m = row0 + 16 * mt + r16;
-                epilogue<NT, NCH, EPI, ADD2>(p, acc, mt, m, m < p.M, gch * NCH * NT * 16, g4);
-            }
+            // the m-tile index is a template argument: a run-time index would push `acc` into scratch.
+            // sched_barrier: the epilogue's loads must not be hoisted above the MFMA loop (spills)
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue<NT, NCH, EPI, ADD2, 0>(p, acc, row0 + r16, row0 + r16 < p.M, gch * NCH * NT * 16, g4i);
+            __builtin_amdgcn_sched_barrier(0);
+            epilogue<NT, NCH, EPI, ADD2, 1>(p, acc, row0 + 16 + r16, row0 + 16 + r16 < p.M, gch * NCH * NT * 16, g4i);
+            __builtin_amdgcn_sched_barrier(0);
         }
     }
 }
@@ -298,8 +320,8 @@ int launch_k(const GrlLinearArgs& p, hipStream_t st) {
     const int tiles = p.Npad / 16;
     if (p.epi == GRL_EPI_LN_RES) {
         switch (tiles) {
-            case 12: return p.add2 ? launch_one<KSTEPS, 6, 2, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 6, 2, GRL_EPI_LN_RES>(p, st);
-            case 8: return p.add2 ? launch_one<KSTEPS, 4, 2, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 4, 2, GRL_EPI_LN_RES>(p, st);
+            case 12: return p.add2 ? launch_one<KSTEPS, 12, 1, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 12, 1, GRL_EPI_LN_RES>(p, st);
+            case 8: return p.add2 ? launch_one<KSTEPS, 8, 1, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 8, 1, GRL_EPI_LN_RES>(p, st);
             case 4: return p.add2 ? launch_one<KSTEPS, 4, 1, GRL_EPI_LN_RES, true>(p, st) : launch_one<KSTEPS, 4, 1, GRL_EPI_LN_RES>(p, st);
             default: return GRL_ERR_UNSUPPORTED;
         }
