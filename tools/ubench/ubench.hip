@@ -8,6 +8,9 @@ typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
 
 template <int MODE>
 __global__ __launch_bounds__(256) void k(float* out, int iters) {
+    __shared__ float lds[8192 + 64];
+    for (int i = threadIdx.x; i < 8192; i += 256) lds[i] = -1.0f - 0.001f * i;
+    __syncthreads();
     float x[16];
     for (int i = 0; i < 16; ++i) x[i] = -0.001f * (threadIdx.x + i);
     f32x16 acc = {0}, acc2 = {0};
@@ -56,6 +59,30 @@ __global__ __launch_bounds__(256) void k(float* out, int iters) {
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q0, acc2, 0, 0, 0);
             acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, p1, acc, 0, 0, 0);
             acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, q1, acc2, 0, 0, 0);
+        } else if constexpr (MODE == 9 || MODE == 10) {  // mode 7 + the LDS traffic of the real kernel (bias 32 x b32, K/V frags)
+            f32x16 s0, s1;
+            const float* tp0 = lds + ((threadIdx.x * 5 + it * 32) & 4095);
+            const float* tp1 = lds + ((threadIdx.x * 5 + it * 32 + 95) & 4095);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { s0[r] = tp0[(r & 3) + 8 * (r >> 2)]; s1[r] = tp1[(r & 3) + 8 * (r >> 2)]; }
+            bf16x8 ka = a, kb = b;
+            if constexpr (MODE == 10) {
+                ka = *(const bf16x8*)(lds + 4096 + ((threadIdx.x * 16 + it * 64) & 4095));
+                kb = *(const bf16x8*)(lds + 4096 + ((threadIdx.x * 16 + it * 64 + 8) & 4095));
+            }
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, a, s1, 0, 0, 0);
+            s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, b, s0, 0, 0, 0);
+            s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, a, s1, 0, 0, 0);
+            bf16x8 p0, p1, q0, q1;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { p0[i] = (__bf16)__builtin_amdgcn_exp2f(s0[i]); p1[i] = (__bf16)__builtin_amdgcn_exp2f(s0[8 + i]); }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { q0[i] = (__bf16)__builtin_amdgcn_exp2f(s1[i]); q1[i] = (__bf16)__builtin_amdgcn_exp2f(s1[8 + i]); }
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, p0, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, q0, acc2, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, p1, acc, 0, 0, 0);
+            acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, q1, acc2, 0, 0, 0);
         } else if constexpr (MODE == 8) {  // like 3 without exp: fma instead
             f32x16 s = {0};
             s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, s, 0, 0, 0);
@@ -113,6 +140,8 @@ int main() {
         run<6>("indep 4mfma || 32fma", w, 1);
         run<7>("attn 2 tiles: 8mfma+32exp+16cvt", w, 1);
         run<8>("attn-like fma: 4mfma+16fma+8cvt", w, 1);
+        run<9>("attn 2 tiles + 32 bias LDS reads", w, 1);
+        run<10>("attn 2 tiles + bias + frag LDS reads", w, 1);
     }
     return 0;
 }
