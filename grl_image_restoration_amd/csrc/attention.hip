@@ -377,9 +377,9 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
     }
 
-    f32x16 HA, HB;  // bias fragments carried across key rows (PIPE == 2)
+    f32x16 HA, HB, H1, H2, H3;  // bias fragments carried across key rows (PIPE == 2: HA/HB, PIPE == 3: ring HA,H1,H2,H3)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { HA[r] = 0.f; HB[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { HA[r] = 0.f; HB[r] = 0.f; H1[r] = 0.f; H2[r] = 0.f; H3[r] = 0.f; }
     const int kseg = p.k.ww >> 5;
     const int nrc = p.k.wh / FROWS;  // chunks per strip
     const int nch = kseg * nrc;
@@ -548,6 +548,80 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 gather(0, hk0 + kt + 1, HB);              // HB (tile 1 @ row kt) is consumed
                 pair(kf, vf, HB, HA, ids);                // tile 1 @ row kt+1 == tile 0 @ row kt
             }
+        } else if constexpr (PIPE == 3) {
+            // Fragment ring for four query tiles per wave: fragment(tile t, key row hk) = fragment(tile 0,
+            // row hk - t).  Tile 0's gather at row hk lands in ring[(-hk) & 3]; tile t reads ring[(t - hk) & 3].
+            // A strip's first row gathers all four, every other row gathers one: 4x fewer LDS bias reads and
+            // K / V^T fragments shared by four tiles.
+            static_assert(QTN == 4 || PIPE != 3, "ring reuse is written for four query tiles per wave");
+            auto frags = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], uint32_t (&ids)[4]) {
+                const int kb = kt * 32;
+                const int kk = kb + l31;
+                const int sw = (kk >> 2) & 3;
+                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
+                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
+                    const bf16x4 lo = *(const bf16x4*)(vp);
+                    const bf16x4 hi = *(const bf16x4*)(vp + 16);
+                    vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+                if (border) {
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
+                }
+            };
+            auto gather = [&](int t, int hk, f32x16& dst) {
+                const float* tp = tab + (Ub[t] + hk * D + 32 * sk);
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dst[r] = tp[(r & 3) + 8 * (r >> 2)];
+            };
+            auto two = [&](int t0, bf16x8 (&kf)[2], bf16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
+                f32x16 S[2];
+                S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t0][0], C0, 0, 0, 0);
+                S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t0 + 1][0], C1, 0, 0, 0);
+                S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t0][1], S[0], 0, 0, 0);
+                S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t0 + 1][1], S[1], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    if (border) {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
+                            S[u][r] += idk != idq[t0 + u] ? MASK_L2 : 0.f;
+                        }
+                    }
+                    bf16x8 pb[2];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[u][r]);
+                    O[t0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t0 + u], 0, 0, 0);
+                    O[t0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t0 + u], 0, 0, 0);
+                }
+            };
+#define GRL_RING_ROW(J, R0, R1, R2, R3)                                                        \
+    {                                                                                          \
+        bf16x8 kf[2], vf[2];                                                                   \
+        uint32_t ids[4] = {0, 0, 0, 0};                                                        \
+        frags(kt + J, kf, vf, ids);                                                            \
+        gather(0, hk0 + kt + J, R0);                                                           \
+        two(0, kf, vf, R0, R1, ids);                                                           \
+        two(2, kf, vf, R2, R3, ids);                                                           \
+    }
+#pragma unroll 1
+            for (int kt = 0; kt < FROWS; kt += 4) {
+                if (hk0 + kt == 0) {  // strip start: rows -1..-3 do not exist, gather tiles 1..3 for row 0
+                    gather(1, 0, H1);
+                    gather(2, 0, H2);
+                    gather(3, 0, H3);
+                }
+                // row j: tile t reads ring[(t - j) & 3]; the new fragment goes to ring[(-j) & 3]
+                GRL_RING_ROW(0, HA, H1, H2, H3)
+                GRL_RING_ROW(1, H3, HA, H1, H2)
+                GRL_RING_ROW(2, H2, H3, HA, H1)
+                GRL_RING_ROW(3, H1, H2, H3, HA)
+            }
+#undef GRL_RING_ROW
         } else if constexpr (PIPE == 1) {
             // two register sets (A, B): while one key tile is in the matrix core the next one's LDS reads are in flight
             bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
@@ -634,6 +708,7 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     if (variant == 2) return launch_fast_v<4, 2, 4, 3, 0>(p, st);   // 3 workgroups per CU
     if (variant == 3 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 0>(p, st);
     if (variant == 4) return launch_fast_v<4, 2, 8, 2, 1>(p, st);
+    if (variant == 5 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 3>(p, st);   // 4-tile fragment ring
     return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // bias-fragment reuse
 }
 
