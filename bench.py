@@ -131,7 +131,8 @@ def main():
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "attention_traffic.json")
         if os.path.isfile(tpath):
-            traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+            traffic = json.load(open(tpath)).get("hbm_bytes_per_tile")  # PMC pass (profiles/), per tile
+            traffic = traffic * args.tiles if traffic else None
         line = {
             "metric": "LQ megapixels/s, GRL-Base x4 SR, 256x256 LQ tiles",
             "value": round(mp, 4),
