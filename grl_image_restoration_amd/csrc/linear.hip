@@ -21,18 +21,20 @@
 //     LayerNorm + residual (+ the CAB branch) so no intermediate goes back to HBM.
 #include "common.h"
 #include "grl_hip_internal.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int WAVES = 8;             // 512 threads = 2 waves per SIMD; one persistent workgroup per CU (two if LDS allows)
-constexpr int ROWS_PER_WAVE = 32;    // 2 MFMA m-tiles
-constexpr int ROWS_PER_WG = WAVES * ROWS_PER_WAVE;
+// Workgroup shapes: MT m-tiles (16 token rows each) per wave, WV waves per workgroup.
+//   MT = 2, WV = 8  : 256 rows / workgroup, weight fragments shared by two m-tiles, <= 256 VGPRs
+//   MT = 1, WV = 16 : 256 rows / workgroup, <= 128 VGPRs -> 4 waves per SIMD hide the load / epilogue latency
+//                     of these HBM-bound layers better (measured), at twice the LDS fragment reads per MFMA
 
-template <int KSTEPS>
-__device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, int lane, gemm_x8 (&a)[2][KSTEPS]) {
+template <int KSTEPS, int MT>
+__device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, int lane, gemm_x8 (&a)[MT][KSTEPS]) {
     const int r = lane & 15, kg = lane >> 4;
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+    for (int mt = 0; mt < MT; ++mt) {
         int m = row0 + 16 * mt + r;
         const bool valid = m < p.M;
         if (!valid) m = p.M - 1;
@@ -81,8 +83,8 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
 }
 
 // Epilogue of one 16-row m-tile over NCH chunks of NT n-tiles held in registers.
-template <int NT, int NCH, int EPI, bool ADD2, int mt>
-__device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][2][NT], int m, bool valid, int n0, int g4) {
+template <int NT, int NCH, int MT, int EPI, bool ADD2, int mt>
+__device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][MT][NT], int m, bool valid, int n0, int g4) {
     if constexpr (EPI == GRL_EPI_GROUPNORM) {
         // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
         // gscale == 0 marks a pass-through group (v).  F.normalize eps: efficient.py:85.
@@ -214,8 +216,9 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 // (accumulators of NCH chunks are kept when the LayerNorm epilogue needs the whole row), runs the
 // epilogue and stores -- so loads, MFMAs and stores of the 8 waves of a CU overlap freely and the
 // weights are fetched from L2 once per CU instead of once per 128 rows.
-template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2>
-__global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2, int MT, int WV>
+__global__ __launch_bounds__(WV * 64) void linear_kernel(GrlLinearArgs p) {
+    constexpr int WAVES = WV, ROWS_PER_WAVE = 16 * MT, ROWS_PER_WG = WV * 16 * MT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KPAD = KSTEPS * 32;
     constexpr int ROWB = KPAD * 2 + 16;  // padded LDS row (bytes)
@@ -248,21 +251,21 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int row0 = tile * ROWS_PER_WG + wave * ROWS_PER_WAVE;
         if (row0 >= p.M) continue;
-        gemm_x8 a[2][KSTEPS];
-        load_a_slab<KSTEPS>(p, row0, lane, a);
+        gemm_x8 a[MT][KSTEPS];
+        load_a_slab<KSTEPS, MT>(p, row0, lane, a);
         // opaque per-iteration copy of the lane's column group: keeps the compiler from hoisting the
         // (tile-invariant) bias / gamma / beta / column addresses out of the persistent loop, where
         // ~150 live address registers force the accumulators into scratch
         int g4i = g4;
         asm volatile("" : "+v"(g4i));
         for (int gch = 0; gch < ngroups; ++gch) {
-            f32x4 acc[NCH][2][NT];
+            f32x4 acc[NCH][MT][NT];
 #pragma unroll
             for (int c = 0; c < NCH; ++c) {
                 const int n0 = (gch * NCH + c) * NT * 16;
                 const char* wbase = smem + n0 * ROWB;
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
+                for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                     for (int nt = 0; nt < NT; ++nt) acc[c][mt][nt] = f32x4{0, 0, 0, 0};
 #pragma unroll
@@ -271,8 +274,8 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
                     for (int nt = 0; nt < NT; ++nt) {
                         const gemm_x8 w = *(const gemm_x8*)(wbase + (nt * 16 + r16) * ROWB + (32 * s + 8 * g4) * 2);
                         // D^T tile: rows = output channel (A operand = W), cols = token (B operand = A slab)
-                        acc[c][0][nt] = mfma16_gemm(w, a[0][s], acc[c][0][nt]);
-                        acc[c][1][nt] = mfma16_gemm(w, a[1][s], acc[c][1][nt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) acc[c][mt][nt] = mfma16_gemm(w, a[mt][s], acc[c][mt][nt]);
                     }
                 }
                 // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16
@@ -280,7 +283,7 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4i);
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
+                    for (int mt = 0; mt < MT; ++mt) {
                         acc[c][mt][nt][0] += b4.x; acc[c][mt][nt][1] += b4.y; acc[c][mt][nt][2] += b4.z; acc[c][mt][nt][3] += b4.w;
                     }
                 }
@@ -288,29 +291,38 @@ __global__ __launch_bounds__(WAVES * 64) void linear_kernel(GrlLinearArgs p) {
             // the m-tile index is a template argument: a run-time index would push `acc` into scratch.
             // sched_barrier: the epilogue's loads must not be hoisted above the MFMA loop (spills)
             __builtin_amdgcn_sched_barrier(0);
-            epilogue<NT, NCH, EPI, ADD2, 0>(p, acc, row0 + r16, row0 + r16 < p.M, gch * NCH * NT * 16, g4i);
+            epilogue<NT, NCH, MT, EPI, ADD2, 0>(p, acc, row0 + r16, row0 + r16 < p.M, gch * NCH * NT * 16, g4i);
             __builtin_amdgcn_sched_barrier(0);
-            epilogue<NT, NCH, EPI, ADD2, 1>(p, acc, row0 + 16 + r16, row0 + 16 + r16 < p.M, gch * NCH * NT * 16, g4i);
-            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (MT == 2) {
+                epilogue<NT, NCH, MT, EPI, ADD2, 1>(p, acc, row0 + 16 + r16, row0 + 16 + r16 < p.M, gch * NCH * NT * 16, g4i);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
     }
 }
 
 constexpr size_t LDS_BUDGET = 160 * 1024;
 
-template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2 = false>
-int launch_one(const GrlLinearArgs& p, hipStream_t st) {
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2, int MT, int WV>
+int launch_shape(const GrlLinearArgs& p, hipStream_t st) {
+    constexpr int ROWS_PER_WG = WV * 16 * MT;
     const size_t lds = (size_t)p.Npad * (KSTEPS * 64 + 16);
     if (lds > LDS_BUDGET) return GRL_ERR_UNSUPPORTED;
     const int ntiles = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
-    const int per_cu = (int)(LDS_BUDGET / lds) >= 2 ? 2 : 1;  // 8-wave workgroups: at most 2 per CU by VGPRs
-    const int grid = ntiles < 256 * per_cu ? ntiles : 256 * per_cu;
-    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI, ADD2>;
+    const int grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU
+    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI, ADD2, MT, WV>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WAVES * 64), lds, st, p);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WV * 64), lds, st, p);
     GRL_CHECK_LAUNCH();
     return 0;
+}
+
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2 = false>
+int launch_one(const GrlLinearArgs& p, hipStream_t st) {
+    static const int shape = getenv("GRL_LINEAR_SHAPE") ? atoi(getenv("GRL_LINEAR_SHAPE")) : 1;
+    if (shape == 0) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 2, 8>(p, st);
+    return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
 }
 
 // chunk = NT n-tiles (NT*16 output channels) swept per pass over the A slab; LayerNorm needs the whole
