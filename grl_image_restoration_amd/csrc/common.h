@@ -57,7 +57,21 @@ __device__ __forceinline__ uint32_t pack16(float lo, float hi, int kind) {
 // exchange with the lane 32 apart (both halves of a wave64)
 __device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
 
-__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// exact-GELU x*Phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32
+// round-off level; the reference uses torch's erf-GELU, swin_v1_block.py:23,38).  ~14 VALU ops with two
+// quarter-rate transcendentals instead of libm erff's ~40: the fc1 epilogue is VALU-bound otherwise.
+__device__ __forceinline__ float gelu_erf(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * LOG2E_F);
+    const float erf_abs = 1.0f - poly * t * e;
+    const float erf_x = copysignf(erf_abs, x);
+    return 0.5f * x * (1.0f + erf_x);
+}
 
 // sum over the 16 lanes that share (lane >> 4)
 __device__ __forceinline__ float row16_sum(float v) {

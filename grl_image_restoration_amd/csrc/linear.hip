@@ -320,8 +320,12 @@ int launch_shape(const GrlLinearArgs& p, hipStream_t st) {
 
 template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2 = false>
 int launch_one(const GrlLinearArgs& p, hipStream_t st) {
-    static const int shape = getenv("GRL_LINEAR_SHAPE") ? atoi(getenv("GRL_LINEAR_SHAPE")) : 1;
+    static const int shape = getenv("GRL_LINEAR_SHAPE") ? atoi(getenv("GRL_LINEAR_SHAPE")) : -1;
     if (shape == 0) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 2, 8>(p, st);
+    if (shape == 1) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
+    if (shape == 2) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
+    // default: LayerNorm epilogues need ~150 VGPRs -> 12 waves (3 per SIMD); the others fit 16 waves
+    if constexpr (EPI == GRL_EPI_LN_RES) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
     return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
 }
 
