@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -126,6 +126,7 @@ class GrlConvArgs(_Strict):
         ("resid", C.c_void_p),
         ("ldr", C.c_int64),
         ("pool_partial", C.c_void_p),
+        ("pool_stride", C.c_int64),
         ("out", C.c_void_p),
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),

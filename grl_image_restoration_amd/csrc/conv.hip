@@ -19,6 +19,7 @@
 // optional pixel-shuffle store.
 #include "common.h"
 #include "grl_hip_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -26,7 +27,9 @@ constexpr int TH = 8, TW = 32;       // output tile (pixels); wave w owns tile r
 constexpr int CWAVES = 8;
 constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 
-template <int KC, int NT>
+// ALLTAPS: the weight slices of all 9 taps of the current channel chunk are resident in LDS (9*NT*16 rows),
+// so a chunk costs two barriers instead of ten -- used whenever they fit (narrow outputs: CAB convs, tail).
+template <int KC, int NT, bool ALLTAPS>
 __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = KC * 2 + 16;                 // padded row (bytes) for pixels and weight rows
@@ -73,10 +76,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
         }
     };
 
-    for (int kc = 0; kc < nkc; ++kc) {
-        load_w(0, kc);
-        __syncthreads();  // previous chunk's readers are done with in_s / wt_s
-        // ---- stage the halo tile of this channel chunk as bf16 ----
+    auto stage_input = [&](int kc) {
 #pragma unroll 2
         for (int s = tid; s < HALO_H * HALO_W * SEG_ROW; s += CWAVES * 64) {
             const int pix = s / SEG_ROW, cc = s % SEG_ROW;
@@ -96,31 +96,70 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             }
             *(gemm_x8*)(in_s + pix * ROWB + cc * 16) = v;
         }
-        store_w(0);
-        __syncthreads();
+    };
+    auto mfma_tap = [&](int tap, const char* wb) {
+        const int dy = tap / 3, dx = tap - dy * 3;
+        gemm_x8 af[2][KS];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks)
+                af[mt][ks] = *(const gemm_x8*)(in_s + ((wave + dy) * HALO_W + (16 * mt + r16 + dx)) * ROWB + (32 * ks + 8 * g4) * 2);
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const gemm_x8 wf = *(const gemm_x8*)(wb + (nt * 16 + r16) * ROWB + (32 * ks + 8 * g4) * 2);
+                acc[0][nt] = mfma16_gemm(wf, af[0][ks], acc[0][nt]);
+                acc[1][nt] = mfma16_gemm(wf, af[1][ks], acc[1][nt]);
+            }
+        }
+    };
 
-        for (int tap = 0; tap < 9; ++tap) {
-            if (tap < 8) load_w(tap + 1, kc);  // in flight during the MFMAs below
-            const int dy = tap / 3, dx = tap - dy * 3;
-            const char* wb = wt_s + (tap & 1) * WT_BYTES;
-            gemm_x8 af[2][KS];
+    if constexpr (ALLTAPS) {
+        constexpr int ASEGS = 9 * WSEGS;
+        constexpr int GRP = 4;
+        for (int kc = 0; kc < nkc; ++kc) {
+            __syncthreads();  // previous chunk's readers are done
+            stage_input(kc);
+            for (int i0 = tid; i0 < ASEGS; i0 += GRP * CWAVES * 64) {
+                gemm_x8 wv[GRP];
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
+                for (int j = 0; j < GRP; ++j) {
+                    const int i = i0 + j * CWAVES * 64;
+                    if (i < ASEGS) {
+                        const int tap = i / WSEGS, r = i % WSEGS;
+                        wv[j] = *(const gemm_x8*)((const gemm_t*)p.w + (int64_t)tap * p.w_tap_stride + (int64_t)(r / SEG_ROW) * p.CinP +
+                                                  kc * KC + (r % SEG_ROW) * 8);
+                    }
+                }
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks)
-                    af[mt][ks] = *(const gemm_x8*)(in_s + ((wave + dy) * HALO_W + (16 * mt + r16 + dx)) * ROWB + (32 * ks + 8 * g4) * 2);
-#pragma unroll
-            for (int ks = 0; ks < KS; ++ks) {
-#pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    const gemm_x8 wf = *(const gemm_x8*)(wb + (nt * 16 + r16) * ROWB + (32 * ks + 8 * g4) * 2);
-                    acc[0][nt] = mfma16_gemm(wf, af[0][ks], acc[0][nt]);
-                    acc[1][nt] = mfma16_gemm(wf, af[1][ks], acc[1][nt]);
+                for (int j = 0; j < GRP; ++j) {
+                    const int i = i0 + j * CWAVES * 64;
+                    if (i < ASEGS) {
+                        const int tap = i / WSEGS, r = i % WSEGS;
+                        *(gemm_x8*)(wt_s + tap * WT_BYTES + (r / SEG_ROW) * ROWB + (r % SEG_ROW) * 16) = wv[j];
+                    }
                 }
             }
-            if (tap < 8) {
-                store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
-                __syncthreads();
+            __syncthreads();
+#pragma unroll
+            for (int tap = 0; tap < 9; ++tap) mfma_tap(tap, wt_s + tap * WT_BYTES);
+        }
+    } else {
+        for (int kc = 0; kc < nkc; ++kc) {
+            load_w(0, kc);
+            __syncthreads();  // previous chunk's readers are done with in_s / wt_s
+            stage_input(kc);
+            store_w(0);
+            __syncthreads();
+            for (int tap = 0; tap < 9; ++tap) {
+                if (tap < 8) load_w(tap + 1, kc);  // in flight during the MFMAs below
+                mfma_tap(tap, wt_s + (tap & 1) * WT_BYTES);
+                if (tap < 8) {
+                    store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
+                    __syncthreads();
+                }
             }
         }
     }
@@ -203,7 +242,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             float s = 0.f;
 #pragma unroll
             for (int w = 0; w < CWAVES; ++w) s += red[w * (NT * 16) + c];
-            p.pool_partial[(int64_t)wg * p.CoutP + c] = s;
+            p.pool_partial[(int64_t)wg * p.pool_stride + c] = s;
         }
     }
 }
@@ -211,11 +250,22 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
 template <int KC, int NT>
 int launch_conv(const GrlConvArgs& p, hipStream_t st) {
     const dim3 grid((p.W + TW - 1) / TW, (p.H + TH - 1) / TH, p.B);
-    const size_t lds = (size_t)HALO_H * HALO_W * (KC * 2 + 16) + 2 * (size_t)NT * 16 * (KC * 2 + 16);
-    auto kfn = conv3x3_kernel<KC, NT>;
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
+    const size_t rowb = KC * 2 + 16;
+    const size_t lds_in = (size_t)HALO_H * HALO_W * rowb;
+    const size_t lds_all = lds_in + 9 * (size_t)NT * 16 * rowb;
+    hipError_t e;
+    if (lds_all <= 160 * 1024 && !getenv("GRL_CONV_PERTAP")) {
+        auto kfn = conv3x3_kernel<KC, NT, true>;
+        e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds_all, st, p);
+    } else {
+        const size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
+        auto kfn = conv3x3_kernel<KC, NT, false>;
+        e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
+    }
     GRL_CHECK_LAUNCH();
     return 0;
 }
@@ -293,6 +343,7 @@ extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     const GrlConvArgs& p = *args;
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return GRL_ERR_BAD_ARG;
     if (p.CinP % 32 || p.CoutP % 16 || p.CoutP > 192 || (p.ldx % 8) || (p.ldo % 4)) return GRL_ERR_BAD_ARG;
+    if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;
     if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (p.CinP % 64 == 0) return launch_conv_nt<64>(p, st);

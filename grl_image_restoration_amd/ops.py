@@ -248,11 +248,13 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     if want_pool:
         nwg = lib.grl_conv3x3_num_workgroups(B, H, W)
         pool = torch.empty(nwg, CoutP, dtype=torch.float32, device=x.device)
-    # at most 192 output channels per launch; larger layers are split on the channel axis
+    # at most 192 output channels per launch; larger layers are split on the channel axis.  Layers with a
+    # cheap input (<= 64 channels) are computed as 64-channel output slabs: then all nine taps of a
+    # slab's weights stay resident in LDS (kernel's ALLTAPS mode) and the input is simply re-read.
     step = CoutP
-    if CoutP > 192:
-        step = max(s for s in (192, 128, 96, 64, 48, 32, 16) if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0))
-        assert not want_pool
+    if CoutP > 192 or (CoutP > 64 and CinP <= 64 and CoutP % 64 == 0 and (shuffle_r <= 1 or 64 % shuffle_cg == 0)):
+        step = max(s for s in (192, 128, 96, 64, 48, 32, 16)
+                   if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0) and (CinP > 64 or s <= 64))
     for c0 in range(0, CoutP, step):
         args = L.GrlConvArgs(
             x=_ptr(x), x_dtype=_KIND[x.dtype], ldx=x.stride(0),
@@ -261,7 +263,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             B=B, H=H, W=W, CinP=CinP, CoutP=step, act=act, slope=slope,
             resid=C.c_void_p(resid.data_ptr() + c0 * 4) if resid is not None else C.c_void_p(0),
             ldr=resid.stride(0) if resid is not None else 0,
-            pool_partial=_ptr(pool),
+            pool_partial=C.c_void_p(pool.data_ptr() + c0 * 4) if pool is not None else C.c_void_p(0), pool_stride=CoutP,
             out=C.c_void_p(out.data_ptr() + (0 if shuffle_r > 1 else c0 * out.element_size())),
             out_dtype=_KIND[out.dtype], ldo=out.stride(0),
             shuffle_r=shuffle_r, shuffle_cg=shuffle_cg, shuffle_ij0=(c0 // shuffle_cg if shuffle_r > 1 else 0),

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 5
+#define GRL_ABI_VERSION 6
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -136,8 +136,10 @@ typedef struct GrlConvArgs {
     float slope;
     const float* resid;     /* optional fp32 [B*H*W, ldr] added after the activation                */
     int64_t ldr;
-    float* pool_partial;    /* optional [grl_conv3x3_num_workgroups(B,H,W), CoutP]: per-workgroup    */
-                            /* channel sums of the output (two-stage global average pool)           */
+    float* pool_partial;    /* optional [grl_conv3x3_num_workgroups(B,H,W), pool_stride]: per-       */
+                            /* workgroup channel sums of the output (two-stage global average pool) */
+    int64_t pool_stride;    /* floats per workgroup row (>= CoutP; the full layer's channel count    */
+                            /* when the layer is computed as several output-channel slabs)          */
     void* out;              /* [rows, ldo] GRL_DT_F32 or GRL_DT_F16                                 */
     int32_t out_dtype;
     int64_t ldo;
