@@ -28,7 +28,9 @@ constexpr int CWAVES = 8;
 constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 
 // ALLTAPS: the weight slices of all 9 taps of the current channel chunk are resident in LDS (9*NT*16 rows),
-// so a chunk costs two barriers instead of ten -- used whenever they fit (narrow outputs: CAB convs, tail).
+// so a chunk costs two barriers instead of ten.  Measured on MI355X (CAB convs): 25-35 % SLOWER than the
+// per-tap double buffer because the larger LDS footprint leaves one workgroup per CU; kept as an opt-in
+// (GRL_CONV_ALLTAPS=1) experiment.
 template <int KC, int NT, bool ALLTAPS>
 __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -254,7 +256,7 @@ int launch_conv(const GrlConvArgs& p, hipStream_t st) {
     const size_t lds_in = (size_t)HALO_H * HALO_W * rowb;
     const size_t lds_all = lds_in + 9 * (size_t)NT * 16 * rowb;
     hipError_t e;
-    if (lds_all <= 160 * 1024 && !getenv("GRL_CONV_PERTAP")) {
+    if (lds_all <= 160 * 1024 && getenv("GRL_CONV_ALLTAPS")) {  // measured slower (1 workgroup/CU): opt-in only
         auto kfn = conv3x3_kernel<KC, NT, true>;
         e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) return (int)e;

@@ -248,13 +248,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     if want_pool:
         nwg = lib.grl_conv3x3_num_workgroups(B, H, W)
         pool = torch.empty(nwg, CoutP, dtype=torch.float32, device=x.device)
-    # at most 192 output channels per launch; larger layers are split on the channel axis.  Layers with a
-    # cheap input (<= 64 channels) are computed as 64-channel output slabs: then all nine taps of a
-    # slab's weights stay resident in LDS (kernel's ALLTAPS mode) and the input is simply re-read.
+    # at most 192 output channels per launch; larger layers are split on the channel axis
     step = CoutP
-    if CoutP > 192 or (CoutP > 64 and CinP <= 64 and CoutP % 64 == 0 and (shuffle_r <= 1 or 64 % shuffle_cg == 0)):
-        step = max(s for s in (192, 128, 96, 64, 48, 32, 16)
-                   if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0) and (CinP > 64 or s <= 64))
+    if CoutP > 192:
+        step = max(s for s in (192, 128, 96, 64, 48, 32, 16) if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0))
     for c0 in range(0, CoutP, step):
         args = L.GrlConvArgs(
             x=_ptr(x), x_dtype=_KIND[x.dtype], ldx=x.stride(0),
