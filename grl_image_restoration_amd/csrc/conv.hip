@@ -31,7 +31,7 @@ constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 // so a chunk costs two barriers instead of ten.  Measured on MI355X (CAB convs): 25-35 % SLOWER than the
 // per-tap double buffer because the larger LDS footprint leaves one workgroup per CU; kept as an opt-in
 // (GRL_CONV_ALLTAPS=1) experiment.
-template <int KC, int NT, bool ALLTAPS, bool OUT16>
+template <int KC, int NT, bool ALLTAPS>
 __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = KC * 2 + 16;                 // padded row (bytes) for pixels and weight rows
@@ -219,7 +219,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                     *(uint2*)((gemm_t*)p.out + orow * p.ldo + oc) = pk;
                 } else {
                     *(float4*)((float*)p.out + orow * p.ldo + oc) = float4{v[0], v[1], v[2], v[3]};
-                    if constexpr (OUT16) {  // fp16 shadow of an fp32 output (residual stream)
+                    if (p.out16 != nullptr) {  // fp16 shadow of an fp32 output (residual stream)
                         uint2 pk;
                         pk.x = pack_f16(v[0], v[1]);
                         pk.y = pack_f16(v[2], v[3]);
@@ -263,25 +263,16 @@ int launch_conv(const GrlConvArgs& p, hipStream_t st) {
     const size_t lds_all = lds_in + 9 * (size_t)NT * 16 * rowb;
     hipError_t e;
     if (lds_all <= 160 * 1024 && getenv("GRL_CONV_ALLTAPS")) {  // measured slower (1 workgroup/CU): opt-in only
-        auto kfn = conv3x3_kernel<KC, NT, true, false>;
-        if (p.out16) return GRL_ERR_UNSUPPORTED;
+        auto kfn = conv3x3_kernel<KC, NT, true>;
         e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds_all, st, p);
     } else {
         const size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
-        if (p.out16 != nullptr && p.out_dtype == GRL_DT_F32 && p.shuffle_r <= 1) {
-            auto kfn = conv3x3_kernel<KC, NT, false, true>;
-            e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
-        } else {
-            if (p.out16 != nullptr) return GRL_ERR_BAD_ARG;
-            auto kfn = conv3x3_kernel<KC, NT, false, false>;
-            e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            if (e != hipSuccess) return (int)e;
-            hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
-        }
+        auto kfn = conv3x3_kernel<KC, NT, false>;
+        e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
     }
     GRL_CHECK_LAUNCH();
     return 0;

@@ -83,7 +83,7 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
 }
 
 // Epilogue of one 16-row m-tile over NCH chunks of NT n-tiles held in registers.
-template <int NT, int NCH, int MT, int EPI, bool ADD2, bool OUT16, int mt>
+template <int NT, int NCH, int MT, int EPI, bool ADD2, int mt>
 __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][MT][NT], int m, bool valid, int n0, int g4) {
     if constexpr (EPI == GRL_EPI_GROUPNORM) {
         // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
@@ -184,7 +184,7 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
                         o4.w = (col + 3) < p.n_real ? y[3] : 0.f;
                         if (valid) {
                             *(float4*)((float*)p.out + (int64_t)m * p.ldo + n0 + col) = o4;  // LN output is fp32
-                            if constexpr (OUT16) {  // fp16 shadow for the next GEMM / conv consumers
+                            if (p.out16 != nullptr) {  // fp16 shadow for the next GEMM / conv consumers
                                 uint2 pk;
                                 pk.x = pack_f16(o4.x, o4.y);
                                 pk.y = pack_f16(o4.z, o4.w);
@@ -224,7 +224,7 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 // (accumulators of NCH chunks are kept when the LayerNorm epilogue needs the whole row), runs the
 // epilogue and stores -- so loads, MFMAs and stores of the 8 waves of a CU overlap freely and the
 // weights are fetched from L2 once per CU instead of once per 128 rows.
-template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2, bool OUT16, int MT, int WV>
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2, int MT, int WV>
 __global__ __launch_bounds__(WV * 64) void linear_kernel(GrlLinearArgs p) {
     constexpr int WAVES = WV, ROWS_PER_WAVE = 16 * MT, ROWS_PER_WG = WV * 16 * MT;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -299,10 +299,10 @@ __global__ __launch_bounds__(WV * 64) void linear_kernel(GrlLinearArgs p) {
             // the m-tile index is a template argument: a run-time index would push `acc` into scratch.
             // sched_barrier: the epilogue's loads must not be hoisted above the MFMA loop (spills)
             __builtin_amdgcn_sched_barrier(0);
-            epilogue<NT, NCH, MT, EPI, ADD2, OUT16, 0>(p, acc, row0 + r16, row0 + r16 < p.M, gch * NCH * NT * 16, g4i);
+            epilogue<NT, NCH, MT, EPI, ADD2, 0>(p, acc, row0 + r16, row0 + r16 < p.M, gch * NCH * NT * 16, g4i);
             __builtin_amdgcn_sched_barrier(0);
             if constexpr (MT == 2) {
-                epilogue<NT, NCH, MT, EPI, ADD2, OUT16, 1>(p, acc, row0 + 16 + r16, row0 + 16 + r16 < p.M, gch * NCH * NT * 16, g4i);
+                epilogue<NT, NCH, MT, EPI, ADD2, 1>(p, acc, row0 + 16 + r16, row0 + 16 + r16 < p.M, gch * NCH * NT * 16, g4i);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -311,14 +311,14 @@ __global__ __launch_bounds__(WV * 64) void linear_kernel(GrlLinearArgs p) {
 
 constexpr size_t LDS_BUDGET = 160 * 1024;
 
-template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2, bool OUT16, int MT, int WV>
+template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2, int MT, int WV>
 int launch_shape(const GrlLinearArgs& p, hipStream_t st) {
     constexpr int ROWS_PER_WG = WV * 16 * MT;
     const size_t lds = (size_t)p.Npad * (KSTEPS * 64 + 16);
     if (lds > LDS_BUDGET) return GRL_ERR_UNSUPPORTED;
     const int ntiles = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
     const int grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU
-    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI, ADD2, OUT16, MT, WV>;
+    auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI, ADD2, MT, WV>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WV * 64), lds, st, p);
@@ -329,18 +329,12 @@ int launch_shape(const GrlLinearArgs& p, hipStream_t st) {
 template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2 = false>
 int launch_one(const GrlLinearArgs& p, hipStream_t st) {
     static const int shape = getenv("GRL_LINEAR_SHAPE") ? atoi(getenv("GRL_LINEAR_SHAPE")) : -1;
-    if constexpr (EPI == GRL_EPI_LN_RES) {
-        // LayerNorm epilogues need ~150 VGPRs -> 12 waves (3 per SIMD); the fp16 shadow store is a
-        // compile-time variant (a run-time branch per store group costs registers -> spills)
-        if (shape == 0) return p.out16 ? launch_shape<KSTEPS, NT, NCH, EPI, ADD2, true, 2, 8>(p, st)
-                                       : launch_shape<KSTEPS, NT, NCH, EPI, ADD2, false, 2, 8>(p, st);
-        return p.out16 ? launch_shape<KSTEPS, NT, NCH, EPI, ADD2, true, 1, 12>(p, st)
-                       : launch_shape<KSTEPS, NT, NCH, EPI, ADD2, false, 1, 12>(p, st);
-    } else {
-        if (p.out16) return GRL_ERR_BAD_ARG;
-        if (shape == 0) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, false, 2, 8>(p, st);
-        return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, false, 1, 16>(p, st);
-    }
+    if (shape == 0) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 2, 8>(p, st);
+    if (shape == 1) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
+    if (shape == 2) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
+    // default: LayerNorm epilogues need ~150 VGPRs -> 12 waves (3 per SIMD); the others fit 16 waves
+    if constexpr (EPI == GRL_EPI_LN_RES) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
+    return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
 }
 
 // chunk = NT n-tiles (NT*16 output channels) swept per pass over the A slab; LayerNorm needs the whole
