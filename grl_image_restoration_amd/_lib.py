@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 6
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -69,8 +69,6 @@ class GrlLinearArgs(_Strict):
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
         ("out_plane_stride", C.c_int64),
-        ("out16", C.c_void_p),
-        ("ldo16", C.c_int64),
     ]
 
 
@@ -132,8 +130,6 @@ class GrlConvArgs(_Strict):
         ("out", C.c_void_p),
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
-        ("out16", C.c_void_p),
-        ("ldo16", C.c_int64),
         ("shuffle_r", C.c_int32),
         ("shuffle_cg", C.c_int32),
         ("shuffle_ij0", C.c_int32),
@@ -164,7 +160,7 @@ def lib():
     L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
     L.grl_attention_fwd.restype = C.c_int
     L.grl_layernorm_fwd.argtypes = [
-        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
+        C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_int32, C.c_int32, C.c_int32, C.c_float,
     ]
     L.grl_layernorm_fwd.restype = C.c_int

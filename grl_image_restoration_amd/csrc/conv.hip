@@ -219,12 +219,6 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                     *(uint2*)((gemm_t*)p.out + orow * p.ldo + oc) = pk;
                 } else {
                     *(float4*)((float*)p.out + orow * p.ldo + oc) = float4{v[0], v[1], v[2], v[3]};
-                    if (p.out16 != nullptr) {  // fp16 shadow of an fp32 output (residual stream)
-                        uint2 pk;
-                        pk.x = pack_f16(v[0], v[1]);
-                        pk.y = pack_f16(v[2], v[3]);
-                        *(uint2*)((gemm_t*)p.out16 + orow * p.ldo16 + oc) = pk;
-                    }
                 }
             }
         }
@@ -354,9 +348,7 @@ extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;
     if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // 64-channel chunks halve the barrier count; 32-channel chunks halve the LDS footprint (2 workgroups/CU for wide outputs)
-    static const int kc32 = getenv("GRL_CONV_KC32") ? atoi(getenv("GRL_CONV_KC32")) : 0;
-    if (p.CinP % 64 == 0 && !(kc32 == 1 || (kc32 == 2 && p.CoutP > 64))) return launch_conv_nt<64>(p, st);
+    if (p.CinP % 64 == 0) return launch_conv_nt<64>(p, st);
     return launch_conv_nt<32>(p, st);
 }
 

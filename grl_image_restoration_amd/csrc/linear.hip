@@ -182,15 +182,7 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
                         o4.y = (col + 1) < p.n_real ? y[1] : 0.f;
                         o4.z = (col + 2) < p.n_real ? y[2] : 0.f;
                         o4.w = (col + 3) < p.n_real ? y[3] : 0.f;
-                        if (valid) {
-                            *(float4*)((float*)p.out + (int64_t)m * p.ldo + n0 + col) = o4;  // LN output is fp32
-                            if (p.out16 != nullptr) {  // fp16 shadow for the next GEMM / conv consumers
-                                uint2 pk;
-                                pk.x = pack_f16(o4.x, o4.y);
-                                pk.y = pack_f16(o4.z, o4.w);
-                                *(uint2*)((gemm_t*)p.out16 + (int64_t)m * p.ldo16 + n0 + col) = pk;
-                            }
-                        }
+                        if (valid) *(float4*)((float*)p.out + (int64_t)m * p.ldo + n0 + col) = o4;  // LN output is fp32
                     }
                 }
             }

@@ -7,8 +7,7 @@ namespace {
 
 // one wave per token row; n_pad <= 256 channels; pad channels written as 0
 __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict__ x, int64_t ldx, float* __restrict__ y,
-                                                        int64_t ldy, f16* __restrict__ y16, int64_t ldy16,
-                                                        const float* __restrict__ gamma,
+                                                        int64_t ldy, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int M, int n_real, int n_pad,
                                                         float eps) {
     const int lane = threadIdx.x & 63;
@@ -40,23 +39,17 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
         for (int i = 0; i < 4; ++i)
             o4[i] = (c + i) < n_real ? (e[i] - mean) * rstd * gamma[c + i] + beta[c + i] : 0.f;
         *(float4*)(y + (int64_t)row * ldy + c) = float4{o4[0], o4[1], o4[2], o4[3]};
-        if (y16 != nullptr) {
-            uint2 pk;
-            pk.x = pack_f16(o4[0], o4[1]);
-            pk.y = pack_f16(o4[2], o4[3]);
-            *(uint2*)(y16 + (int64_t)row * ldy16 + c) = pk;
-        }
     }
 }
 
 }  // namespace
 
-extern "C" int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, void* y16, int64_t ldy16,
-                                 const float* gamma, const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps) {
+extern "C" int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                                 const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps) {
     if (M <= 0) return 0;
     if (n_pad > 256 || (n_pad & 3) || n_real > n_pad || (ldx & 3) || (ldy & 3)) return GRL_ERR_BAD_ARG;
-    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, (f16*)y16,
-                       ldy16, gamma, beta, M, n_real, n_pad, eps);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((M + 3) / 4), dim3(256), 0, (hipStream_t)stream, x, ldx, y, ldy, gamma,
+                       beta, M, n_real, n_pad, eps);
     GRL_CHECK_LAUNCH();
     return 0;
 }

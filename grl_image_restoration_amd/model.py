@@ -500,9 +500,7 @@ class GRL(nn.Module):
         gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])
         return raw, gate
 
-    def _block(self, r, r16, pk, geo: BlockGeo, B, H, W):
-        """One transformer block on the fp32 residual stream ``r``; ``r16`` is its fp16 shadow (written by
-        the producing kernel's epilogue) which the QKV GEMM, CAB conv and fc1 read instead (half the bytes)."""
+    def _block(self, r, pk, geo: BlockGeo, B, H, W):
         C, CP = self.embed_dim, r.shape[1]
         M = B * H * W
         nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
@@ -511,7 +509,7 @@ class GRL(nn.Module):
         dev = r.device
         # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
-        qkv = ops.linear(r16, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
         anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
         att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
         y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=torch.bfloat16, device=dev)
@@ -538,30 +536,26 @@ class GRL(nn.Module):
                       fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
         ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
                       table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
-        cab, gate = self._cab(r16, pk, B, H, W, CP) if self.local_connection else (None, None)
+        cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         # x = x + res_scale * norm1(proj(attn)) + cab(x)   (efficient.py:543-548)
         r1 = ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
                         ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab, add2_scale=gate,
-                        rows_per_image=H * W, out16=r16)   # r16 is dead after the CAB conv / QKV: reuse it for r1
+                        rows_per_image=H * W)
         # x = x + res_scale * norm2(mlp(x))                 (efficient.py:554)
-        h = ops.linear(r16, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU)
-        r2_16 = torch.empty_like(r16)
-        r2 = ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
-                        ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1, out16=r2_16)
-        return r2, r2_16
+        h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU)
+        return ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
+                          ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1)
 
     def forward_features(self, f, plan, B, H, W):
         """grl.py:491-504 on the token matrix f [B*H*W, CP] (fp32) -> [B*H*W, CP]."""
         C = self.embed_dim
-        t16 = torch.empty(f.shape, dtype=ops.GEMM_DTYPE, device=f.device)
-        t = ops.layernorm(f, plan["ns_g"], plan["ns_b"], C, out16=t16)
+        t = ops.layernorm(f, plan["ns_g"], plan["ns_b"], C)
         for si, st in enumerate(plan["stages"]):
-            r, r16 = t, t16
+            r = t
             for bi, pk in enumerate(st["blocks"]):
-                r, r16 = self._block(r, r16, pk, plan["sched"][si][bi], B, H, W)
-            # TransformerStage.forward (grl.py:164-170): conv3x3 + residual (reads the fp16 shadow of r)
-            t16 = torch.empty_like(r16)
-            t = ops.conv3x3(r16, st["conv_w"], st["conv_b"], B, H, W, resid=t, out16=t16)
+                r = self._block(r, pk, plan["sched"][si][bi], B, H, W)
+            # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
+            t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t)
         return ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
 
     @staticmethod

@@ -86,7 +86,6 @@ def linear(
     pool: Optional[Tuple[int, int, int]] = None,
     M: Optional[int] = None,
     planes: bool = False,
-    out16: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
@@ -127,14 +126,12 @@ def linear(
         ldadd2=add2.stride(0) if add2 is not None else 0,
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image,
         out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
-        out16=_ptr(out16), ldo16=out16.stride(0) if out16 is not None else 0,
     )
     if epi == L.EPI_GROUPNORM:
         assert gscale is not None and gscale.dtype == torch.float32 and gscale.numel() == Npad // 32
     if epi == L.EPI_LN_RES:
         assert resid is not None and resid.dtype == torch.float32 and ln_g.numel() == Npad and ln_b.numel() == Npad
         assert out.dtype == torch.float32
-        assert out16 is None or (out16.dtype == GEMM_DTYPE and out16.shape[0] >= M and out16.shape[1] >= Npad)
     with _timed("linear"):
         L.check(L.lib().grl_linear_fwd(L.stream_ptr(), C.byref(args)), "grl_linear_fwd")
     return out
@@ -189,15 +186,14 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
 
 
 def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: int, eps: float = 1e-5,
-              out: Optional[torch.Tensor] = None, out16: Optional[torch.Tensor] = None) -> torch.Tensor:
-    _dev_check(x, gamma, beta, out, out16)
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _dev_check(x, gamma, beta, out)
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
     if out is None:
         out = torch.empty_like(x)
     L.check(
-        L.lib().grl_layernorm_fwd(L.stream_ptr(), _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(out16),
-                                  out16.stride(0) if out16 is not None else 0, _ptr(gamma), _ptr(beta), x.shape[0], n_real,
-                                  x.shape[1], eps),
+        L.lib().grl_layernorm_fwd(L.stream_ptr(), _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma),
+                                  _ptr(beta), x.shape[0], n_real, x.shape[1], eps),
         "grl_layernorm_fwd",
     )
     return out
@@ -233,8 +229,7 @@ def pack_conv_bias(b: torch.Tensor, cout_pad: int, shuffle_r: int = 0, shuffle_c
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int, *, act: int = 0,
             slope: float = 0.0, resid: Optional[torch.Tensor] = None, want_pool: bool = False,
-            out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0,
-            out16: Optional[torch.Tensor] = None):
+            out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0):
     """3x3 conv (stride 1, pad 1) on a channels-last token matrix x[B*H*W, >=CinP]; w packed by
     pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool)."""
     _dev_check(x, w, bias, resid, out)
@@ -268,8 +263,6 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             pool_partial=C.c_void_p(pool.data_ptr() + c0 * 4) if pool is not None else C.c_void_p(0), pool_stride=CoutP,
             out=C.c_void_p(out.data_ptr() + (0 if shuffle_r > 1 else c0 * out.element_size())),
             out_dtype=_KIND[out.dtype], ldo=out.stride(0),
-            out16=C.c_void_p(out16.data_ptr() + c0 * 2) if out16 is not None else C.c_void_p(0),
-            ldo16=out16.stride(0) if out16 is not None else 0,
             shuffle_r=shuffle_r, shuffle_cg=shuffle_cg, shuffle_ij0=(c0 // shuffle_cg if shuffle_r > 1 else 0),
         )
         with _timed("conv3x3"):

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 7
+#define GRL_ABI_VERSION 6
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -66,8 +66,6 @@ typedef struct GrlLinearArgs {
     int64_t ldo;
     int64_t out_plane_stride; /* >0: write 32-column groups as planes: element (m, c) goes to          */
                               /* out[(c/32)*out_plane_stride + m*32 + c%32]  (ldo ignored)             */
-    void* out16;              /* LN_RES: optional fp16 shadow [M, ldo16] of the fp32 output -- the     */
-    int64_t ldo16;            /* GEMM/conv consumers of the residual stream read half the bytes        */
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
@@ -145,8 +143,6 @@ typedef struct GrlConvArgs {
     void* out;              /* [rows, ldo] GRL_DT_F32 or GRL_DT_F16                                 */
     int32_t out_dtype;
     int64_t ldo;
-    void* out16;            /* optional fp16 shadow [rows, ldo16] of an fp32 output (not with shuffle)*/
-    int64_t ldo16;
     int32_t shuffle_r;      /* >1: PixelShuffle(r) store into a [B, H*r, W*r, shuffle_cg] matrix;    */
     int32_t shuffle_cg;     /*     output channels are packed in (i, j, c) order, this call's        */
     int32_t shuffle_ij0;    /*     channel 0 belongs to sub-pixel group shuffle_ij0                  */
@@ -164,9 +160,8 @@ int grl_se_scale_fwd(void* stream, const float* pool_partial, int32_t B, int32_t
 /* ---------------------------------------------------------------------------------------------
  * Row LayerNorm on a padded token matrix (norm_start / norm_end, models/networks/grl.py:494,501).
  * ------------------------------------------------------------------------------------------- */
-int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, void* y16, int64_t ldy16,
-                      const float* gamma, const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps);
-/* y16: optional fp16 shadow of y (NULL: none) */
+int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
+                      const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps);
 
 /* Library self-description (used by the loader to refuse a stale build). */
 int grl_abi_version(void);

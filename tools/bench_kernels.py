@@ -34,11 +34,10 @@ def main():
     st = plan["stages"][0]
     r = torch.randn(M, CP, device="cuda")
     r[:, C:] = 0
-    r16 = r.to(torch.float16)   # fp16 shadow of the residual stream (what QKV / CAB conv / fc1 / stage conv read)
     nh, df = 3, geo.df
     Ha, Wa = H // df, W // df
     TG = ops.TokenGrid
-    qkv = ops.linear(r16, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+    qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
     anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
     att = torch.zeros(M, 2 * nh * 32, dtype=torch.float16, device="cuda")
     y = torch.zeros(nh, B * Ha * Wa, 32, dtype=torch.bfloat16, device="cuda")
@@ -56,14 +55,13 @@ def main():
     cab = torch.zeros(M, CP, dtype=torch.float16, device="cuda")
     pool = torch.zeros(L.lib().grl_conv3x3_num_workgroups(B, H, W), CP, device="cuda")
     gate = torch.ones(B, CP, device="cuda")
-    r16b = torch.empty_like(r16)
     L_, Nw, N2 = H * W, ws[0] * ws[1], ast[0] * ast[1]
     fl_att = 2 * L_ * Nw * C * B
     fl_s = 2 * L_ * N2 * C * B
 
     kernels = {
-        "qkv": (lambda: ops.linear(r16, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv, planes=True),
-                6 * L_ * C * C * B, M * (CP * 2 * 2 + 576 * 2)),
+        "qkv": (lambda: ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv, planes=True),
+                6 * L_ * C * C * B, M * (CP * 4 + 576 * 2)),
         "anchor": (lambda: ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), out=anc, planes=True),
                    L_ * C * C * B // (df * df), M * CP * 4),
         "attn_window": (lambda: ops.attention(TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh, H, W, ws[0], ws[1], sh, sh),
@@ -75,16 +73,16 @@ def main():
         "attn_w2a": (lambda: ops.attention(g_q, g_a, g_y, TG(att, nh, H, W, stp[0], stp[1], ss[0], ss[1]), B=B, nh=nh,
                                            table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=30,
                                            head_dim=30), fl_s, M * 2 * 96 * 2),
-        "cab_conv1": (lambda: ops.conv3x3(r16, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid), 2 * 9 * L_ * C * 45 * B, M * (CP * 2 + 96)),
+        "cab_conv1": (lambda: ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid), 2 * 9 * L_ * C * 45 * B, M * (CP * 4 + 96)),
         "cab_conv2": (lambda: ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out=cab), 2 * 9 * L_ * C * 45 * B, M * (128 + CP * 2)),
         "se": (lambda: ops.se_scale(pool, B, CP, C, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"]), 0, pool.numel() * 4),
         "proj_ln": (lambda: ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
-                                       ln_b=pk["n1_b"], n_real=C, resid=r, add2=cab, add2_scale=gate, rows_per_image=H * W, out16=r16b),
-                    2 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4 + CP * 2)),
-        "fc1_gelu": (lambda: ops.linear(r16, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out=h), 4 * L_ * C * C * B, M * (CP * 2 + 384 * 2)),
+                                       ln_b=pk["n1_b"], n_real=C, resid=r, add2=cab, add2_scale=gate, rows_per_image=H * W),
+                    2 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4)),
+        "fc1_gelu": (lambda: ops.linear(r, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out=h), 4 * L_ * C * C * B, M * (CP * 4 + 384 * 2)),
         "fc2_ln": (lambda: ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
-                                      ln_b=pk["n2_b"], n_real=C, resid=r, out16=r16b), 4 * L_ * C * C * B, M * (384 * 2 + CP * 8 + CP * 2)),
-        "stage_conv": (lambda: ops.conv3x3(r16, st["conv_w"], st["conv_b"], B, H, W, resid=r, out16=r16b), 18 * L_ * C * C * B, M * CP * 12),
+                                      ln_b=pk["n2_b"], n_real=C, resid=r), 4 * L_ * C * C * B, M * (384 * 2 + CP * 8)),
+        "stage_conv": (lambda: ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=r), 18 * L_ * C * C * B, M * CP * 12),
         "layernorm": (lambda: ops.layernorm(r, plan["ns_g"], plan["ns_b"], C), 0, M * CP * 8),
     }
     only = [s for s in a.only.split(",") if s]
