@@ -189,23 +189,43 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
         }
         return;
     }
+    if (p.out_dtype != GRL_DT_F32) {
+        // 16-bit outputs: a lane owns 4 channels (8 B) of tile nt and of tile nt+1.  The lane pairs
+        // (g4, g4^1) -- 16 lanes apart -- swap one of the two so that every lane holds 8 CONSECUTIVE
+        // channels and issues one 16-B store per tile pair: 64 B contiguous per token instead of two
+        // instructions of 32-B pieces (8-B-per-lane stores were the bottleneck of these epilogues).
+        // All lanes take part in the exchange; only the store is predicated.
+        const bool odd = g4 & 1;
+#pragma unroll
+        for (int c = 0; c < NCH; ++c)
+#pragma unroll
+            for (int nt = 0; nt < NT; nt += 2) {
+                uint2 lo, hi;  // this lane's 4 channels of tile nt / tile nt+1
+                lo.x = pack16(acc[c][mt][nt][0], acc[c][mt][nt][1], p.out_dtype);
+                lo.y = pack16(acc[c][mt][nt][2], acc[c][mt][nt][3], p.out_dtype);
+                hi.x = pack16(acc[c][mt][nt + 1][0], acc[c][mt][nt + 1][1], p.out_dtype);
+                hi.y = pack16(acc[c][mt][nt + 1][2], acc[c][mt][nt + 1][3], p.out_dtype);
+                const uint2 send = odd ? lo : hi;       // even lanes keep tile nt, odd lanes keep tile nt+1
+                uint2 recv;
+                recv.x = __shfl_xor(send.x, 16, 64);
+                recv.y = __shfl_xor(send.y, 16, 64);
+                const uint4 v = odd ? uint4{recv.x, recv.y, hi.x, hi.y} : uint4{lo.x, lo.y, recv.x, recv.y};
+                // even lane g4: channels 4*g4 .. 4*g4+7 of tile nt; odd lane: channels 4*(g4-1) .. of tile nt+1
+                const int col = n0 + 16 * (c * NT + nt + (odd ? 1 : 0)) + 4 * (g4 & ~1);
+                const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
+                                                           : (int64_t)m * p.ldo + col;
+                if (valid) *(uint4*)((bf16*)p.out + off) = v;
+            }
+        return;
+    }
     if (!valid) return;
 #pragma unroll
     for (int c = 0; c < NCH; ++c)
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + 16 * (c * NT + nt) + 4 * g4;
-            if (p.out_dtype != GRL_DT_F32) {
-                uint2 pk;
-                pk.x = pack16(acc[c][mt][nt][0], acc[c][mt][nt][1], p.out_dtype);
-                pk.y = pack16(acc[c][mt][nt][2], acc[c][mt][nt][3], p.out_dtype);
-                const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
-                                                           : (int64_t)m * p.ldo + col;
-                *(uint2*)((bf16*)p.out + off) = pk;
-            } else {
-                *(float4*)((float*)p.out + (int64_t)m * p.ldo + col) =
-                    float4{acc[c][mt][nt][0], acc[c][mt][nt][1], acc[c][mt][nt][2], acc[c][mt][nt][3]};
-            }
+            *(float4*)((float*)p.out + (int64_t)m * p.ldo + col) =
+                float4{acc[c][mt][nt][0], acc[c][mt][nt][1], acc[c][mt][nt][2], acc[c][mt][nt][3]};
         }
 }
 
@@ -397,6 +417,7 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     const GrlLinearArgs& p = *args;
     if (p.M <= 0) return 0;
     if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % 8 != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
+    if (p.out_dtype != GRL_DT_F32 && p.out_plane_stride <= 0 && (p.ldo % 8) != 0) return GRL_ERR_BAD_ARG;  // 16-B stores
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
     if (p.add2 != nullptr && (p.add2_dtype != GRL_DT_F16 || p.add2_scale == nullptr || p.rows_per_image <= 0)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
