@@ -53,6 +53,7 @@ def cpu_baseline(cfg):
     from grl_image_restoration_amd import GRL
 
     torch.manual_seed(0)
+    torch.set_num_threads(min(32, os.cpu_count() or 1))  # small per-op work: more threads only add overhead
     c = dict(cfg)
     c["img_size"] = 64
     m = GRL(**c)
@@ -77,7 +78,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=4, help="256x256 LQ tiles per GPU per step")
+    ap.add_argument("--tiles", type=int, default=8, help="256x256 LQ tiles per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
 
@@ -144,7 +145,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16",
+            "dtype": "bf16 (attention) / f16 (linear, conv) MFMA operands, f32 accumulate + residual",
             "data": "synthetic",
             "config": {
                 "workload": "BASELINE configs[2]: GRL-Base x4 SR, 256x256 LQ tiles, ckpt geometry "

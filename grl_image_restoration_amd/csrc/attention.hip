@@ -709,6 +709,8 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     if (variant == 3 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 0>(p, st);
     if (variant == 4) return launch_fast_v<4, 2, 8, 2, 1>(p, st);
     if (variant == 5 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 3>(p, st);   // 4-tile fragment ring
+    if (variant == 6) return launch_fast_v<8, 2, 8, 2, 2>(p, st);   // 8 waves share one K/V chunk
+    if (variant == 7) return launch_fast_v<8, 2, 16, 2, 2>(p, st);  // ... and 16-row chunks
     return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // bias-fragment reuse
 }
 
