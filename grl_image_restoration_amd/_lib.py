@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -17,6 +17,8 @@ EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
 # every symbol include/grl_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "grl_linear_fwd",
+    "grl_mlp_fwd",
+    "grl_mlp_blob_bytes",
     "grl_attention_fwd",
     "grl_layernorm_fwd",
     "grl_conv3x3_fwd",
@@ -69,6 +71,25 @@ class GrlLinearArgs(_Strict):
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
         ("out_plane_stride", C.c_int64),
+    ]
+
+
+class GrlMlpArgs(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("blob", C.c_void_p),
+        ("M", C.c_int32),
+        ("Cpad", C.c_int32),
+        ("Hpad", C.c_int32),
+        ("b2", C.c_void_p),
+        ("ln_g", C.c_void_p),
+        ("ln_b", C.c_void_p),
+        ("n_real", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("res_scale", C.c_float),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
     ]
 
 
@@ -157,6 +178,10 @@ def lib():
     L.grl_build_info.restype = C.c_char_p
     L.grl_linear_fwd.argtypes = [C.c_void_p, C.POINTER(GrlLinearArgs)]
     L.grl_linear_fwd.restype = C.c_int
+    L.grl_mlp_fwd.argtypes = [C.c_void_p, C.POINTER(GrlMlpArgs)]
+    L.grl_mlp_fwd.restype = C.c_int
+    L.grl_mlp_blob_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.grl_mlp_blob_bytes.restype = C.c_int64
     L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
     L.grl_attention_fwd.restype = C.c_int
     L.grl_layernorm_fwd.argtypes = [

@@ -1,0 +1,259 @@
+// Fused transformer MLP of a GRL block (gfx950):  out = x + res_scale * LayerNorm(fc2(GELU(fc1(x))))
+//
+// Replaces Mlp.forward (models/common/swin_v1_block.py:37-43) + norm2 + residual
+// (models/common/mixed_attn_block_efficient.py:554) in ONE pass over the residual stream: the hidden
+// activations (2C channels per token) never leave the CU.  As two kernels the pair moves
+// x(4C) + h(2*2C) + h(2*2C) + x(4C) + out(4C) = 20C bytes per token through HBM, fused 8C:
+// 969 MB -> 378 MB per launch for 4 tiles of GRL-Base.
+//
+// Design
+//   * a wave owns 16 tokens; their fc1 operand slab (fp16, C x 16) and the fc2 accumulators
+//     (16 tokens x C channels, fp32) stay in VGPRs for the whole hidden sweep;
+//   * the hidden dimension is swept in chunks of 32 channels:  h_c = GELU(W1_c . x + b1_c)  (2 MFMA n-tiles)
+//     is consumed immediately by  acc += W2[:, c] . h_c  (C/16 MFMAs).  The product is computed transposed
+//     (D^T = W . X^T, mfma_f32_16x16x32_f16), so the fc1 accumulator fragment of a lane -- 2 x 4 hidden
+//     channels of one token -- IS the B operand of the fc2 MFMA once W2's k-slots are stored in the matching
+//     order (slot 8g+e <-> hidden channel 4g+e for e < 4, 16+4g+e-4 otherwise; done by the host pack):
+//     no shuffle, no LDS round trip for the hidden activations;
+//   * W1 + W2 (2 x 2C x C fp16 = 288 KB for Base) exceed the 160 KB LDS, so the weights stream from L2
+//     through a double-buffered LDS ring, one 32-channel chunk (W1 rows, W2 columns, b1) per step; the
+//     chunk sequence is cyclic, so the ring keeps running across the token tiles of the persistent
+//     workgroup.  One barrier per chunk.
+#include "common.h"
+#include <stdlib.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+typedef const __attribute__((address_space(1))) void* gbl_ptr_t;
+
+template <int KSTEPS>
+struct MlpShape {
+    static constexpr int CP = KSTEPS * 32;          // padded channels (= K of fc1 = N of fc2)
+    static constexpr int NT2 = CP / 16;             // fc2 n-tiles
+    static constexpr int W1ROW = CP * 2 + 16;       // bytes per W1 row (16 B pad: conflict-free ds_read_b128)
+    static constexpr int W2ROW = 64 + 16;           // bytes per W2 row of one chunk (32 k-slots + pad)
+    static constexpr int W1B = 32 * W1ROW;
+    static constexpr int W2B = CP * W2ROW;
+    static constexpr int BUF = W1B + W2B + 128;     // + b1 chunk (32 floats)
+    static constexpr int BUFP = (BUF + 1023) / 1024 * 1024;   // chunk image, padded to whole 1-KiB DMA pieces
+    static constexpr int PIECES = BUFP / 1024;
+};
+
+// Fused MLP, see the file header.  WV waves x 16 tokens per workgroup, one persistent workgroup per CU.
+//   * weight ring: the blob already IS the LDS image of a chunk (padded rows), so a chunk is copied by
+//     PIECES wave-wide global_load_lds_dwordx4 (1 KiB each, no staging registers, no ds_write pass);
+//   * the fp32 token slab stays in registers for the residual (no re-read) next to its fp16 MFMA copy, and the
+//     next tile's slab is prefetched into a second register set half way through the hidden sweep.
+template <int KSTEPS, int WV>
+__global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
+    using S = MlpShape<KSTEPS>;
+    constexpr int CP = S::CP, NT2 = S::NT2;
+    constexpr int THREADS = WV * 64;
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r16 = lane & 15, g4 = lane >> 4;
+    const int nchunks = p.Hpad / 32;
+    const char* blob = (const char*)p.blob;
+
+    auto fetch = [&](int chunk, char* buf) {   // this wave's share of the chunk image: pieces wave, wave + WV, ...
+        const char* src = blob + (size_t)chunk * S::BUFP + lane * 16;
+#pragma unroll
+        for (int q0 = 0; q0 < S::PIECES; q0 += WV) {
+            const int q = q0 + wave;
+            if (q < S::PIECES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + q * 1024), (lds_ptr_t)(buf + q * 1024), 16, 0, 0);
+        }
+    };
+
+    const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
+    if ((int)blockIdx.x >= ntiles) return;
+    // fc2 bias and the norm affine live in LDS behind the ring (read once per tile by every lane)
+    float* vec = (float*)(smem + 2 * S::BUFP);
+    for (int i = tid; i < 3 * CP; i += THREADS) vec[i] = i < CP ? p.b2[i] : (i < 2 * CP ? p.ln_g[i - CP] : p.ln_b[i - 2 * CP]);
+    fetch(0, smem);
+    int it = 0;   // running chunk counter of the ring (chunk = it % nchunks, buffer = it & 1)
+
+    // token slab of a tile (fp32): lane = token r16; its 8 k-slots of k-step s are the channels 32s + 4*g4 + [0..3]
+    // and 32s + 16 + 4*g4 + [0..3] -- the accumulator layout of n-tiles 2s / 2s+1 (W1's columns are packed in the
+    // same slot order), so the registers that feed fc1 also provide the residual of the epilogue: x is read once.
+    float4 xs[KSTEPS][2], xn[KSTEPS][2];
+    auto load_slab = [&](int tile, float4 (&x)[KSTEPS][2]) {
+        int m = tile * (WV * 16) + wave * 16 + r16;
+        m = m < p.M ? m : p.M - 1;
+        const float* base = p.x + (int64_t)m * p.ldx + 4 * g4;
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            x[s][0] = *(const float4*)(base + 32 * s);
+            x[s][1] = *(const float4*)(base + 32 * s + 16);
+        }
+    };
+    load_slab(blockIdx.x, xn);
+
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int m = tile * (WV * 16) + wave * 16 + r16;
+        const bool valid = m < p.M;
+        gemm_x8 a[KSTEPS];
+#pragma unroll
+        for (int s = 0; s < KSTEPS; ++s) {
+            xs[s][0] = xn[s][0];
+            xs[s][1] = xn[s][1];
+            gemm_x8 v;
+            v[0] = (gemm_t)xs[s][0].x; v[1] = (gemm_t)xs[s][0].y; v[2] = (gemm_t)xs[s][0].z; v[3] = (gemm_t)xs[s][0].w;
+            v[4] = (gemm_t)xs[s][1].x; v[5] = (gemm_t)xs[s][1].y; v[6] = (gemm_t)xs[s][1].z; v[7] = (gemm_t)xs[s][1].w;
+            a[s] = v;
+        }
+        f32x4 acc[NT2];
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
+        const int next_tile = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+
+#pragma unroll 1
+        for (int c = 0; c < ((dbg & 16) ? 1 : nchunks); ++c, ++it) {
+            // every wave waits for its own DMA pieces of chunk `it` (vmcnt) before the barrier publishes them;
+            // after the barrier nobody reads buffer (it+1)&1 any more, so the next chunk may land there
+            if (!(dbg & 2)) __syncthreads();
+            char* cur = smem + (it & 1) * S::BUFP;
+            if (!(dbg & 1)) fetch(c + 1 < nchunks ? c + 1 : 0, smem + ((it + 1) & 1) * S::BUFP);
+            if (c == nchunks / 2) load_slab(next_tile, xn);   // lands during the second half of the sweep
+
+            // ---- h = GELU(W1_c . x + b1_c): two n-tiles of 16 hidden channels ----
+            // LDS fragment reads are issued in batches ahead of the MFMAs that consume them (the compiler
+            // otherwise emits read -> wait -> MFMA one by one and fills the MFMA->VALU hazards with s_nop)
+            const float4 bA = *(const float4*)(cur + S::W1B + S::W2B + (4 * g4) * 4);
+            const float4 bB = *(const float4*)(cur + S::W1B + S::W2B + (16 + 4 * g4) * 4);
+            f32x4 h0 = f32x4{0, 0, 0, 0}, h1 = f32x4{0, 0, 0, 0};
+            constexpr int KB = KSTEPS > 4 ? KSTEPS / 2 : KSTEPS;   // k-steps per read batch (register budget)
+#pragma unroll
+            for (int s0 = 0; s0 < KSTEPS; s0 += KB) {
+                gemm_x8 wa[KB], wb[KB];
+#pragma unroll
+                for (int s = 0; s < KB; ++s) {
+                    wa[s] = *(const gemm_x8*)(cur + r16 * S::W1ROW + (32 * (s0 + s) + 8 * g4) * 2);
+                    wb[s] = *(const gemm_x8*)(cur + (16 + r16) * S::W1ROW + (32 * (s0 + s) + 8 * g4) * 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int s = 0; s < KB; ++s) {
+                    h0 = mfma16_gemm(wa[s], a[s0 + s], h0);
+                    h1 = mfma16_gemm(wb[s], a[s0 + s], h1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            constexpr int QB = 4, NB = NT2 / QB;   // fc2 n-tiles per read batch; batch k+1 is in flight while k multiplies
+            gemm_x8 w2[2][QB];
+#pragma unroll
+            for (int j = 0; j < QB; ++j) w2[0][j] = *(const gemm_x8*)(cur + S::W1B + (16 * j + r16) * S::W2ROW + 16 * g4);
+            __builtin_amdgcn_sched_barrier(0);
+            gemm_x8 hb;   // k-slots 8*g4 + [0..7] of this chunk for token r16 (see the header comment)
+            hb[0] = (gemm_t)gelu_erf(h0[0] + bA.x); hb[1] = (gemm_t)gelu_erf(h0[1] + bA.y);
+            hb[2] = (gemm_t)gelu_erf(h0[2] + bA.z); hb[3] = (gemm_t)gelu_erf(h0[3] + bA.w);
+            hb[4] = (gemm_t)gelu_erf(h1[0] + bB.x); hb[5] = (gemm_t)gelu_erf(h1[1] + bB.y);
+            hb[6] = (gemm_t)gelu_erf(h1[2] + bB.z); hb[7] = (gemm_t)gelu_erf(h1[3] + bB.w);
+            __builtin_amdgcn_sched_barrier(0);
+            // ---- acc += W2[:, chunk] . h ----
+#pragma unroll
+            for (int k = 0; k < NB; ++k) {
+                if (k + 1 < NB) {
+#pragma unroll
+                    for (int j = 0; j < QB; ++j)
+                        w2[(k + 1) & 1][j] = *(const gemm_x8*)(cur + S::W1B + (16 * (QB * (k + 1) + j) + r16) * S::W2ROW + 16 * g4);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int j = 0; j < QB; ++j) acc[QB * k + j] = mfma16_gemm(w2[k & 1][j], hb, acc[QB * k + j]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+
+        // ---- epilogue: + b2, LayerNorm over the n_real channels, residual (from the register slab) ----
+        float s1 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const float4 b4 = *(const float4*)(vec + 16 * nt + 4 * g4);
+            acc[nt][0] += b4.x; acc[nt][1] += b4.y; acc[nt][2] += b4.z; acc[nt][3] += b4.w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s1 += (16 * nt + 4 * g4 + e) < p.n_real ? acc[nt][e] : 0.f;
+        }
+        s1 += __shfl_xor(s1, 16, 64);
+        s1 += __shfl_xor(s1, 32, 64);
+        const float mean = s1 / (float)p.n_real;
+        float s2 = 0.f;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float d = acc[nt][e] - mean;
+                s2 += (16 * nt + 4 * g4 + e) < p.n_real ? d * d : 0.f;
+            }
+        s2 += __shfl_xor(s2, 16, 64);
+        s2 += __shfl_xor(s2, 32, 64);
+        const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
+        const int64_t mc = valid ? m : (int64_t)p.M - 1;
+        float* orow = p.out + mc * p.ldo;
+#pragma unroll
+        for (int nt = 0; nt < NT2; ++nt) {
+            const int col = 16 * nt + 4 * g4;
+            const float4 res = (dbg & 8) ? float4{0, 0, 0, 0} : xs[nt >> 1][nt & 1];
+            const float4 g = *(const float4*)(vec + CP + col);
+            const float4 bb = *(const float4*)(vec + 2 * CP + col);
+            float4 o4;
+            o4.x = res.x + p.res_scale * ((acc[nt][0] - mean) * rstd * g.x + bb.x);
+            o4.y = res.y + p.res_scale * ((acc[nt][1] - mean) * rstd * g.y + bb.y);
+            o4.z = res.z + p.res_scale * ((acc[nt][2] - mean) * rstd * g.z + bb.z);
+            o4.w = res.w + p.res_scale * ((acc[nt][3] - mean) * rstd * g.w + bb.w);
+            if (col + 0 >= p.n_real) o4.x = 0.f;   // keep pad channels 0
+            if (col + 1 >= p.n_real) o4.y = 0.f;
+            if (col + 2 >= p.n_real) o4.z = 0.f;
+            if (col + 3 >= p.n_real) o4.w = 0.f;
+            if (valid) *(float4*)(orow + col) = o4;
+        }
+    }
+}
+
+template <int KSTEPS, int WV>
+int launch_mlp(const GrlMlpArgs& p, hipStream_t st) {
+    using S = MlpShape<KSTEPS>;
+    const size_t lds = 2 * (size_t)S::BUFP + 3 * S::CP * sizeof(float);
+    const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
+    const int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU
+    auto kfn = mlp_kernel<KSTEPS, WV>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    static const int dbg = getenv("GRL_MLP_DEBUG") ? atoi(getenv("GRL_MLP_DEBUG")) : 0;  // timing ablations only
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WV * 64), lds, st, p, dbg);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+int64_t chunk_bytes(int Cpad) {
+    switch (Cpad / 32) {
+        case 2: return MlpShape<2>::BUFP;
+        case 4: return MlpShape<4>::BUFP;
+        case 6: return MlpShape<6>::BUFP;
+        default: return 0;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad) {
+    if (Cpad <= 0 || Hpad <= 0 || (Cpad % 32) || (Hpad % 32) || chunk_bytes(Cpad) == 0) return GRL_ERR_BAD_ARG;
+    return (int64_t)(Hpad / 32) * chunk_bytes(Cpad);
+}
+
+extern "C" int grl_mlp_fwd(void* stream, const GrlMlpArgs* args) {
+    const GrlMlpArgs& p = *args;
+    if (p.M <= 0) return 0;
+    if ((p.Cpad % 32) || (p.Hpad % 32) || p.Hpad <= 0 || (p.ldx % 4) || (p.ldo % 4) || p.ldx < p.Cpad || p.ldo < p.Cpad ||
+        p.n_real > p.Cpad || p.n_real <= 0)
+        return GRL_ERR_BAD_ARG;
+    if (p.x == nullptr || p.blob == nullptr || p.out == nullptr || (const void*)p.x == (const void*)p.out) return GRL_ERR_BAD_ARG;
+    if (((uintptr_t)p.blob & 15) != 0) return GRL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    switch (p.Cpad / 32) {
+        case 2: return launch_mlp<2, 8>(p, st);
+        case 4: return launch_mlp<4, 8>(p, st);
+        case 6: return launch_mlp<6, 8>(p, st);
+        default: return GRL_ERR_UNSUPPORTED;
+    }
+}

@@ -10,6 +10,7 @@ the forward pass (grl.py:506-551) on MI355X through libgrl_hip.so.
 There is no CPU / eager fallback for the hot path: calling the model on CPU tensors raises.
 """
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -397,6 +398,9 @@ class GRL(nn.Module):
         W2[:C, :Hd] = blk.mlp.fc2.weight.detach().float()
         pk.update(fc1_w=W1.to(G16), fc1_b=padv(blk.mlp.fc1.bias, HP), fc2_w=W2.to(G16),
                   fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
+        if CP in (64, 128, 192):  # fused fc1 -> GELU -> fc2 -> norm2 -> residual kernel (csrc/mlp.hip)
+            pk.update(mlp_blob=ops.pack_mlp(blk.mlp.fc1.weight.to(dev), blk.mlp.fc1.bias.to(dev), blk.mlp.fc2.weight.to(dev), CP, HP),
+                      mlp_hp=HP)
 
         # --- relative-position bias tables in the kernel's exp2 domain ---
         def table(m: _Affine, win, df, scale):
@@ -491,6 +495,14 @@ class GRL(nn.Module):
             x = F.pad(x, (0, pw, 0, ph), "constant")
         return x
 
+    def _side_stream(self, dev):
+        if os.environ.get("GRL_SIDE_STREAM", "0") != "1":
+            return None
+        st = getattr(self, "_side", None)
+        if st is None or st.device != dev:
+            st = self._side = torch.cuda.Stream(dev)
+        return st
+
     def _cab(self, r, pk, B, H, W, CP):
         """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output (bf16) and the
         per-image squeeze-excite gate; the gate is applied inside the proj+norm1 epilogue."""
@@ -509,6 +521,13 @@ class GRL(nn.Module):
         dev = r.device
         # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
+        side = self._side_stream(dev) if self.local_connection else None
+        if side is not None:
+            # the CAB branch only reads r: run it on a second HIP stream beside the attention chain
+            main = torch.cuda.current_stream(dev)
+            side.wait_stream(main)
+            with torch.cuda.stream(side):
+                cab, gate = self._cab(r, pk, B, H, W, CP)
         qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
         anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
         att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
@@ -536,12 +555,20 @@ class GRL(nn.Module):
                       fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
         ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
                       table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
-        cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
+        if side is not None:
+            main.wait_stream(side)
+            cab.record_stream(main)
+            gate.record_stream(main)
+        else:
+            cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         # x = x + res_scale * norm1(proj(attn)) + cab(x)   (efficient.py:543-548)
         r1 = ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
                         ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab, add2_scale=gate,
                         rows_per_image=H * W)
         # x = x + res_scale * norm2(mlp(x))                 (efficient.py:554)
+        if "mlp_blob" in pk and os.environ.get("GRL_FUSED_MLP", "1") != "0":
+            return ops.mlp(r1, pk["mlp_blob"], pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C,
+                           res_scale=self.res_scale)
         h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU)
         return ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
                           ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1)
@@ -550,6 +577,9 @@ class GRL(nn.Module):
         """grl.py:491-504 on the token matrix f [B*H*W, CP] (fp32) -> [B*H*W, CP]."""
         C = self.embed_dim
         t = ops.layernorm(f, plan["ns_g"], plan["ns_b"], C)
+        n = self.stream_groups(B)
+        if n > 1:
+            return self._features_streams(t, plan, B, H, W, n)
         for si, st in enumerate(plan["stages"]):
             r = t
             for bi, pk in enumerate(st["blocks"]):
@@ -557,6 +587,42 @@ class GRL(nn.Module):
             # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
             t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t)
         return ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
+
+    @staticmethod
+    def stream_groups(B: int) -> int:
+        """Number of tile groups / HIP streams a batch of B tiles is processed in (GRL_SPLIT_STREAMS, default 2;
+        measured on MI355X: 2 groups +6 % tiles/s over one stream, 4 groups are host-launch bound)."""
+        n = int(os.environ.get("GRL_SPLIT_STREAMS", "2"))
+        return n if n > 1 and B >= n and B % n == 0 else 1
+
+    def _features_streams(self, t, plan, B, H, W, n):
+        """The tile batch is cut into n groups that advance block by block on n HIP streams: tiles are independent,
+        and the HBM-bound linear kernels of one group overlap the MFMA-bound attention of another."""
+        dev = t.device
+        main = torch.cuda.current_stream(dev)
+        pool = getattr(self, "_streams", None)
+        if pool is None or len(pool) < n or pool[0].device != dev:
+            pool = self._streams = [torch.cuda.Stream(dev) for _ in range(n)]
+        Bg = B // n
+        Mg = t.shape[0] // n
+        parts = [t[g * Mg : (g + 1) * Mg] for g in range(n)]
+        for g in range(n):
+            pool[g].wait_stream(main)
+        for si, st in enumerate(plan["stages"]):
+            r = list(parts)
+            for bi, pk in enumerate(st["blocks"]):
+                for g in range(n):
+                    with torch.cuda.stream(pool[g]):
+                        r[g] = self._block(r[g], pk, plan["sched"][si][bi], Bg, H, W)
+            for g in range(n):
+                with torch.cuda.stream(pool[g]):
+                    parts[g] = ops.conv3x3(r[g], st["conv_w"], st["conv_b"], Bg, H, W, resid=parts[g])
+        out = torch.empty_like(t)
+        for g in range(n):
+            with torch.cuda.stream(pool[g]):
+                ops.layernorm(parts[g], plan["ne_g"], plan["ne_b"], self.embed_dim, out=out[g * Mg : (g + 1) * Mg])
+            main.wait_stream(pool[g])
+        return out
 
     @staticmethod
     def _tokens(x, cpad):

@@ -137,6 +137,55 @@ def linear(
     return out
 
 
+def pack_mlp(fc1_w: torch.Tensor, fc1_b: torch.Tensor, fc2_w: torch.Tensor, Cpad: int, Hpad: int) -> torch.Tensor:
+    """Weight chunk stream of grl_mlp_fwd (layout in include/grl_hip.h): per 32 hidden channels one LDS image
+    W1 rows | W2 columns | fc1 bias, rows padded by 16 B, k-slots in the kernel's order, chunk padded to 1 KiB.
+    fc1_w: (Hd, C), fc2_w: (C, Hd) -- swin_v1_block.py:29-33.  Returns a uint8 device tensor."""
+    dev = fc1_w.device
+    Hd, Cin = fc1_w.shape
+    assert fc2_w.shape == (Cin, Hd) and Cpad % 32 == 0 and Hpad % 32 == 0 and Cpad >= Cin and Hpad >= Hd
+    W1 = torch.zeros(Hpad, Cpad, dtype=torch.float32, device=dev)
+    W1[:Hd, :Cin] = fc1_w.detach().float()
+    W2 = torch.zeros(Cpad, Hpad, dtype=torch.float32, device=dev)
+    W2[:Cin, :Hd] = fc2_w.detach().float()
+    b1 = torch.zeros(Hpad, dtype=torch.float32, device=dev)
+    b1[:Hd] = fc1_b.detach().float()
+    nch = Hpad // 32
+    # k-slot sigma = 8g + e of a 32-group  ->  channel 4g + e (e < 4) | 16 + 4g + (e - 4): the MFMA accumulator
+    # fragment of one layer is the operand fragment of the next (csrc/mlp.hip)
+    sig = torch.arange(32, device=dev)
+    g, e = sig // 8, sig % 8
+    chan = torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4))
+    w1c = W1.view(nch, 32, Cpad // 32, 32)[..., chan].reshape(nch, 32, Cpad).to(GEMM_DTYPE)        # [chunk][32 rows][Cpad slots]
+    w2c = W2.view(Cpad, nch, 32)[:, :, chan].permute(1, 0, 2).contiguous().to(GEMM_DTYPE)          # [chunk][Cpad rows][32 slots]
+    total = L.lib().grl_mlp_blob_bytes(Cpad, Hpad)
+    assert total > 0 and total % nch == 0
+    blob = torch.zeros(nch, total // nch, dtype=torch.uint8, device=dev)
+    w1row, w2row = Cpad * 2 + 16, 80
+    w1b, w2b = 32 * w1row, Cpad * w2row
+    blob[:, :w1b].view(nch, 32, w1row)[:, :, : Cpad * 2] = w1c.contiguous().view(torch.uint8).view(nch, 32, Cpad * 2)
+    blob[:, w1b : w1b + w2b].view(nch, Cpad, w2row)[:, :, :64] = w2c.view(torch.uint8).view(nch, Cpad, 64)
+    blob[:, w1b + w2b : w1b + w2b + 128] = b1.view(nch, 32).contiguous().view(torch.uint8).view(nch, 128)
+    return blob.contiguous()
+
+
+def mlp(x: torch.Tensor, blob: torch.Tensor, b2: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, *, Hpad: int,
+        n_real: int, ln_eps: float = 1e-5, res_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = x + res_scale * LayerNorm(fc2(GELU(fc1(x)))) on the token matrix x [M, Cpad] (fp32), one kernel."""
+    _dev_check(x, blob, b2, ln_g, ln_b, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32
+    M, Cpad = x.shape
+    assert blob.dtype == torch.uint8 and blob.is_contiguous() and b2.numel() == Cpad and ln_g.numel() == Cpad and ln_b.numel() == Cpad
+    if out is None:
+        out = torch.empty(M, Cpad, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape == (M, Cpad) and out.data_ptr() != x.data_ptr()
+    args = L.GrlMlpArgs(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), M=M, Cpad=Cpad, Hpad=Hpad, b2=_ptr(b2), ln_g=_ptr(ln_g),
+                        ln_b=_ptr(ln_b), n_real=n_real, ln_eps=ln_eps, res_scale=res_scale, out=_ptr(out), ldo=out.stride(0))
+    with _timed("mlp"):
+        L.check(L.lib().grl_mlp_fwd(L.stream_ptr(), C.byref(args)), "grl_mlp_fwd")
+    return out
+
+
 @dataclass
 class TokenGrid:
     """A bf16 token tensor viewed as windows: mirrors GrlTokenGrid.

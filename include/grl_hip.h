@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 6
+#define GRL_ABI_VERSION 7
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -69,6 +69,39 @@ typedef struct GrlLinearArgs {
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused transformer MLP:  out = x + res_scale * LayerNorm(fc2(GELU(fc1(x))))  in one pass over x.
+ *   replaces  Mlp.forward             models/common/swin_v1_block.py:37-43
+ *             norm2 + residual         models/common/mixed_attn_block_efficient.py:554
+ * The hidden activations never reach HBM and x is read once.  The weights arrive as a chunk stream ("blob"),
+ * one chunk per 32 hidden channels c = 0 .. Hpad/32-1.  A chunk is the LDS image the kernel DMAs into its ring:
+ *     W1c  32 rows x (2*Cpad + 16) bytes   fp16 rows 32c .. 32c+31 of fc1.weight (zero padded), columns in
+ *                                          k-slot order per 32-group, 16 pad bytes per row
+ *     W2c  Cpad rows x (64 + 16) bytes     fp16 columns of fc2.weight for the chunk's hidden channels in
+ *                                          k-slot order, 16 pad bytes per row
+ *     b1c  32 fp32                         fc1.bias for the chunk
+ *   padded to a multiple of 1024 bytes; k-slot order of a 32-group: slot 8g+e <-> element 4g+e (e < 4),
+ *   16+4g+e-4 (e >= 4) -- the 16x16x32 MFMA accumulator fragment of one layer is then the operand fragment of
+ *   the next.  grl_mlp_blob_bytes gives the total size; ops.pack_mlp builds it; the blob must be 16-B aligned.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GrlMlpArgs {
+    const float* x;         /* [M, ldx] fp32 input, also the residual                               */
+    int64_t ldx;
+    const void* blob;       /* weight chunk stream, see above                                       */
+    int32_t M, Cpad, Hpad;  /* Cpad in {64, 128, 192}; Hpad % 32 == 0                               */
+    const float* b2;        /* [Cpad] fc2.bias                                                      */
+    const float* ln_g;      /* [Cpad] norm2 weight / bias; n_real real channels                     */
+    const float* ln_b;
+    int32_t n_real;
+    float ln_eps;
+    float res_scale;
+    float* out;             /* [M, ldo] fp32, pad channels written as 0; must not alias x           */
+    int64_t ldo;
+} GrlMlpArgs;
+
+int grl_mlp_fwd(void* stream, const GrlMlpArgs* args);
+int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad);
 
 /* ---------------------------------------------------------------------------------------------
  * Cosine window / anchored-stripe attention (one call = one softmax(QK^T)V over all windows).

@@ -83,6 +83,43 @@ def test_linear_ln_residual_and_gelu(M, K, N, nreal):
     assert (outg.cpu().double() - refg).abs().max() < 2e-2
 
 
+@pytest.mark.parametrize("M,C,Hd", [(1000, 180, 360), (4099, 180, 360), (777, 128, 256), (300, 64, 128), (50, 60, 120)])
+def test_fused_mlp(M, C, Hd):
+    """grl_mlp_fwd = Mlp.forward (swin_v1_block.py:37-43) + norm2 + residual (efficient.py:554) in one kernel,
+    against fp64 torch on the fp16-rounded operands, and against the two-kernel path (fc1+GELU, fc2+LN)."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    CP, HP = (C + 31) // 32 * 32, (Hd + 31) // 32 * 32
+    g = torch.Generator().manual_seed(11)
+    x = torch.zeros(M, CP)
+    x[:, :C] = torch.randn(M, C, generator=g)
+    w1 = torch.randn(Hd, C, generator=g) / math.sqrt(C)
+    b1 = 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(C, Hd, generator=g) / math.sqrt(Hd)
+    b2 = torch.zeros(CP); b2[:C] = 0.1 * torch.randn(C, generator=g)
+    gam = torch.zeros(CP); gam[:C] = 1 + 0.1 * torch.randn(C, generator=g)
+    bet = torch.zeros(CP); bet[:C] = 0.1 * torch.randn(C, generator=g)
+    h16 = lambda t: t.to(torch.float16).double()
+    hid = F.gelu(h16(x[:, :C]) @ h16(w1).t() + b1.double())
+    y = h16(hid) @ h16(w2).t() + b2[:C].double()
+    ref = x[:, :C].double() + 0.5 * F.layer_norm(y, (C,), gam[:C].double(), bet[:C].double(), 1e-5)
+    d = _dev()
+    blob = ops.pack_mlp(w1.to(d), b1.to(d), w2.to(d), CP, HP)
+    out = ops.mlp(x.to(d), blob, b2.to(d), gam.to(d), bet.to(d), Hpad=HP, n_real=C, res_scale=0.5).cpu()
+    err = (out[:, :C].double() - ref).abs().max().item()
+    assert err < 2e-3, err
+    if C < CP:
+        assert out[:, C:].abs().max().item() == 0.0
+    # two-kernel path on the same operands
+    W1 = torch.zeros(HP, CP); W1[:Hd, :C] = w1
+    W2 = torch.zeros(CP, HP); W2[:C, :Hd] = w2
+    B1 = torch.zeros(HP); B1[:Hd] = b1
+    hbuf = ops.linear(x.to(d), W1.to(torch.float16).to(d), B1.to(d), epi=L.EPI_GELU)
+    out2 = ops.linear(hbuf, W2.to(torch.float16).to(d), b2.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=gam.to(d),
+                      ln_b=bet.to(d), n_real=C, res_scale=0.5, resid=x.to(d)).cpu()
+    assert (out - out2).abs().max().item() < 1e-3
+
+
 def test_linear_pooled_anchor():
     """AnchorLinear: avg-pool df x df (mixed_attn_block.py:727-736) fused into the A load."""
     from grl_image_restoration_amd import _lib as L, ops

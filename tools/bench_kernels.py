@@ -80,6 +80,8 @@ def main():
                                        ln_b=pk["n1_b"], n_real=C, resid=r, add2=cab, add2_scale=gate, rows_per_image=H * W),
                     2 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4)),
         "fc1_gelu": (lambda: ops.linear(r, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out=h), 4 * L_ * C * C * B, M * (CP * 4 + 384 * 2)),
+        "mlp_fused": (lambda: ops.mlp(r, pk["mlp_blob"], pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C),
+                      8 * L_ * C * C * B, M * (CP * 4 * 2)),
         "fc2_ln": (lambda: ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
                                       ln_b=pk["n2_b"], n_real=C, resid=r), 4 * L_ * C * C * B, M * (384 * 2 + CP * 8)),
         "stage_conv": (lambda: ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=r), 18 * L_ * C * C * B, M * CP * 12),
