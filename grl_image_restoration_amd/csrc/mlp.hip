@@ -56,12 +56,22 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
     const int nchunks = p.Hpad / 32;
     const char* blob = (const char*)p.blob;
 
-    auto fetch = [&](int chunk, char* buf) {   // this wave's share of the chunk image: pieces wave, wave + WV, ...
+    // Chunk DMA: this wave's share of the image, pieces wave, wave + WV, ... (1 KiB each, lane * 16 B implicit).
+    // Issued as inline asm on purpose: with the builtin the compiler knows the instruction writes LDS and drains
+    // vmcnt(0) in front of the next ds_read, i.e. it waits for the prefetch it has just issued.  Hidden from the
+    // compiler, the DMA is ordered by hand: a counted s_waitcnt before the barrier that publishes the chunk.
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    auto fetch = [&](int chunk, int buf_off) {
         const char* src = blob + (size_t)chunk * S::BUFP + lane * 16;
 #pragma unroll
         for (int q0 = 0; q0 < S::PIECES; q0 += WV) {
-            const int q = q0 + wave;
-            if (q < S::PIECES) __builtin_amdgcn_global_load_lds((gbl_ptr_t)(src + q * 1024), (lds_ptr_t)(buf + q * 1024), 16, 0, 0);
+            const int q = q0 + wave_u;
+            if (q < S::PIECES) {
+                const uint32_t m0v = lds0 + buf_off + q * 1024;
+                const char* g = src + q * 1024;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
+            }
         }
     };
 
@@ -70,51 +80,70 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
     // fc2 bias and the norm affine live in LDS behind the ring (read once per tile by every lane)
     float* vec = (float*)(smem + 2 * S::BUFP);
     for (int i = tid; i < 3 * CP; i += THREADS) vec[i] = i < CP ? p.b2[i] : (i < 2 * CP ? p.ln_g[i - CP] : p.ln_b[i - 2 * CP]);
-    fetch(0, smem);
-    int it = 0;   // running chunk counter of the ring (chunk = it % nchunks, buffer = it & 1)
 
-    // token slab of a tile (fp32): lane = token r16; its 8 k-slots of k-step s are the channels 32s + 4*g4 + [0..3]
-    // and 32s + 16 + 4*g4 + [0..3] -- the accumulator layout of n-tiles 2s / 2s+1 (W1's columns are packed in the
-    // same slot order), so the registers that feed fc1 also provide the residual of the epilogue: x is read once.
-    float4 xs[KSTEPS][2], xn[KSTEPS][2];
-    auto load_slab = [&](int tile, float4 (&x)[KSTEPS][2]) {
-        int m = tile * (WV * 16) + wave * 16 + r16;
-        m = m < p.M ? m : p.M - 1;
-        const float* base = p.x + (int64_t)m * p.ldx + 4 * g4;
-#pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            x[s][0] = *(const float4*)(base + 32 * s);
-            x[s][1] = *(const float4*)(base + 32 * s + 16);
-        }
+    // Token tile staging: the fp32 rows of the NEXT tile are DMA'd into LDS (rows padded by 16 B) in 1-KiB pieces
+    // spread evenly over the chunk iterations of the current tile, so HBM reads run beside the MFMAs instead of in a
+    // burst at the tile boundary, and cost no registers.
+    constexpr int XROW = CP * 4 + 16, XSEG = XROW / 16;             // bytes / 16-B segments per staged row
+    constexpr int XPIECES = (WV * 16 * XROW + 1023) / 1024;
+    const int xoff = 2 * S::BUFP + 3 * CP * 4;                       // LDS offset of the token tile
+    auto fetch_x = [&](int tile, int piece) {                        // piece: wave-uniform
+        const int sigma = piece * 64 + lane;                         // LDS segment this lane fills
+        int row = sigma / XSEG, seg = sigma - row * XSEG;
+        seg = seg < XSEG - 1 ? seg : XSEG - 2;                       // the pad segment repeats the last real one
+        int m = tile * (WV * 16) + row;
+        m = m < p.M ? m : p.M - 1;                                   // rows past the end (and past the tile) stay in range
+        const float* g = p.x + (int64_t)m * p.ldx + seg * 4;
+        const uint32_t m0v = lds0 + xoff + piece * 1024;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
     };
-    load_slab(blockIdx.x, xn);
+    const char* xt = smem + xoff;
+
+    for (int q = wave_u; q < XPIECES; q += WV) fetch_x(blockIdx.x, q);
+    fetch(0, 0);
+    int it = 0;   // running chunk counter of the ring (chunk = it % nchunks, buffer = it & 1)
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m = tile * (WV * 16) + wave * 16 + r16;
         const bool valid = m < p.M;
+        // the tile's rows have landed (own pieces: vmcnt, everybody's: barrier).  Lane = token r16; its 8 k-slots of
+        // k-step s are the channels 32s + 4*g4 + [0..3] and 32s + 16 + 4*g4 + [0..3] -- the accumulator layout of n-tiles
+        // 2s / 2s+1 (W1's columns are packed in the same slot order), so the registers that feed fc1 also provide the
+        // residual of the epilogue: x is read from HBM exactly once.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float4 xs[KSTEPS][2];
         gemm_x8 a[KSTEPS];
+        {
+            const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
 #pragma unroll
-        for (int s = 0; s < KSTEPS; ++s) {
-            xs[s][0] = xn[s][0];
-            xs[s][1] = xn[s][1];
-            gemm_x8 v;
-            v[0] = (gemm_t)xs[s][0].x; v[1] = (gemm_t)xs[s][0].y; v[2] = (gemm_t)xs[s][0].z; v[3] = (gemm_t)xs[s][0].w;
-            v[4] = (gemm_t)xs[s][1].x; v[5] = (gemm_t)xs[s][1].y; v[6] = (gemm_t)xs[s][1].z; v[7] = (gemm_t)xs[s][1].w;
-            a[s] = v;
+            for (int s = 0; s < KSTEPS; ++s) {
+                xs[s][0] = *(const float4*)(rowp + 128 * s);
+                xs[s][1] = *(const float4*)(rowp + 128 * s + 64);
+            }
+#pragma unroll
+            for (int s = 0; s < KSTEPS; ++s) {
+                gemm_x8 v;
+                v[0] = (gemm_t)xs[s][0].x; v[1] = (gemm_t)xs[s][0].y; v[2] = (gemm_t)xs[s][0].z; v[3] = (gemm_t)xs[s][0].w;
+                v[4] = (gemm_t)xs[s][1].x; v[5] = (gemm_t)xs[s][1].y; v[6] = (gemm_t)xs[s][1].z; v[7] = (gemm_t)xs[s][1].w;
+                a[s] = v;
+            }
         }
         f32x4 acc[NT2];
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) acc[nt] = f32x4{0, 0, 0, 0};
-        const int next_tile = tile + (int)gridDim.x < ntiles ? tile + (int)gridDim.x : tile;
+        const int next_tile = tile + (int)gridDim.x;   // may lie past the end: rows are clamped, the data is never read
 
 #pragma unroll 1
         for (int c = 0; c < ((dbg & 16) ? 1 : nchunks); ++c, ++it) {
-            // every wave waits for its own DMA pieces of chunk `it` (vmcnt) before the barrier publishes them;
-            // after the barrier nobody reads buffer (it+1)&1 any more, so the next chunk may land there
-            if (!(dbg & 2)) __syncthreads();
+            // Every wave waits for its own DMA pieces (chunk `it` and the token pieces of the previous iteration) before
+            // the barrier publishes them; after the barrier nobody reads ring buffer (it+1)&1 any more -- and, at c == 0,
+            // everybody has copied its token rows into registers -- so the next DMAs may land.
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: my LDS reads of the token tile / last chunk are done
+            if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
             char* cur = smem + (it & 1) * S::BUFP;
-            if (!(dbg & 1)) fetch(c + 1 < nchunks ? c + 1 : 0, smem + ((it + 1) & 1) * S::BUFP);
-            if (c == nchunks / 2) load_slab(next_tile, xn);   // lands during the second half of the sweep
+            if (!(dbg & 1)) fetch(c + 1 < nchunks ? c + 1 : 0, ((it + 1) & 1) * S::BUFP);
+            for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) fetch_x(next_tile, q);
 
             // ---- h = GELU(W1_c . x + b1_c): two n-tiles of 16 hidden channels ----
             // LDS fragment reads are issued in batches ahead of the MFMAs that consume them (the compiler
@@ -213,7 +242,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
 template <int KSTEPS, int WV>
 int launch_mlp(const GrlMlpArgs& p, hipStream_t st) {
     using S = MlpShape<KSTEPS>;
-    const size_t lds = 2 * (size_t)S::BUFP + 3 * S::CP * sizeof(float);
+    const size_t lds = 2 * (size_t)S::BUFP + 3 * S::CP * sizeof(float) + (size_t)((WV * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
     const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
     const int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU
     auto kfn = mlp_kernel<KSTEPS, WV>;

@@ -113,7 +113,7 @@ def test_ctypes_layout_matches_the_c_header(tmp_path):
     import subprocess
 
     structs = {"GrlLinearArgs": _lib.GrlLinearArgs, "GrlTokenGrid": _lib.GrlTokenGrid, "GrlAttnArgs": _lib.GrlAttnArgs,
-               "GrlConvArgs": _lib.GrlConvArgs}
+               "GrlConvArgs": _lib.GrlConvArgs, "GrlMlpArgs": _lib.GrlMlpArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "grl_hip.h"', 'int main(void) {']
     for name, st in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
@@ -148,3 +148,35 @@ def test_ctypes_structs_refuse_unknown_fields():
         _lib.GrlConvArgs(Cin_pad=3)
     a = _lib.GrlConvArgs(CinP=64, CoutP=192, w_tap_stride=5)
     assert a.CinP == 64 and a.CoutP == 192 and a.w_tap_stride == 5
+
+
+def test_mlp_blob_layout():
+    """ops.pack_mlp writes the chunk images include/grl_hip.h documents (W1 rows | W2 columns | b1, padded rows,
+    k-slot order 8g+e <-> 4g+e / 16+4g+e-4); checked by un-permuting the blob on the host."""
+    from grl_image_restoration_amd import ops
+
+    C_, Hd, CP, HP = 60, 120, 64, 128
+    g = torch.Generator().manual_seed(5)
+    w1, b1, w2 = torch.randn(Hd, C_, generator=g), torch.randn(Hd, generator=g), torch.randn(C_, Hd, generator=g)
+    blob = ops.pack_mlp(w1, b1, w2, CP, HP)
+    nch = HP // 32
+    assert blob.dtype == torch.uint8 and blob.shape[0] == nch and blob.numel() == _lib.lib().grl_mlp_blob_bytes(CP, HP)
+    assert blob.shape[1] % 1024 == 0
+    slot_chan = [4 * (s // 8) + s % 8 if s % 8 < 4 else 16 + 4 * (s // 8) + s % 8 - 4 for s in range(32)]
+    w1row, w2row = CP * 2 + 16, 80
+    for c in range(nch):
+        img = blob[c]
+        W1 = img[: 32 * w1row].view(32, w1row)[:, : CP * 2].contiguous().view(torch.float16).view(32, CP // 32, 32)
+        W2 = img[32 * w1row : 32 * w1row + CP * w2row].view(CP, w2row)[:, :64].contiguous().view(torch.float16)
+        B1 = img[32 * w1row + CP * w2row :][:128].contiguous().view(torch.float32)
+        ref1 = torch.zeros(32, CP)
+        rows = min(32, max(0, Hd - 32 * c))
+        ref1[:rows, :C_] = w1[32 * c : 32 * c + rows]
+        ref2 = torch.zeros(CP, 32)
+        ref2[:C_, :rows] = w2[:, 32 * c : 32 * c + rows]
+        refb = torch.zeros(32)
+        refb[:rows] = b1[32 * c : 32 * c + rows]
+        for s_, ch in enumerate(slot_chan):
+            assert torch.equal(W1[:, :, s_], ref1.view(32, CP // 32, 32)[:, :, ch].to(torch.float16))
+            assert torch.equal(W2[:, s_], ref2[:, ch].to(torch.float16))
+        assert torch.equal(B1, refb)
