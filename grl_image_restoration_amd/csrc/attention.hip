@@ -350,8 +350,21 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     char* Vt = Ks + FKC * 64;
     unsigned char* kreg = (unsigned char*)(Vt + 32 * FVROW);
 
-    // the table arrives REVERSED (see grl_hip.h) so that a lane's 16 key rows read ascending addresses
-    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, FW * 64);
+    // the table arrives REVERSED (see grl_hip.h) so that a lane's 16 key rows read ascending addresses.
+    // It is DMA'd (global_load_lds, 1 KiB per wave-instruction, no staging registers): all pieces are in flight at
+    // once and overlap the first K/V chunk's loads; the barrier in front of the first LDS commit waits for them.
+    // A last partial piece re-reads the final 16 bytes; its tail lands in the K staging area, which is written later.
+    {
+        const int n4 = (p.trows + 3) >> 2;
+        const float4* s4 = (const float4*)(p.table + (int64_t)head * p.tstride);
+        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+        for (int q = wave_u; q * 64 < n4; q += FW) {
+            int i = q * 64 + lane;
+            i = i < n4 ? i : n4 - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s4 + i),
+                                             (__attribute__((address_space(3))) void*)(tab + q * 256), 16, 0, 0);
+        }
+    }
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
 
     // ---- this wave's unit: query rows QTN*pr .. QTN*pr+QTN-1, segment sg ----
