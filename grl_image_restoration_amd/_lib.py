@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -19,6 +19,8 @@ EXPORTS = [
     "grl_linear_fwd",
     "grl_mlp_fwd",
     "grl_mlp_blob_bytes",
+    "grl_qkv_fwd",
+    "grl_qkv_blob_bytes",
     "grl_attention_fwd",
     "grl_layernorm_fwd",
     "grl_conv3x3_fwd",
@@ -90,6 +92,19 @@ class GrlMlpArgs(_Strict):
         ("res_scale", C.c_float),
         ("out", C.c_void_p),
         ("ldo", C.c_int64),
+    ]
+
+
+class GrlQkvArgs(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("blob", C.c_void_p),
+        ("M", C.c_int32),
+        ("Cpad", C.c_int32),
+        ("nslots", C.c_int32),
+        ("out", C.c_void_p),
+        ("out_plane_stride", C.c_int64),
     ]
 
 
@@ -182,6 +197,10 @@ def lib():
     L.grl_mlp_fwd.restype = C.c_int
     L.grl_mlp_blob_bytes.argtypes = [C.c_int32, C.c_int32]
     L.grl_mlp_blob_bytes.restype = C.c_int64
+    L.grl_qkv_fwd.argtypes = [C.c_void_p, C.POINTER(GrlQkvArgs)]
+    L.grl_qkv_fwd.restype = C.c_int
+    L.grl_qkv_blob_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.grl_qkv_blob_bytes.restype = C.c_int64
     L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
     L.grl_attention_fwd.restype = C.c_int
     L.grl_layernorm_fwd.argtypes = [

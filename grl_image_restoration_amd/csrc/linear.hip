@@ -329,7 +329,8 @@ int launch_shape(const GrlLinearArgs& p, hipStream_t st) {
     const size_t lds = (size_t)p.Npad * (KSTEPS * 64 + 16);
     if (lds > LDS_BUDGET) return GRL_ERR_UNSUPPORTED;
     const int ntiles = (p.M + ROWS_PER_WG - 1) / ROWS_PER_WG;
-    const int grid = ntiles < 256 ? ntiles : 256;  // one persistent workgroup per CU
+    static const int cap = getenv("GRL_PERSIST_GRID") ? atoi(getenv("GRL_PERSIST_GRID")) : 256;  // tuning knob
+    const int grid = ntiles < cap ? ntiles : cap;  // one persistent workgroup per CU
     auto kfn = linear_kernel<KSTEPS, NT, NCH, EPI, ADD2, MT, WV>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

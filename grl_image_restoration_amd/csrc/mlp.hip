@@ -244,7 +244,8 @@ int launch_mlp(const GrlMlpArgs& p, hipStream_t st) {
     using S = MlpShape<KSTEPS>;
     const size_t lds = 2 * (size_t)S::BUFP + 3 * S::CP * sizeof(float) + (size_t)((WV * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
     const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
-    const int grid = ntiles < 256 ? ntiles : 256;   // one persistent workgroup per CU
+    static const int cap = getenv("GRL_PERSIST_GRID") ? atoi(getenv("GRL_PERSIST_GRID")) : 256;   // tuning knob
+    const int grid = ntiles < cap ? ntiles : cap;   // one persistent workgroup per CU
     auto kfn = mlp_kernel<KSTEPS, WV>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;

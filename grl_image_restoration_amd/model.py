@@ -362,6 +362,8 @@ class GRL(nn.Module):
                         gs[g] = 1.0 if br == 0 else sc_1[h] * LOG2E
         G16 = ops.GEMM_DTYPE
         pk = dict(qkv_w=Wp.to(G16), qkv_b=bp, qkv_gs=gs, fixed=fixed)
+        if CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
+            pk.update(qkv_blob=ops.pack_qkv(Wp, bp, gs), qkv_slots=G)
 
         # --- anchor projection (avg-pool fused in the kernel) ---
         Wa = a.anchor.body[0].reduction.weight.detach().float()
@@ -528,7 +530,10 @@ class GRL(nn.Module):
             side.wait_stream(main)
             with torch.cuda.stream(side):
                 cab, gate = self._cab(r, pk, B, H, W, CP)
-        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+        if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
+            qkv = ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"])
+        else:
+            qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
         anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
         att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
         y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=torch.bfloat16, device=dev)

@@ -169,6 +169,52 @@ def pack_mlp(fc1_w: torch.Tensor, fc1_b: torch.Tensor, fc2_w: torch.Tensor, Cpad
     return blob.contiguous()
 
 
+def _kslot_perm(dev):
+    """k-slot sigma = 8g + e of a 32-group -> element 4g + e (e < 4) | 16 + 4g + (e - 4)  (csrc/mlp.hip, csrc/qkv.hip)."""
+    sig = torch.arange(32, device=dev)
+    g, e = sig // 8, sig % 8
+    return torch.where(e < 4, 4 * g + e, 16 + 4 * g + (e - 4))
+
+
+def pack_qkv(w: torch.Tensor, bias: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
+    """Weight stream of grl_qkv_fwd from the slotted QKV matrix w [nslots*32, Cpad] (any float dtype), bias
+    [nslots*32] and gscale [nslots] (layout in include/grl_hip.h).  Returns a uint8 device tensor."""
+    dev = w.device
+    N, Cpad = w.shape
+    nslots = N // 32
+    assert N % 32 == 0 and Cpad % 32 == 0 and bias.numel() == N and gscale.numel() == nslots
+    spc = 2 if nslots % 2 == 0 else 1
+    total = L.lib().grl_qkv_blob_bytes(Cpad, nslots)
+    assert total > 0
+    nch = nslots // spc
+    wrow = Cpad * 2 + 16
+    slot_b = 32 * wrow + 128 + 16
+    chan = _kslot_perm(dev)
+    wp = w.detach().float().view(nslots, 32, Cpad // 32, 32)[..., chan].reshape(nslots, 32, Cpad).to(GEMM_DTYPE).contiguous()
+    img = torch.zeros(nslots, slot_b, dtype=torch.uint8, device=dev)
+    img[:, : 32 * wrow].view(nslots, 32, wrow)[:, :, : Cpad * 2] = wp.view(torch.uint8).view(nslots, 32, Cpad * 2)
+    img[:, 32 * wrow : 32 * wrow + 128] = bias.detach().float().view(nslots, 32).contiguous().view(torch.uint8).view(nslots, 128)
+    img[:, 32 * wrow + 128 : 32 * wrow + 132] = gscale.detach().float().view(nslots, 1).contiguous().view(torch.uint8).view(nslots, 4)
+    blob = torch.zeros(nch, total // nch, dtype=torch.uint8, device=dev)
+    blob[:, : spc * slot_b] = img.view(nch, spc * slot_b)
+    return blob.contiguous()
+
+
+def qkv(x: torch.Tensor, blob: torch.Tensor, nslots: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Head planes [nslots, M, 32] (bf16) of the slotted, normalised QKV projection of x [M, Cpad] (fp32)."""
+    _dev_check(x, blob, out)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and blob.dtype == torch.uint8 and blob.is_contiguous()
+    M, Cpad = x.shape
+    if out is None:
+        out = torch.empty(nslots, M, 32, dtype=torch.bfloat16, device=x.device)
+    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (nslots, M, 32)
+    args = L.GrlQkvArgs(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), M=M, Cpad=Cpad, nslots=nslots, out=_ptr(out),
+                        out_plane_stride=M * 32)
+    with _timed("qkv"):
+        L.check(L.lib().grl_qkv_fwd(L.stream_ptr(), C.byref(args)), "grl_qkv_fwd")
+    return out
+
+
 def mlp(x: torch.Tensor, blob: torch.Tensor, b2: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, *, Hpad: int,
         n_real: int, ln_eps: float = 1e-5, res_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = x + res_scale * LayerNorm(fc2(GELU(fc1(x)))) on the token matrix x [M, Cpad] (fp32), one kernel."""

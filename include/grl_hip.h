@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 7
+#define GRL_ABI_VERSION 8
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -102,6 +102,28 @@ typedef struct GrlMlpArgs {
 
 int grl_mlp_fwd(void* stream, const GrlMlpArgs* args);
 int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad);
+
+/* ---------------------------------------------------------------------------------------------
+ * Streaming QKV projection: head planes out[slot][m][0..31] (bf16) = groupnorm(x[m,:] . W_slot^T + b_slot),
+ * one pass over x for any number of slots (the weights-resident grl_linear_fwd needs column slabs above 160 KB).
+ *   replaces  QKVProjection.forward   models/common/mixed_attn_block.py:669-676
+ *             F.normalize + logit scale of Attention.attn   models/common/mixed_attn_block_efficient.py:39,85-90
+ * A slot = 32 output columns (one head of q, k or v; see grl_attention_fwd).  Weight stream ("blob"): chunks of
+ * 2 slots (1 if nslots is odd), each slot image = 32 rows x (2*Cpad + 16) bytes fp16 (columns in the k-slot order
+ * of GrlMlpArgs, 16 pad bytes per row) | bias 32 fp32 | gscale fp32 + 12 pad bytes; chunk padded to 1024 bytes.
+ * gscale as in GRL_EPI_GROUPNORM: != 0 -> L2-normalise the slot and multiply, == 0 -> pass through.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GrlQkvArgs {
+    const float* x;            /* [M, ldx] fp32 tokens                                               */
+    int64_t ldx;
+    const void* blob;          /* see above; 16-B aligned; grl_qkv_blob_bytes(Cpad, nslots) bytes    */
+    int32_t M, Cpad, nslots;   /* Cpad in {64, 128, 192}                                             */
+    void* out;                 /* bf16 planes: element (m, slot, c) at slot*out_plane_stride + m*32 + c */
+    int64_t out_plane_stride;  /* >= M*32                                                            */
+} GrlQkvArgs;
+
+int grl_qkv_fwd(void* stream, const GrlQkvArgs* args);
+int64_t grl_qkv_blob_bytes(int32_t Cpad, int32_t nslots);
 
 /* ---------------------------------------------------------------------------------------------
  * Cosine window / anchored-stripe attention (one call = one softmax(QK^T)V over all windows).

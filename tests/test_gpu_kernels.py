@@ -120,6 +120,32 @@ def test_fused_mlp(M, C, Hd):
     assert (out - out2).abs().max().item() < 1e-3
 
 
+@pytest.mark.parametrize("M,C,nslots", [(1000, 180, 18), (4099, 180, 18), (700, 128, 12), (300, 64, 12), (333, 60, 3)])
+def test_streaming_qkv(M, C, nslots):
+    """grl_qkv_fwd against the weights-resident GROUPNORM linear on the same operands (bit-level agreement is not
+    required: accumulation order differs) and against fp64 torch."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    CP = (C + 31) // 32 * 32
+    g = torch.Generator().manual_seed(12)
+    x = torch.zeros(M, CP)
+    x[:, :C] = torch.randn(M, C, generator=g)
+    w = torch.zeros(nslots * 32, CP)
+    w[:, :C] = torch.randn(nslots * 32, C, generator=g) / math.sqrt(C)
+    b = 0.1 * torch.randn(nslots * 32, generator=g)
+    gs = torch.rand(nslots, generator=g) * 10
+    gs[2::3] = 0.0  # pass-through slots (v)
+    d = _dev()
+    out = ops.qkv(x.to(d), ops.pack_qkv(w.to(d), b.to(d), gs.to(d)), nslots).cpu()
+    ref = (x.to(torch.float16).double() @ w.to(torch.float16).double().t() + b.double()).view(M, nslots, 32)
+    nrm = ref.norm(dim=-1, keepdim=True).clamp_min(1e-12)
+    ref = torch.where(gs.view(1, -1, 1) != 0, ref / nrm * gs.view(1, -1, 1).double(), ref).permute(1, 0, 2)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2e-2 * max(1.0, ref.abs().max().item() / 2), err
+    old = ops.linear(x.to(d), w.to(torch.float16).to(d), b.to(d), epi=L.EPI_GROUPNORM, gscale=gs.to(d), planes=True).cpu()
+    assert (out.float() - old.float()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item() / 2)
+
+
 def test_linear_pooled_anchor():
     """AnchorLinear: avg-pool df x df (mixed_attn_block.py:727-736) fused into the A load."""
     from grl_image_restoration_amd import _lib as L, ops

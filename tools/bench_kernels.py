@@ -60,6 +60,7 @@ def main():
     fl_s = 2 * L_ * N2 * C * B
 
     kernels = {
+        "qkv_stream": (lambda: ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"], out=qkv), 6 * L_ * C * C * B, M * (CP * 4 + 18 * 32 * 2)),
         "qkv": (lambda: ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv, planes=True),
                 6 * L_ * C * C * B, M * (CP * 4 + 576 * 2)),
         "anchor": (lambda: ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), out=anc, planes=True),
