@@ -641,8 +641,38 @@ class GRL(nn.Module):
     def _image(t, B, H, W, C):
         return t.view(B, H, W, -1)[..., :C].permute(0, 3, 1, 2)
 
+    def enable_graph(self, flag: bool = True):
+        """Replay the whole forward as one captured HIP graph per input shape.  A forward is ~500
+        kernel launches; at one 256x256 tile the eager path is bound by the host issuing them, the graph is not.
+        Weights must not change while graphs are cached (call ``enable_graph(False)`` / ``enable_graph()`` to drop them).
+        """
+        self._use_graph = bool(flag)
+        self._graphs = {}
+        return self
+
     def forward(self, x):
-        """grl.py:506-551."""
+        """grl.py:506-551.  Eager launch sequence, or a captured HIP graph (``enable_graph`` / GRL_GRAPH=1)."""
+        if getattr(self, "_use_graph", None) is None:
+            self._use_graph, self._graphs = os.environ.get("GRL_GRAPH", "0") == "1", {}
+        if not (self._use_graph and x.is_cuda) or ops.profiling():
+            return self._forward_eager(x)
+        key = (tuple(x.shape), x.dtype, str(x.device))
+        ent = self._graphs.get(key)
+        if ent is None:
+            with torch.no_grad():
+                self._forward_eager(x)                     # builds the plan, warms the allocator and kernel attributes
+                torch.cuda.synchronize(x.device)
+                static_in = x.clone()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    static_out = self._forward_eager(static_in)
+            ent = self._graphs[key] = (static_in, graph, static_out)
+        static_in, graph, static_out = ent
+        static_in.copy_(x)
+        graph.replay()
+        return static_out.clone()                          # the engine clamps its output in place (utils_image.py:31)
+
+    def _forward_eager(self, x):
         if not x.is_cuda:
             raise RuntimeError(
                 "grl_image_restoration_amd.GRL runs only on an AMD GPU (MI355X/gfx950): got a CPU tensor and "

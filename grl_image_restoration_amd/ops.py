@@ -4,6 +4,7 @@ These functions only validate tensors and fill the argument structs; all arithme
 the HIP kernels.  Inputs must be CUDA (ROCm) tensors -- there is no CPU path.
 """
 import ctypes as C
+import os
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -23,6 +24,10 @@ def profile_begin():
     """Start collecting (start, stop) event pairs around every C-ABI kernel launch."""
     global _PROFILE
     _PROFILE = {}
+
+
+def profiling() -> bool:
+    return _PROFILE is not None
 
 
 def profile_end():
@@ -345,7 +350,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
         pool = torch.empty(nwg, CoutP, dtype=torch.float32, device=x.device)
     # at most 192 output channels per launch; larger layers are split on the channel axis
     step = CoutP
-    if CoutP > 192:
+    split = int(os.environ.get("GRL_CONV_SPLIT", "0"))   # experiment: narrower launches -> 2 workgroups per CU
+    if split and CoutP > split and CoutP % split == 0 and shuffle_r <= 1:
+        step = split
+    elif CoutP > 192:
         step = max(s for s in (192, 128, 96, 64, 48, 32, 16) if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0))
     for c0 in range(0, CoutP, step):
         args = L.GrlConvArgs(
