@@ -32,7 +32,7 @@ constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 // per-tap double buffer because the larger LDS footprint leaves one workgroup per CU; kept as an opt-in
 // (GRL_CONV_ALLTAPS=1) experiment.
 template <int KC, int NT, bool ALLTAPS>
-__global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
+__global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int dbg) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = KC * 2 + 16;                 // padded row (bytes) for pixels and weight rows
     constexpr int KS = KC / 32;                       // MFMA k-steps per chunk
@@ -152,14 +152,14 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
         for (int kc = 0; kc < nkc; ++kc) {
             load_w(0, kc);
             __syncthreads();  // previous chunk's readers are done with in_s / wt_s
-            stage_input(kc);
+            if (!(dbg & 8)) stage_input(kc);
             store_w(0);
             __syncthreads();
             for (int tap = 0; tap < 9; ++tap) {
-                if (tap < 8) load_w(tap + 1, kc);  // in flight during the MFMAs below
-                mfma_tap(tap, wt_s + (tap & 1) * WT_BYTES);
+                if (tap < 8 && !(dbg & 2)) load_w(tap + 1, kc);  // in flight during the MFMAs below
+                if (!(dbg & 1)) mfma_tap(tap, wt_s + (tap & 1) * WT_BYTES);
                 if (tap < 8) {
-                    store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
+                    if (!(dbg & 2)) store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
                     __syncthreads();
                 }
             }
@@ -167,14 +167,63 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
     }
 
     // ---- epilogue: lane owns channels 16*nt + 4*g4 + [0..3] of pixel (y0+wave, x0+16*mt+r16) ----
+    if (dbg & 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 1.f; return; }
     const int gy = y0 + wave;
     float psum[NT][4];
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) psum[nt][e] = 0.f;
+
+    // 16-bit outputs without pixel shuffle (CAB convs, conv_before_upsample): the tile is packed into LDS as
+    // [pixel][CoutP] rows and written back with whole-row 16-B stores -- a tile row (32 pixels) is contiguous in the
+    // token matrix.  Storing from the accumulator layout instead costs 2*NT instructions of 16 x 32-B pieces per wave
+    // (measured: 55 % of the CAB conv2 kernel).
+    const bool staged = p.out_dtype != GRL_DT_F32 && p.shuffle_r <= 1 && p.resid == nullptr;
+    constexpr int OROW = NT * 32 + 16;   // bytes per staged pixel row (16 B pad: conflict-free 8-B writes)
+    if (staged) {
+        __syncthreads();   // all MFMA-phase readers of in_s / wt_s are done: the space is reused for the tile
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < 2; ++mt) {
+            const int gx = x0 + 16 * mt + r16;
+            const bool valid = gy < p.H && gx < p.W;
+            char* prow = smem + (wave * TW + 16 * mt + r16) * OROW;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const int c = 16 * nt + 4 * g4;
+                const float4 b4 = *(const float4*)(p.bias + c);
+                float v[4] = {acc[mt][nt][0] + b4.x, acc[mt][nt][1] + b4.y, acc[mt][nt][2] + b4.z, acc[mt][nt][3] + b4.w};
+                if (p.act == 1) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+                } else if (p.act == 2) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
+                }
+                if (valid) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) psum[nt][e] += v[e];
+                }
+                uint2 pk;
+                pk.x = pack16(v[0], v[1], p.out_dtype);
+                pk.y = pack16(v[2], v[3], p.out_dtype);
+                *(uint2*)(prow + c * 2) = pk;
+            }
+        }
+        __syncthreads();
+        constexpr int SEGS = NT * 2;   // 16-B segments per pixel row
+        for (int i = tid; i < TH * TW * SEGS; i += CWAVES * 64) {
+            const int px = i / SEGS, sg = i - px * SEGS;
+            const int ty = px / TW, tx = px - ty * TW;
+            const int oy = y0 + ty, ox = x0 + tx;
+            if (oy < p.H && ox < p.W) {
+                const int64_t row = ((int64_t)b * p.H + oy) * p.W + ox;
+                *(uint4*)((gemm_t*)p.out + row * p.ldo + sg * 8) = *(const uint4*)(smem + px * OROW + sg * 16);
+            }
+        }
+    }
+#pragma unroll
+    for (int mt = 0; mt < (staged ? 0 : 2); ++mt) {
         const int gx = x0 + 16 * mt + r16;
         const bool valid = gy < p.H && gx < p.W;
         const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
@@ -260,13 +309,16 @@ int launch_conv(const GrlConvArgs& p, hipStream_t st) {
         auto kfn = conv3x3_kernel<KC, NT, true>;
         e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds_all, st, p);
+        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds_all, st, p, 0);
     } else {
-        const size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
+        size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
+        const size_t tile_b = (size_t)TH * TW * (NT * 32 + 16);   // LDS-staged 16-bit output tile (epilogue)
+        if (lds < tile_b) lds = tile_b;
         auto kfn = conv3x3_kernel<KC, NT, false>;
         e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
+        static const int dbg = getenv("GRL_CONV_DEBUG") ? atoi(getenv("GRL_CONV_DEBUG")) : 0;  // timing ablations only
+        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p, dbg);
     }
     GRL_CHECK_LAUNCH();
     return 0;

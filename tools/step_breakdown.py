@@ -1,0 +1,30 @@
+#!/usr/bin/env python3
+"""Share of one forward per C-ABI entry point (HIP events around every launch, single stream so that launches do not
+overlap): where a 256x256-tile batch spends its time.  Debug tool."""
+import os, sys
+os.environ["GRL_SPLIT_STREAMS"] = "1"
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from grl_image_restoration_amd import GRL, baseline_config, ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+m = GRL(**baseline_config(3)).eval().cuda()
+x = torch.rand(B, 3, 256, 256, device="cuda")
+with torch.no_grad():
+    for _ in range(2):
+        m(x)
+    torch.cuda.synchronize()
+    ops.profile_begin()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    m(x)
+    e1.record()
+    prof = ops.profile_end()
+tot = e0.elapsed_time(e1)
+print(f"B={B}: forward {tot:.2f} ms (single stream)")
+acc = 0.0
+for k, v in sorted(prof.items(), key=lambda kv: -sum(kv[1])):
+    s = sum(v)
+    acc += s
+    print(f"  {k:12s} {len(v):5d} launches  {s:8.2f} ms  {100 * s / tot:5.1f} %   mean {1e3 * s / len(v):8.1f} us")
+print(f"  (timed launches {acc:.2f} ms = {100 * acc / tot:.1f} %; rest = torch glue: pad/normalise/permute/fill/copies)")
