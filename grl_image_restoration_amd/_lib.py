@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 8
+ABI_VERSION = 9
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -19,6 +19,8 @@ EXPORTS = [
     "grl_linear_fwd",
     "grl_mlp_fwd",
     "grl_mlp_blob_bytes",
+    "grl_block_tail_fwd",
+    "grl_proj_blob_bytes",
     "grl_qkv_fwd",
     "grl_qkv_blob_bytes",
     "grl_attention_fwd",
@@ -87,6 +89,35 @@ class GrlMlpArgs(_Strict):
         ("b2", C.c_void_p),
         ("ln_g", C.c_void_p),
         ("ln_b", C.c_void_p),
+        ("n_real", C.c_int32),
+        ("ln_eps", C.c_float),
+        ("res_scale", C.c_float),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+    ]
+
+
+class GrlTailArgs(_Strict):
+    _fields_ = [
+        ("att", C.c_void_p),
+        ("ldatt", C.c_int64),
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("cab", C.c_void_p),
+        ("ldcab", C.c_int64),
+        ("gate", C.c_void_p),
+        ("rows_per_image", C.c_int32),
+        ("pblob", C.c_void_p),
+        ("pb", C.c_void_p),
+        ("n1_g", C.c_void_p),
+        ("n1_b", C.c_void_p),
+        ("blob", C.c_void_p),
+        ("M", C.c_int32),
+        ("Cpad", C.c_int32),
+        ("Hpad", C.c_int32),
+        ("b2", C.c_void_p),
+        ("n2_g", C.c_void_p),
+        ("n2_b", C.c_void_p),
         ("n_real", C.c_int32),
         ("ln_eps", C.c_float),
         ("res_scale", C.c_float),
@@ -197,6 +228,10 @@ def lib():
     L.grl_mlp_fwd.restype = C.c_int
     L.grl_mlp_blob_bytes.argtypes = [C.c_int32, C.c_int32]
     L.grl_mlp_blob_bytes.restype = C.c_int64
+    L.grl_block_tail_fwd.argtypes = [C.c_void_p, C.POINTER(GrlTailArgs)]
+    L.grl_block_tail_fwd.restype = C.c_int
+    L.grl_proj_blob_bytes.argtypes = [C.c_int32]
+    L.grl_proj_blob_bytes.restype = C.c_int64
     L.grl_qkv_fwd.argtypes = [C.c_void_p, C.POINTER(GrlQkvArgs)]
     L.grl_qkv_fwd.restype = C.c_int
     L.grl_qkv_blob_bytes.argtypes = [C.c_int32, C.c_int32]

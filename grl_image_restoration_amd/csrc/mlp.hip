@@ -45,8 +45,28 @@ struct MlpShape {
 //     PIECES wave-wide global_load_lds_dwordx4 (1 KiB each, no staging registers, no ds_write pass);
 //   * the fp32 token slab stays in registers for the residual (no re-read) next to its fp16 MFMA copy, and the
 //     next tile's slab is prefetched into a second register set half way through the hidden sweep.
-template <int KSTEPS, int WV>
-__global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
+// Internal argument block: the MLP alone (grl_mlp_fwd) or preceded by the attention output projection + norm1 +
+// residual + gated CAB branch (grl_block_tail_fwd, PROJ = true).
+struct TailP {
+    const float* x; int64_t ldx;
+    const void* blob;                // MLP chunk images
+    int M, Cpad, Hpad;
+    const float* b2; const float* ln_g; const float* ln_b;
+    int n_real; float ln_eps, res_scale;
+    float* out; int64_t ldo;
+    // PROJ only
+    const gemm_t* att; int64_t ldatt;
+    const void* pblob;               // projection chunk images: 32 output rows x (2*Cpad + 16) bytes, padded to 1 KiB
+    const float* pb; const float* n1_g; const float* n1_b;
+    const gemm_t* cab; int64_t ldcab;
+    const float* gate; int rows_per_image;
+};
+
+// PROJ: a tile first runs  r1 = x + res_scale * LayerNorm1(att . Wp^T + bp) + cab * gate  (MixedAttention.proj + norm1 +
+// residual + CAB, mixed_attn_block_efficient.py:379,543-548) through the same weight ring -- Cpad/32 extra chunk
+// iterations -- and feeds r1 to the MLP from registers: the intermediate residual stream never goes to HBM.
+template <int KSTEPS, int WV, bool PROJ>
+__global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
     using S = MlpShape<KSTEPS>;
     constexpr int CP = S::CP, NT2 = S::NT2;
     constexpr int THREADS = WV * 64;
@@ -62,12 +82,17 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
     // compiler, the DMA is ordered by hand: a counted s_waitcnt before the barrier that publishes the chunk.
     const uint32_t lds0 = (uint32_t)(uintptr_t)(lds_ptr_t)smem;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
-    auto fetch = [&](int chunk, int buf_off) {
-        const char* src = blob + (size_t)chunk * S::BUFP + lane * 16;
+    constexpr int NP = PROJ ? KSTEPS : 0;                           // projection chunks per tile (32 output channels each)
+    constexpr int PPIECES = (32 * S::W1ROW + 1023) / 1024;          // DMA pieces of a projection chunk image
+    const char* pblob = (const char*)p.pblob;
+    auto fetch = [&](int k, int buf_off) {   // chunk k of the per-tile sequence [NP projection chunks | nchunks MLP chunks]
+        const bool isp = PROJ && k < NP;
+        const char* src = (isp ? pblob + (size_t)k * (PPIECES * 1024) : blob + (size_t)(k - NP) * S::BUFP) + lane * 16;
+        const int pieces = isp ? PPIECES : S::PIECES;
 #pragma unroll
         for (int q0 = 0; q0 < S::PIECES; q0 += WV) {
             const int q = q0 + wave_u;
-            if (q < S::PIECES) {
+            if (q < pieces) {
                 const uint32_t m0v = lds0 + buf_off + q * 1024;
                 const char* g = src + q * 1024;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
@@ -80,13 +105,16 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
     // fc2 bias and the norm affine live in LDS behind the ring (read once per tile by every lane)
     float* vec = (float*)(smem + 2 * S::BUFP);
     for (int i = tid; i < 3 * CP; i += THREADS) vec[i] = i < CP ? p.b2[i] : (i < 2 * CP ? p.ln_g[i - CP] : p.ln_b[i - 2 * CP]);
+    if constexpr (PROJ)   // [3CP..6CP): projection bias, norm1 weight / bias; [6CP..8CP): SE gate rows of the tile's <= 2 images
+        for (int i = tid; i < 3 * CP; i += THREADS) vec[3 * CP + i] = i < CP ? p.pb[i] : (i < 2 * CP ? p.n1_g[i - CP] : p.n1_b[i - 2 * CP]);
+    constexpr int VECF = PROJ ? 8 * CP : 3 * CP;
 
     // Token tile staging: the fp32 rows of the NEXT tile are DMA'd into LDS (rows padded by 16 B) in 1-KiB pieces
     // spread evenly over the chunk iterations of the current tile, so HBM reads run beside the MFMAs instead of in a
     // burst at the tile boundary, and cost no registers.
     constexpr int XROW = CP * 4 + 16, XSEG = XROW / 16;             // bytes / 16-B segments per staged row
     constexpr int XPIECES = (WV * 16 * XROW + 1023) / 1024;
-    const int xoff = 2 * S::BUFP + 3 * CP * 4;                       // LDS offset of the token tile
+    const int xoff = 2 * S::BUFP + VECF * 4;                         // LDS offset of the token tile
     auto fetch_x = [&](int tile, int piece) {                        // piece: wave-uniform
         const int sigma = piece * 64 + lane;                         // LDS segment this lane fills
         int row = sigma / XSEG, seg = sigma - row * XSEG;
@@ -110,24 +138,114 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
         // k-step s are the channels 32s + 4*g4 + [0..3] and 32s + 16 + 4*g4 + [0..3] -- the accumulator layout of n-tiles
         // 2s / 2s+1 (W1's columns are packed in the same slot order), so the registers that feed fc1 also provide the
         // residual of the epilogue: x is read from HBM exactly once.
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        float4 xs[KSTEPS][2];
+        float4 xs[KSTEPS][2];   // fp32 token rows in accumulator layout: MLP input and final residual
         gemm_x8 a[KSTEPS];
-        {
+        if constexpr (PROJ) {
+            // ---- attention output projection + norm1 + residual + gated CAB  ->  xs (registers) ----
+            const int64_t mc0 = valid ? m : (int64_t)p.M - 1;
+            const int img0 = (tile * (WV * 16)) / p.rows_per_image;
+            for (int i = tid; i < 2 * CP; i += THREADS) {   // gate rows of the (at most two) images this tile touches
+                const int im = img0 + i / CP;
+                const int last = (p.M - 1) / p.rows_per_image;
+                vec[6 * CP + i] = p.gate[(int64_t)(im < last ? im : last) * CP + (i % CP)];
+            }
+            gemm_x8 a0[KSTEPS];
+            gemm_x4 cb[NT2];
+            {
+                const gemm_t* arow = p.att + mc0 * p.ldatt + 8 * g4;
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) a0[s] = *(const gemm_x8*)(arow + 32 * s);
+                const gemm_t* crow = p.cab + mc0 * p.ldcab + 4 * g4;
+#pragma unroll
+                for (int nt = 0; nt < NT2; ++nt) cb[nt] = *(const gemm_x4*)(crow + 16 * nt);
+            }
+            f32x4 pacc[NT2];
+#pragma unroll
+            for (int j = 0; j < NP; ++j, ++it) {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                char* cur = smem + (it & 1) * S::BUFP;
+                fetch(j + 1, ((it + 1) & 1) * S::BUFP);   // j + 1 == NP is MLP chunk 0
+                gemm_x8 wa[KSTEPS], wb[KSTEPS];
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    wa[s] = *(const gemm_x8*)(cur + r16 * S::W1ROW + (32 * s + 8 * g4) * 2);
+                    wb[s] = *(const gemm_x8*)(cur + (16 + r16) * S::W1ROW + (32 * s + 8 * g4) * 2);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 h0 = f32x4{0, 0, 0, 0}, h1 = f32x4{0, 0, 0, 0};
+#pragma unroll
+                for (int s = 0; s < KSTEPS; ++s) {
+                    h0 = mfma16_gemm(wa[s], a0[s], h0);
+                    h1 = mfma16_gemm(wb[s], a0[s], h1);
+                }
+                pacc[2 * j] = h0;
+                pacc[2 * j + 1] = h1;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            // the token tile landed before the first of the barriers above (issued a whole tile earlier)
+            float s1 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                const float4 b4 = *(const float4*)(vec + 3 * CP + 16 * nt + 4 * g4);
+                pacc[nt][0] += b4.x; pacc[nt][1] += b4.y; pacc[nt][2] += b4.z; pacc[nt][3] += b4.w;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s1 += (16 * nt + 4 * g4 + e) < p.n_real ? pacc[nt][e] : 0.f;
+            }
+            s1 += __shfl_xor(s1, 16, 64);
+            s1 += __shfl_xor(s1, 32, 64);
+            const float mean = s1 / (float)p.n_real;
+            float s2 = 0.f;
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float d = pacc[nt][e] - mean;
+                    s2 += (16 * nt + 4 * g4 + e) < p.n_real ? d * d : 0.f;
+                }
+            s2 += __shfl_xor(s2, 16, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
+            const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
+            const float* grow = vec + 6 * CP + ((int)(mc0 / p.rows_per_image) - img0) * CP;
+#pragma unroll
+            for (int nt = 0; nt < NT2; ++nt) {
+                const int col = 16 * nt + 4 * g4;
+                const float4 res = *(const float4*)(rowp + 64 * nt);
+                const float4 g = *(const float4*)(vec + 4 * CP + col);
+                const float4 bb = *(const float4*)(vec + 5 * CP + col);
+                const float4 gt = *(const float4*)(grow + col);
+                float4 o4;
+                o4.x = res.x + p.res_scale * ((pacc[nt][0] - mean) * rstd * g.x + bb.x) + (float)cb[nt][0] * gt.x;
+                o4.y = res.y + p.res_scale * ((pacc[nt][1] - mean) * rstd * g.y + bb.y) + (float)cb[nt][1] * gt.y;
+                o4.z = res.z + p.res_scale * ((pacc[nt][2] - mean) * rstd * g.z + bb.z) + (float)cb[nt][2] * gt.z;
+                o4.w = res.w + p.res_scale * ((pacc[nt][3] - mean) * rstd * g.w + bb.w) + (float)cb[nt][3] * gt.w;
+                if (col + 0 >= p.n_real) o4.x = 0.f;   // keep pad channels 0
+                if (col + 1 >= p.n_real) o4.y = 0.f;
+                if (col + 2 >= p.n_real) o4.z = 0.f;
+                if (col + 3 >= p.n_real) o4.w = 0.f;
+                xs[nt >> 1][nt & 1] = o4;
+            }
+        } else {
+            // the tile's rows have landed (own pieces: vmcnt, everybody's: barrier).  Lane = token r16; its 8 k-slots of
+            // k-step s are the channels 32s + 4*g4 + [0..3] and 32s + 16 + 4*g4 + [0..3] -- the accumulator layout of n-tiles
+            // 2s / 2s+1 (W1's columns are packed in the same slot order), so the registers that feed fc1 also provide the
+            // residual of the epilogue: x is read from HBM exactly once.
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
             const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
                 xs[s][0] = *(const float4*)(rowp + 128 * s);
                 xs[s][1] = *(const float4*)(rowp + 128 * s + 64);
             }
+        }
 #pragma unroll
-            for (int s = 0; s < KSTEPS; ++s) {
-                gemm_x8 v;
-                v[0] = (gemm_t)xs[s][0].x; v[1] = (gemm_t)xs[s][0].y; v[2] = (gemm_t)xs[s][0].z; v[3] = (gemm_t)xs[s][0].w;
-                v[4] = (gemm_t)xs[s][1].x; v[5] = (gemm_t)xs[s][1].y; v[6] = (gemm_t)xs[s][1].z; v[7] = (gemm_t)xs[s][1].w;
-                a[s] = v;
-            }
+        for (int s = 0; s < KSTEPS; ++s) {
+            gemm_x8 v;
+            v[0] = (gemm_t)xs[s][0].x; v[1] = (gemm_t)xs[s][0].y; v[2] = (gemm_t)xs[s][0].z; v[3] = (gemm_t)xs[s][0].w;
+            v[4] = (gemm_t)xs[s][1].x; v[5] = (gemm_t)xs[s][1].y; v[6] = (gemm_t)xs[s][1].z; v[7] = (gemm_t)xs[s][1].w;
+            a[s] = v;
         }
         f32x4 acc[NT2];
 #pragma unroll
@@ -142,7 +260,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: my LDS reads of the token tile / last chunk are done
             if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
             char* cur = smem + (it & 1) * S::BUFP;
-            if (!(dbg & 1)) fetch(c + 1 < nchunks ? c + 1 : 0, ((it + 1) & 1) * S::BUFP);
+            if (!(dbg & 1)) fetch(c + 1 < nchunks ? NP + c + 1 : 0, ((it + 1) & 1) * S::BUFP);
             for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) fetch_x(next_tile, q);
 
             // ---- h = GELU(W1_c . x + b1_c): two n-tiles of 16 hidden channels ----
@@ -239,14 +357,15 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(GrlMlpArgs p, int dbg) {
     }
 }
 
-template <int KSTEPS, int WV>
-int launch_mlp(const GrlMlpArgs& p, hipStream_t st) {
+template <int KSTEPS, int WV, bool PROJ>
+int launch_mlp(const TailP& p, hipStream_t st) {
     using S = MlpShape<KSTEPS>;
-    const size_t lds = 2 * (size_t)S::BUFP + 3 * S::CP * sizeof(float) + (size_t)((WV * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
+    const size_t lds = 2 * (size_t)S::BUFP + (PROJ ? 8 : 3) * S::CP * sizeof(float) +
+                       (size_t)((WV * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
     const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
     static const int cap = getenv("GRL_PERSIST_GRID") ? atoi(getenv("GRL_PERSIST_GRID")) : 256;   // tuning knob
     const int grid = ntiles < cap ? ntiles : cap;   // one persistent workgroup per CU
-    auto kfn = mlp_kernel<KSTEPS, WV>;
+    auto kfn = mlp_kernel<KSTEPS, WV, PROJ>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     static const int dbg = getenv("GRL_MLP_DEBUG") ? atoi(getenv("GRL_MLP_DEBUG")) : 0;  // timing ablations only
@@ -254,6 +373,18 @@ int launch_mlp(const GrlMlpArgs& p, hipStream_t st) {
     GRL_CHECK_LAUNCH();
     return 0;
 }
+
+template <bool PROJ>
+int launch_tail(const TailP& p, hipStream_t st) {
+    switch (p.Cpad / 32) {
+        case 2: return launch_mlp<2, 8, PROJ>(p, st);
+        case 4: return launch_mlp<4, 8, PROJ>(p, st);
+        case 6: return launch_mlp<6, 8, PROJ>(p, st);
+        default: return GRL_ERR_UNSUPPORTED;
+    }
+}
+
+int64_t proj_chunk_bytes(int Cpad) { return ((int64_t)32 * (Cpad * 2 + 16) + 1023) / 1024 * 1024; }
 
 int64_t chunk_bytes(int Cpad) {
     switch (Cpad / 32) {
@@ -271,19 +402,41 @@ extern "C" int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad) {
     return (int64_t)(Hpad / 32) * chunk_bytes(Cpad);
 }
 
+static bool mlp_args_ok(const void* x, int64_t ldx, const void* blob, const void* out, int64_t ldo, int M, int Cpad, int Hpad, int n_real) {
+    if ((Cpad % 32) || (Hpad % 32) || Hpad <= 0 || (ldx % 4) || (ldo % 4) || ldx < Cpad || ldo < Cpad || n_real > Cpad || n_real <= 0) return false;
+    if (x == nullptr || blob == nullptr || out == nullptr || x == out || ((uintptr_t)blob & 15) != 0) return false;
+    return true;
+}
+
 extern "C" int grl_mlp_fwd(void* stream, const GrlMlpArgs* args) {
-    const GrlMlpArgs& p = *args;
-    if (p.M <= 0) return 0;
-    if ((p.Cpad % 32) || (p.Hpad % 32) || p.Hpad <= 0 || (p.ldx % 4) || (p.ldo % 4) || p.ldx < p.Cpad || p.ldo < p.Cpad ||
-        p.n_real > p.Cpad || p.n_real <= 0)
+    const GrlMlpArgs& a = *args;
+    if (a.M <= 0) return 0;
+    if (!mlp_args_ok(a.x, a.ldx, a.blob, a.out, a.ldo, a.M, a.Cpad, a.Hpad, a.n_real)) return GRL_ERR_BAD_ARG;
+    TailP p = {};
+    p.x = a.x; p.ldx = a.ldx; p.blob = a.blob; p.M = a.M; p.Cpad = a.Cpad; p.Hpad = a.Hpad;
+    p.b2 = a.b2; p.ln_g = a.ln_g; p.ln_b = a.ln_b; p.n_real = a.n_real; p.ln_eps = a.ln_eps; p.res_scale = a.res_scale;
+    p.out = a.out; p.ldo = a.ldo;
+    return launch_tail<false>(p, (hipStream_t)stream);
+}
+
+extern "C" int64_t grl_proj_blob_bytes(int32_t Cpad) {
+    if (Cpad <= 0 || (Cpad % 32) || chunk_bytes(Cpad) == 0) return GRL_ERR_BAD_ARG;
+    return (int64_t)(Cpad / 32) * proj_chunk_bytes(Cpad);
+}
+
+extern "C" int grl_block_tail_fwd(void* stream, const GrlTailArgs* args) {
+    const GrlTailArgs& a = *args;
+    if (a.M <= 0) return 0;
+    if (!mlp_args_ok(a.x, a.ldx, a.blob, a.out, a.ldo, a.M, a.Cpad, a.Hpad, a.n_real)) return GRL_ERR_BAD_ARG;
+    if (a.att == nullptr || a.cab == nullptr || a.gate == nullptr || a.pblob == nullptr || ((uintptr_t)a.pblob & 15) != 0 ||
+        (a.ldatt % 8) || a.ldatt < a.Cpad || (a.ldcab % 4) || a.ldcab < a.Cpad || a.pb == nullptr || a.n1_g == nullptr || a.n1_b == nullptr)
         return GRL_ERR_BAD_ARG;
-    if (p.x == nullptr || p.blob == nullptr || p.out == nullptr || (const void*)p.x == (const void*)p.out) return GRL_ERR_BAD_ARG;
-    if (((uintptr_t)p.blob & 15) != 0) return GRL_ERR_BAD_ARG;
-    hipStream_t st = (hipStream_t)stream;
-    switch (p.Cpad / 32) {
-        case 2: return launch_mlp<2, 8>(p, st);
-        case 4: return launch_mlp<4, 8>(p, st);
-        case 6: return launch_mlp<6, 8>(p, st);
-        default: return GRL_ERR_UNSUPPORTED;
-    }
+    if (a.rows_per_image < 128) return GRL_ERR_UNSUPPORTED;   // a 128-token tile may touch at most two images
+    TailP p = {};
+    p.x = a.x; p.ldx = a.ldx; p.blob = a.blob; p.M = a.M; p.Cpad = a.Cpad; p.Hpad = a.Hpad;
+    p.b2 = a.b2; p.ln_g = a.n2_g; p.ln_b = a.n2_b; p.n_real = a.n_real; p.ln_eps = a.ln_eps; p.res_scale = a.res_scale;
+    p.out = a.out; p.ldo = a.ldo;
+    p.att = (const gemm_t*)a.att; p.ldatt = a.ldatt; p.pblob = a.pblob; p.pb = a.pb; p.n1_g = a.n1_g; p.n1_b = a.n1_b;
+    p.cab = (const gemm_t*)a.cab; p.ldcab = a.ldcab; p.gate = a.gate; p.rows_per_image = a.rows_per_image;
+    return launch_tail<true>(p, (hipStream_t)stream);
 }

@@ -151,8 +151,9 @@ int launch_qkv(const GrlQkvArgs& p, hipStream_t st) {
     using S = QkvShape<KSTEPS, SPC>;
     const size_t lds = 2 * (size_t)S::BUFP + (size_t)((WV * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
     const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
-    static const int cap = getenv("GRL_PERSIST_GRID") ? atoi(getenv("GRL_PERSIST_GRID")) : 256;   // tuning knob
-    const int grid = ntiles < cap ? ntiles : cap;   // one persistent workgroup per CU
+    static const int cap0 = getenv("GRL_PERSIST_GRID") ? atoi(getenv("GRL_PERSIST_GRID")) : 256;   // tuning knob
+    const int cap = cap0 * (WV <= 4 ? 2 : 1);       // small workgroups: two per CU (or one beside a workgroup of another kernel)
+    const int grid = ntiles < cap ? ntiles : cap;   // persistent workgroups
     auto kfn = qkv_kernel<KSTEPS, SPC, WV>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
@@ -163,7 +164,8 @@ int launch_qkv(const GrlQkvArgs& p, hipStream_t st) {
 
 template <int KSTEPS>
 int launch_qkv_k(const GrlQkvArgs& p, hipStream_t st) {
-    if (p.nslots % 2 == 0) return launch_qkv<KSTEPS, 2, 8>(p, st);
+    static const int small = getenv("GRL_QKV_SMALL") ? atoi(getenv("GRL_QKV_SMALL")) : 0;   // experiment: 64-token workgroups
+    if (p.nslots % 2 == 0) return small ? launch_qkv<KSTEPS, 2, 4>(p, st) : launch_qkv<KSTEPS, 2, 8>(p, st);
     return launch_qkv<KSTEPS, 1, 8>(p, st);
 }
 

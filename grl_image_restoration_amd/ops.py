@@ -220,6 +220,43 @@ def qkv(x: torch.Tensor, blob: torch.Tensor, nslots: int, out: Optional[torch.Te
     return out
 
 
+def pack_proj(w: torch.Tensor) -> torch.Tensor:
+    """Projection weight stream of grl_block_tail_fwd from the padded matrix w [Cpad, Cpad] (rows = output channels,
+    columns = the slotted attention-output K): chunks of 32 rows x (2*Cpad + 16) bytes fp16, padded to 1 KiB."""
+    dev = w.device
+    N, K = w.shape
+    assert N == K and N % 32 == 0
+    total = L.lib().grl_proj_blob_bytes(N)
+    assert total > 0
+    nch = N // 32
+    wrow = K * 2 + 16
+    blob = torch.zeros(nch, total // nch, dtype=torch.uint8, device=dev)
+    blob[:, : 32 * wrow].view(nch, 32, wrow)[:, :, : K * 2] = w.detach().to(GEMM_DTYPE).contiguous().view(torch.uint8).view(nch, 32, K * 2)
+    return blob.contiguous()
+
+
+def block_tail(att: torch.Tensor, x: torch.Tensor, cab: torch.Tensor, gate: torch.Tensor, rows_per_image: int,
+               pblob: torch.Tensor, pb: torch.Tensor, n1_g: torch.Tensor, n1_b: torch.Tensor,
+               blob: torch.Tensor, b2: torch.Tensor, n2_g: torch.Tensor, n2_b: torch.Tensor, *, Hpad: int, n_real: int,
+               ln_eps: float = 1e-5, res_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """proj + norm1 + residual + gated CAB + MLP + norm2 + residual of a block in one kernel (grl_block_tail_fwd)."""
+    _dev_check(att, x, cab, gate, pblob, pb, n1_g, n1_b, blob, b2, n2_g, n2_b, out)
+    M, Cpad = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and att.dtype == GEMM_DTYPE and att.stride(1) == 1 and att.shape[0] == M
+    assert cab.dtype == GEMM_DTYPE and cab.stride(1) == 1 and cab.shape[0] == M and gate.dtype == torch.float32 and gate.is_contiguous()
+    assert gate.shape[1] == Cpad and att.shape[1] >= Cpad and cab.shape[1] >= Cpad
+    if out is None:
+        out = torch.empty(M, Cpad, dtype=torch.float32, device=x.device)
+    assert out.dtype == torch.float32 and out.stride(1) == 1 and out.data_ptr() != x.data_ptr()
+    args = L.GrlTailArgs(att=_ptr(att), ldatt=att.stride(0), x=_ptr(x), ldx=x.stride(0), cab=_ptr(cab), ldcab=cab.stride(0),
+                         gate=_ptr(gate), rows_per_image=rows_per_image, pblob=_ptr(pblob), pb=_ptr(pb), n1_g=_ptr(n1_g),
+                         n1_b=_ptr(n1_b), blob=_ptr(blob), M=M, Cpad=Cpad, Hpad=Hpad, b2=_ptr(b2), n2_g=_ptr(n2_g), n2_b=_ptr(n2_b),
+                         n_real=n_real, ln_eps=ln_eps, res_scale=res_scale, out=_ptr(out), ldo=out.stride(0))
+    with _timed("block_tail"):
+        L.check(L.lib().grl_block_tail_fwd(L.stream_ptr(), C.byref(args)), "grl_block_tail_fwd")
+    return out
+
+
 def mlp(x: torch.Tensor, blob: torch.Tensor, b2: torch.Tensor, ln_g: torch.Tensor, ln_b: torch.Tensor, *, Hpad: int,
         n_real: int, ln_eps: float = 1e-5, res_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """out = x + res_scale * LayerNorm(fc2(GELU(fc1(x)))) on the token matrix x [M, Cpad] (fp32), one kernel."""

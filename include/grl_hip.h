@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 8
+#define GRL_ABI_VERSION 9
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -102,6 +102,45 @@ typedef struct GrlMlpArgs {
 
 int grl_mlp_fwd(void* stream, const GrlMlpArgs* args);
 int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad);
+
+/* ---------------------------------------------------------------------------------------------
+ * Block tail: everything of an EfficientMixAttnTransformerBlock after the attention and CAB kernels, in one pass:
+ *     r1  = x + res_scale * LayerNorm1(att . Wp^T + bp) + cab * gate[image]     (never written to HBM)
+ *     out = r1 + res_scale * LayerNorm2(fc2(GELU(fc1(r1))))
+ *   replaces  MixedAttention.proj                          models/common/mixed_attn_block_efficient.py:379
+ *             norm1 + residual + CAB branch + norm2 + Mlp   :543-556, models/common/swin_v1_block.py:37-43
+ * att: fp16 slotted attention output [M, >= Cpad] (K = Cpad, natural order); cab: fp16 raw CAB conv output;
+ * gate: [images, Cpad] SE gate (grl_se_scale_fwd); pblob: projection weight stream = Cpad/32 chunks, each 32 rows
+ * (output channels) x (2*Cpad + 16) bytes fp16 padded to 1024 bytes (grl_proj_blob_bytes); blob as in GrlMlpArgs.
+ * rows_per_image must be >= 128 (GRL_ERR_UNSUPPORTED otherwise).
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GrlTailArgs {
+    const void* att;
+    int64_t ldatt;
+    const float* x;         /* [M, ldx] fp32 block input (residual)                                 */
+    int64_t ldx;
+    const void* cab;
+    int64_t ldcab;
+    const float* gate;
+    int32_t rows_per_image;
+    const void* pblob;
+    const float* pb;        /* [Cpad] proj.bias, norm1 weight / bias                                */
+    const float* n1_g;
+    const float* n1_b;
+    const void* blob;       /* MLP weight stream (GrlMlpArgs)                                       */
+    int32_t M, Cpad, Hpad;
+    const float* b2;        /* [Cpad] fc2.bias, norm2 weight / bias                                 */
+    const float* n2_g;
+    const float* n2_b;
+    int32_t n_real;
+    float ln_eps;
+    float res_scale;
+    float* out;             /* [M, ldo] fp32; must not alias x                                      */
+    int64_t ldo;
+} GrlTailArgs;
+
+int grl_block_tail_fwd(void* stream, const GrlTailArgs* args);
+int64_t grl_proj_blob_bytes(int32_t Cpad);
 
 /* ---------------------------------------------------------------------------------------------
  * Streaming QKV projection: head planes out[slot][m][0..31] (bf16) = groupnorm(x[m,:] . W_slot^T + b_slot),

@@ -146,6 +146,50 @@ def test_streaming_qkv(M, C, nslots):
     assert (out.float() - old.float()).abs().max().item() <= 2e-2 * max(1.0, ref.abs().max().item() / 2)
 
 
+@pytest.mark.parametrize("M,C,Hd,rpi", [(1000, 180, 360, 500), (4099, 180, 360, 4099), (1300, 128, 256, 650)])
+def test_fused_block_tail(M, C, Hd, rpi):
+    """grl_block_tail_fwd (proj + norm1 + residual + gated CAB + MLP + norm2 + residual) against the separate kernels
+    (LN_RES linear with add2, then the fused MLP) and against fp64 torch on fp16-rounded operands."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    CP, HP = (C + 31) // 32 * 32, (Hd + 31) // 32 * 32
+    g = torch.Generator().manual_seed(21)
+    pad = lambda t, n: torch.cat([t, torch.zeros(*t.shape[:-1], n - t.shape[-1])], dim=-1)
+    x = pad(torch.randn(M, C, generator=g), CP)
+    att = torch.randn(M, CP, generator=g).to(torch.float16)
+    cab = pad(torch.randn(M, C, generator=g), CP).to(torch.float16)
+    nimg = (M + rpi - 1) // rpi
+    gate = pad(torch.rand(nimg, C, generator=g), CP)
+    wp = torch.zeros(CP, CP); wp[:C] = torch.randn(C, CP, generator=g) / math.sqrt(CP)
+    bp = pad(0.1 * torch.randn(C, generator=g), CP)
+    g1, b1n = pad(1 + 0.1 * torch.randn(C, generator=g), CP), pad(0.1 * torch.randn(C, generator=g), CP)
+    w1 = torch.randn(Hd, C, generator=g) / math.sqrt(C)
+    b1 = 0.1 * torch.randn(Hd, generator=g)
+    w2 = torch.randn(C, Hd, generator=g) / math.sqrt(Hd)
+    b2 = pad(0.1 * torch.randn(C, generator=g), CP)
+    g2, b2n = pad(1 + 0.1 * torch.randn(C, generator=g), CP), pad(0.1 * torch.randn(C, generator=g), CP)
+    d = _dev()
+    blob = ops.pack_mlp(w1.to(d), b1.to(d), w2.to(d), CP, HP)
+    out = ops.block_tail(att.to(d), x.to(d), cab.to(d), gate.to(d), rpi, ops.pack_proj(wp.to(d)), bp.to(d), g1.to(d), b1n.to(d),
+                         blob, b2.to(d), g2.to(d), b2n.to(d), Hpad=HP, n_real=C, res_scale=0.5).cpu()
+    # separate kernels
+    r1 = ops.linear(att.to(d), wp.to(torch.float16).to(d), bp.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=g1.to(d),
+                    ln_b=b1n.to(d), n_real=C, res_scale=0.5, resid=x.to(d), add2=cab.to(d), add2_scale=gate.to(d), rows_per_image=rpi)
+    out2 = ops.mlp(r1, blob, b2.to(d), g2.to(d), b2n.to(d), Hpad=HP, n_real=C, res_scale=0.5).cpu()
+    assert (out - out2).abs().max().item() < 2e-3
+    # fp64 reference
+    h16 = lambda t: t.to(torch.float16).double()
+    y = att.double() @ h16(wp[:C]).t() + bp[:C].double()
+    gr = gate[torch.arange(M) // rpi][:, :C].double()
+    r1r = x[:, :C].double() + 0.5 * F.layer_norm(y, (C,), g1[:C].double(), b1n[:C].double(), 1e-5) + cab[:, :C].double() * gr
+    hid = F.gelu(h16(r1r.float()) @ h16(w1).t() + b1.double())
+    y2 = h16(hid.float()) @ h16(w2).t() + b2[:C].double()
+    ref = r1r + 0.5 * F.layer_norm(y2, (C,), g2[:C].double(), b2n[:C].double(), 1e-5)
+    assert (out[:, :C].double() - ref).abs().max().item() < 3e-3
+    if C < CP:
+        assert out[:, C:].abs().max().item() == 0.0
+
+
 def test_linear_pooled_anchor():
     """AnchorLinear: avg-pool df x df (mixed_attn_block.py:727-736) fused into the A load."""
     from grl_image_restoration_amd import _lib as L, ops

@@ -80,6 +80,9 @@ def main():
         "proj_ln": (lambda: ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
                                        ln_b=pk["n1_b"], n_real=C, resid=r, add2=cab, add2_scale=gate, rows_per_image=H * W),
                     2 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4)),
+        "block_tail": (lambda: ops.block_tail(att, r, cab, gate, H * W, pk["proj_blob"], pk["proj_b"], pk["n1_g"], pk["n1_b"], pk["mlp_blob"],
+                                              pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C),
+                       10 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4)),
         "fc1_gelu": (lambda: ops.linear(r, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out=h), 4 * L_ * C * C * B, M * (CP * 4 + 384 * 2)),
         "mlp_fused": (lambda: ops.mlp(r, pk["mlp_blob"], pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C),
                       8 * L_ * C * C * B, M * (CP * 4 * 2)),
