@@ -324,7 +324,20 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 // ------------------------------------------------------------------------------------------------
 
 // FROWS = key rows per LDS chunk (chunk = FROWS x 32 keys of one strip); WPS = waves per SIMD to allocate for
-template <int FW, int QTN, int FROWS, int WPS, int PIPE>
+// Upper bound of the bias-table entries one workgroup of the fast kernel needs (KDMA layout): its queries span at most
+// QTN * (units_per_wg / segments_per_row + 2) rows, every key row of the window, all column offsets.
+__host__ __device__ inline int fast_table_floats(const GrlAttnArgs& p, int fw, int qtn) {
+    const int qseg = p.q.ww >> 5;
+    const int units = (p.q.wh / qtn) * qseg;
+    const int upw = fw < units ? fw : units;
+    const int rows = qtn * (upw / qseg + 2);
+    const int D = p.q.ww + p.k.ww - 1;
+    const int n = (rows - 1 + p.k.wh) * D + 4;
+    const int all = (p.trows + 3) & ~3;
+    return n < all ? n : all;
+}
+
+template <int FW, int QTN, int FROWS, int WPS, int PIPE, bool KDMA>
 __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, int dbg, long long* tbuf) {
     long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (tbuf) tm[0] = __builtin_amdgcn_s_memtime();
@@ -345,22 +358,35 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     const int b = bid / p.nwy;
     const int D = p.q.ww + p.k.ww - 1;
 
+    // LDS: bias table (KDMA: only the rows this workgroup's queries can reach) | K chunk (KDMA: two) | V^T chunk | region ids
     float* tab = (float*)smem;
-    char* Ks = smem + (((size_t)p.trows * 4 + 15) & ~(size_t)15);
-    char* Vt = Ks + FKC * 64;
+    const int tab_floats = KDMA ? fast_table_floats(p, FW, QTN) : p.trows;
+    char* Ks0 = smem + (((size_t)tab_floats * 4 + 15) & ~(size_t)15);
+    char* Vt = Ks0 + (KDMA ? 2 : 1) * FKC * 64;
     unsigned char* kreg = (unsigned char*)(Vt + 32 * FVROW);
 
     // the table arrives REVERSED (see grl_hip.h) so that a lane's 16 key rows read ascending addresses.
     // It is DMA'd (global_load_lds, 1 KiB per wave-instruction, no staging registers): all pieces are in flight at
     // once and overlap the first K/V chunk's loads; the barrier in front of the first LDS commit waits for them.
     // A last partial piece re-reads the final 16 bytes; its tail lands in the K staging area, which is written later.
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    int tab_lo = 0;   // first table entry (reversed order, multiple of 4) held in LDS
     {
-        const int n4 = (p.trows + 3) >> 2;
+        int n4 = (p.trows + 3) >> 2, first4 = 0;
+        if constexpr (KDMA) {
+            // queries of this workgroup: rows hq_lo .. hq_hi  ->  reversed entries trows - (hq_hi + k.wh) * D .. trows - 1 - hq_lo * D
+            const int u0 = qs * upw, u1 = min(u0 + upw, units) - 1;
+            const int hq_lo = QTN * (u0 / qseg), hq_hi = QTN * (u1 / qseg) + QTN - 1;
+            const int pos_lo = p.trows - (hq_hi + p.k.wh) * D, pos_hi = p.trows - 1 - hq_lo * D;
+            tab_lo = pos_lo & ~3;
+            first4 = tab_lo >> 2;
+            n4 = ((pos_hi - tab_lo) >> 2) + 1;
+        }
+        const int last4 = ((p.trows + 3) >> 2) - 1;
         const float4* s4 = (const float4*)(p.table + (int64_t)head * p.tstride);
-        const int wave_u = __builtin_amdgcn_readfirstlane(wave);
         for (int q = wave_u; q * 64 < n4; q += FW) {
-            int i = q * 64 + lane;
-            i = i < n4 ? i : n4 - 1;
+            int i = first4 + q * 64 + lane;
+            i = i < last4 ? i : last4;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(s4 + i),
                                              (__attribute__((address_space(3))) void*)(tab + q * 256), 16, 0, 0);
         }
@@ -382,7 +408,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
         locate(p.q, b, wy, wx, hq * p.q.ww + wq, qrow[t], idq[t]);
         // table index of (query, key (hk, wk)) = U - hk*D - wk, reversed: (trows-1-U) + hk*D + wk;
         // lane's key rows are wk = 32*sk + i, i = (r&3) + 8*(r>>2) + 4*half
-        Ub[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1)) + 4 * half;
+        Ub[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1)) + 4 * half - tab_lo;
         const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
         qf[t][0] = *(const bf16x8*)(src);
         qf[t][1] = *(const bf16x8*)(src + 16);
@@ -402,42 +428,92 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     constexpr int SPT = (FKC * 4) / (FW * 64);
     static_assert(SPT * FW * 64 == FKC * 4, "chunk must divide evenly over the workgroup");
 
+    // slot (key kk, 16-B segment seg) of chunk ch -> row of the token matrix (+ region id of the key)
+    auto key_row = [&](int ch, int kk, int& rid) -> int64_t {
+        const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
+        const int ry = wy * p.k.wh + hk0 + (kk >> 5), rx = wx * p.k.ww + 32 * sk + (kk & 31);
+        int oy = ry + p.k.shy; if (oy >= p.k.Himg) oy -= p.k.Himg;
+        int ox = rx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
+        rid = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
+        return ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
+    };
+    bf16x8 pv_[SPT];
+    int prid[SPT];
+    const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
+    // KDMA: the K chunk goes global -> LDS by DMA (the XOR swizzle is applied on the source side: LDS segment sigma holds
+    // segment (sigma & 3) ^ ((kk >> 2) & 3) of key kk = sigma >> 2), V by registers (it is transposed on the way); both
+    // are issued one chunk ahead, while the previous chunk is in the matrix cores.
+    auto prefetch = [&](int ch) {
+        if constexpr (KDMA) {
+#pragma unroll
+            for (int j = 0; j < (FKC * 64) / (FW * 1024); ++j) {
+                const int q = wave_u + j * FW;
+                const int sigma = q * 64 + lane, kk = sigma >> 2, seg = (sigma & 3) ^ ((kk >> 2) & 3);
+                int rid;
+                const int64_t row = key_row(ch, kk, rid);
+                const bf16* g = (const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8;
+                const uint32_t m0v = lds0 + (uint32_t)(Ks0 - smem) + (ch & 1) * FKC * 64 + q * 1024;
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
+            }
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int i = tid + j * FW * 64;
+                const int64_t row = key_row(ch, i >> 2, prid[j]);
+                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i & 3) * 8);
+            }
+        }
+    };
+    if constexpr (KDMA) prefetch(0);
+
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
         if ((dbg & 16) && ch > 0) break;
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (tbuf) c0 = __builtin_amdgcn_s_memtime();
-        bf16x8 pk_[SPT], pv_[SPT];
-        int prid[SPT];
-        if (!(dbg & 32) || ch == 0)
+        char* Ks = Ks0 + (KDMA ? (ch & 1) * FKC * 64 : 0);
+        if constexpr (KDMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces (table, K chunk) and V loads have landed
+            __builtin_amdgcn_s_barrier();                       // ... everybody's; and all are done reading the previous chunk
+            if (tbuf) c1 = __builtin_amdgcn_s_memtime();
 #pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int i = tid + j * FW * 64;
-            const int kk = i >> 2, seg = i & 3;
-            const int ry = wy * p.k.wh + hk0 + (kk >> 5), rx = wx * p.k.ww + 32 * sk + (kk & 31);
-            int oy = ry + p.k.shy; if (oy >= p.k.Himg) oy -= p.k.Himg;
-            int ox = rx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
-            const int64_t row = ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
-            pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
-            pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
-            prid[j] = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
+            for (int j = 0; j < SPT; ++j) {
+                const int i = tid + j * FW * 64;
+                const int kk = i >> 2, seg = i & 3;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * FVROW + kk * 2) = pv_[j][e];
+                if (seg == 0) kreg[kk] = (unsigned char)prid[j];
+            }
+            if (ch + 1 < nch) prefetch(ch + 1);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();                       // V^T / region ids visible (raw barrier: the prefetch stays in flight)
+        } else {
+            bf16x8 pk_[SPT];
+            if (!(dbg & 32) || ch == 0)
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int i = tid + j * FW * 64;
+                const int64_t row = key_row(ch, i >> 2, prid[j]);
+                pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + (i & 3) * 8);
+                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i & 3) * 8);
+            }
+            __syncthreads();   // everyone is done reading the previous chunk
+            if (tbuf) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = __builtin_amdgcn_s_memtime(); }
+            if (!(dbg & 1) || ch == 0)
+#pragma unroll
+            for (int j = 0; j < SPT; ++j) {
+                const int i = tid + j * FW * 64;
+                const int kk = i >> 2, seg = i & 3;
+                *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * FVROW + kk * 2) = pv_[j][e];
+                if (seg == 0) kreg[kk] = (unsigned char)prid[j];
+            }
+            __syncthreads();
         }
-        __syncthreads();   // everyone is done reading the previous chunk
-        if (tbuf) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = __builtin_amdgcn_s_memtime(); }
-        if (!(dbg & 1) || ch == 0)
-#pragma unroll
-        for (int j = 0; j < SPT; ++j) {
-            const int i = tid + j * FW * 64;
-            const int kk = i >> 2, seg = i & 3;
-            *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * FVROW + kk * 2) = pv_[j][e];
-            if (seg == 0) kreg[kk] = (unsigned char)prid[j];
-        }
-        __syncthreads();
         if (tbuf) c2 = __builtin_amdgcn_s_memtime();
         if (!active) continue;
+        if (dbg & 64) __builtin_amdgcn_s_setprio(1);   // experiment: MFMA phase outranks the other workgroup's staging phase
 
         // LDS reads of one key tile: K fragments, V^T fragments, bias fragments (accumulator init), key region ids
         auto lds_tile = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], f32x16 (&S)[QTN], uint32_t (&ids)[4]) {
@@ -658,6 +734,7 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 compute_tile(kf, vf, S, ids);
             }
         }
+        if (dbg & 64) __builtin_amdgcn_s_setprio(0);
         if (tbuf) { c3 = __builtin_amdgcn_s_memtime(); tm[2] += c1 - c0; tm[3] += c2 - c1; tm[4] += c3 - c2; }
     }
     if (tbuf) tm[5] = __builtin_amdgcn_s_memtime();
@@ -691,22 +768,24 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     }
 }
 
-size_t fast_lds_bytes(const GrlAttnArgs& p, int frows) {
+size_t fast_lds_bytes(const GrlAttnArgs& p, int frows, int fw = 4, int qtn = 2, bool kdma = false) {
     const size_t kc = (size_t)frows * 32;
-    return (((size_t)p.trows * 4 + 15) & ~(size_t)15) + kc * 64 + 32 * (kc * 2 + 8) + kc;
+    const size_t tf = kdma ? (size_t)fast_table_floats(p, fw, qtn) : (size_t)p.trows;
+    return ((tf * 4 + 15) & ~(size_t)15) + (kdma ? 2 : 1) * kc * 64 + 32 * (kc * 2 + 8) + kc;
 }
 
 long long* g_tbuf = nullptr;  // optional per-workgroup phase timestamps (tools/attn_phases.py)
 
-template <int FW, int QTN, int FROWS, int WPS, int PIPE>
+template <int FW, int QTN, int FROWS, int WPS, int PIPE, bool KDMA = false>
 int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     const int units = (p.q.wh / QTN) * (p.q.ww >> 5);
     const int upw = min(FW, units);
     const int nqs = (units + upw - 1) / upw;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
-    const size_t lds = fast_lds_bytes(p, FROWS);
-    auto kfn = attn_fast_kernel<FW, QTN, FROWS, WPS, PIPE>;
+    const size_t lds = fast_lds_bytes(p, FROWS, FW, QTN, KDMA);
+    if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
+    auto kfn = attn_fast_kernel<FW, QTN, FROWS, WPS, PIPE, KDMA>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     static const int dbg = getenv("GRL_ATTN_DEBUG") ? atoi(getenv("GRL_ATTN_DEBUG")) : 0;  // timing ablations only
@@ -724,7 +803,9 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     if (variant == 5 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 3>(p, st);   // 4-tile fragment ring
     if (variant == 6) return launch_fast_v<8, 2, 8, 2, 2>(p, st);   // 8 waves share one K/V chunk
     if (variant == 7) return launch_fast_v<8, 2, 16, 2, 2>(p, st);  // ... and 16-row chunks
-    return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // bias-fragment reuse
+    if (variant == 9) return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // register-staged K (previous default)
+    const int rc = launch_fast_v<4, 2, 8, 2, 2, true>(p, st);   // bias-fragment reuse + K by DMA, V prefetched one chunk ahead
+    return rc == GRL_ERR_UNSUPPORTED ? launch_fast_v<4, 2, 8, 2, 2>(p, st) : rc;
 }
 
 }  // namespace
