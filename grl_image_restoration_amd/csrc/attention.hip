@@ -455,11 +455,12 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 const uint32_t m0v = lds0 + (uint32_t)(Ks0 - smem) + (ch & 1) * FKC * 64 + q * 1024;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
             }
+            // V: a thread owns (key pair, segment) slots so that the transposed LDS writes are 4 bytes (two keys) wide
 #pragma unroll
             for (int j = 0; j < SPT; ++j) {
-                const int i = tid + j * FW * 64;
-                const int64_t row = key_row(ch, i >> 2, prid[j]);
-                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i & 3) * 8);
+                const int i2 = tid + (j >> 1) * FW * 64;           // pair slot: pair = i2 >> 2, segment = i2 & 3
+                const int64_t row = key_row(ch, 2 * (i2 >> 2) + (j & 1), prid[j]);
+                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i2 & 3) * 8);
             }
         }
     };
@@ -476,13 +477,19 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces (table, K chunk) and V loads have landed
             __builtin_amdgcn_s_barrier();                       // ... everybody's; and all are done reading the previous chunk
             if (tbuf) c1 = __builtin_amdgcn_s_memtime();
+            static_assert(!KDMA || (SPT % 2) == 0, "V slots are key pairs");
 #pragma unroll
-            for (int j = 0; j < SPT; ++j) {
-                const int i = tid + j * FW * 64;
-                const int kk = i >> 2, seg = i & 3;
+            for (int j = 0; j < SPT; j += 2) {
+                const int i2 = tid + (j >> 1) * FW * 64;
+                const int kk0 = 2 * (i2 >> 2), seg = i2 & 3;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * FVROW + kk * 2) = pv_[j][e];
-                if (seg == 0) kreg[kk] = (unsigned char)prid[j];
+                for (int e = 0; e < 8; ++e) {
+                    bf16x2 two;
+                    two[0] = pv_[j][e];
+                    two[1] = pv_[j + 1][e];
+                    *(bf16x2*)(Vt + (seg * 8 + e) * FVROW + kk0 * 2) = two;
+                }
+                if (seg == 0) *(unsigned short*)(kreg + kk0) = (unsigned short)(prid[j] | (prid[j + 1] << 8));
             }
             if (ch + 1 < nch) prefetch(ch + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
