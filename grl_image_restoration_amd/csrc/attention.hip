@@ -491,9 +491,9 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 }
                 if (seg == 0) *(unsigned short*)(kreg + kk0) = (unsigned short)(prid[j] | (prid[j + 1] << 8));
             }
-            if (ch + 1 < nch) prefetch(ch + 1);
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();                       // V^T / region ids visible (raw barrier: the prefetch stays in flight)
+            __builtin_amdgcn_s_barrier();                       // V^T / region ids visible
+            if (ch + 1 < nch) prefetch(ch + 1);                 // issued behind the barrier: its address math delays nobody
         } else {
             bf16x8 pk_[SPT];
             if (!(dbg & 32) || ch == 0)
@@ -811,6 +811,7 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     if (variant == 6) return launch_fast_v<8, 2, 8, 2, 2>(p, st);   // 8 waves share one K/V chunk
     if (variant == 7) return launch_fast_v<8, 2, 16, 2, 2>(p, st);  // ... and 16-row chunks
     if (variant == 9) return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // register-staged K (previous default)
+    if (variant == 10) return launch_fast_v<8, 2, 8, 2, 2, true>(p, st);   // 8 waves share the staged chunks (1 workgroup / CU)
     const int rc = launch_fast_v<4, 2, 8, 2, 2, true>(p, st);   // bias-fragment reuse + K by DMA, V prefetched one chunk ahead
     return rc == GRL_ERR_UNSUPPORTED ? launch_fast_v<4, 2, 8, 2, 2>(p, st) : rc;
 }
