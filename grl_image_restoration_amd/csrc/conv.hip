@@ -180,7 +180,10 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
     // token matrix.  Storing from the accumulator layout instead costs 2*NT instructions of 16 x 32-B pieces per wave
     // (measured: 55 % of the CAB conv2 kernel).
     const bool staged = p.out_dtype != GRL_DT_F32 && p.shuffle_r <= 1 && p.resid == nullptr;
-    constexpr int OROW = NT * 32 + 16;   // bytes per staged pixel row (16 B pad: conflict-free 8-B writes)
+    // Channels CoutP .. round_up(CoutP, 32) of the output rows are written as zeros when the row is wide enough
+    // (ldo): the consumer's K dimension is padded to 32, so its input needs no separate zero fill.
+    constexpr int ZSEGS = ((NT * 16 + 31) / 32 * 32 - NT * 16) / 8;   // 16-B zero segments behind the real channels
+    constexpr int OROW = (NT * 2 + ZSEGS) * 16 + 16;   // bytes per staged pixel row (16 B pad: conflict-free 8-B writes)
     if (staged) {
         __syncthreads();   // all MFMA-phase readers of in_s / wt_s are done: the space is reused for the tile
 #pragma unroll
@@ -210,8 +213,13 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
                 *(uint2*)(prow + c * 2) = pk;
             }
         }
+        const int zs = (p.ldo >= (NT * 16 + 31) / 32 * 32) ? ZSEGS : 0;
+        if (ZSEGS > 0 && tid < TH * TW) {
+#pragma unroll
+            for (int z = 0; z < ZSEGS; ++z) *(uint4*)(smem + tid * OROW + (NT * 2 + z) * 16) = uint4{0, 0, 0, 0};
+        }
         __syncthreads();
-        constexpr int SEGS = NT * 2;   // 16-B segments per pixel row
+        const int SEGS = NT * 2 + zs;   // 16-B segments per pixel row
         for (int i = tid; i < TH * TW * SEGS; i += CWAVES * 64) {
             const int px = i / SEGS, sg = i - px * SEGS;
             const int ty = px / TW, tx = px - ty * TW;
@@ -312,7 +320,7 @@ int launch_conv(const GrlConvArgs& p, hipStream_t st) {
         hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds_all, st, p, 0);
     } else {
         size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
-        const size_t tile_b = (size_t)TH * TW * (NT * 32 + 16);   // LDS-staged 16-bit output tile (epilogue)
+        const size_t tile_b = (size_t)TH * TW * (NT * 32 + 32 + 16);   // LDS-staged 16-bit output tile (epilogue), incl. zero segments
         if (lds < tile_b) lds = tile_b;
         auto kfn = conv3x3_kernel<KC, NT, false>;
         e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

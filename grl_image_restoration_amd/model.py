@@ -510,7 +510,7 @@ class GRL(nn.Module):
     def _cab(self, r, pk, B, H, W, CP):
         """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output (bf16) and the
         per-image squeeze-excite gate; the gate is applied inside the proj+norm1 epilogue."""
-        mid = torch.zeros(B * H * W, pk["cab_mid"], dtype=ops.GEMM_DTYPE, device=r.device)
+        mid = torch.empty(B * H * W, pk["cab_mid"], dtype=ops.GEMM_DTYPE, device=r.device)  # pad channels zero-filled by the conv store
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid)
         raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=ops.GEMM_DTYPE)
         gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])

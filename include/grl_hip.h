@@ -234,7 +234,9 @@ typedef struct GrlConvArgs {
                             /* workgroup channel sums of the output (two-stage global average pool) */
     int64_t pool_stride;    /* floats per workgroup row (>= CoutP; the full layer's channel count    */
                             /* when the layer is computed as several output-channel slabs)          */
-    void* out;              /* [rows, ldo] GRL_DT_F32 or GRL_DT_F16                                 */
+    void* out;              /* [rows, ldo] GRL_DT_F32 or GRL_DT_F16.  16-bit outputs without residual /  */
+                            /* pixel shuffle: channels CoutP .. round_up(CoutP, 32) are written as zeros  */
+                            /* when ldo is at least that wide (the consumer's K is padded to 32)          */
     int32_t out_dtype;
     int64_t ldo;
     int32_t shuffle_r;      /* >1: PixelShuffle(r) store into a [B, H*r, W*r, shuffle_cg] matrix;    */
