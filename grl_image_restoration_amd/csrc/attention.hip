@@ -337,7 +337,7 @@ __host__ __device__ inline int fast_table_floats(const GrlAttnArgs& p, int fw, i
     return n < all ? n : all;
 }
 
-template <int FW, int QTN, int FROWS, int WPS, int PIPE, bool KDMA>
+template <int FW, int QTN, int FROWS, int WPS, int PIPE, int KDMA>
 __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, int dbg, long long* tbuf) {
     long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (tbuf) tm[0] = __builtin_amdgcn_s_memtime();
@@ -362,8 +362,8 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     float* tab = (float*)smem;
     const int tab_floats = KDMA ? fast_table_floats(p, FW, QTN) : p.trows;
     char* Ks0 = smem + (((size_t)tab_floats * 4 + 15) & ~(size_t)15);
-    char* Vt = Ks0 + (KDMA ? 2 : 1) * FKC * 64;
-    unsigned char* kreg = (unsigned char*)(Vt + 32 * FVROW);
+    char* Vt = Ks0 + (KDMA ? 2 : 1) * FKC * 64;                 // KDMA 0/1: V^T [32][FVROW]; KDMA 2: V row-major [2][FKC][64 B]
+    unsigned char* kreg0 = (unsigned char*)(Vt + (KDMA == 2 ? 2 * FKC * 64 : 32 * FVROW));   // KDMA 2: two buffers of FKC bytes
 
     // the table arrives REVERSED (see grl_hip.h) so that a lane's 16 key rows read ascending addresses.
     // It is DMA'd (global_load_lds, 1 KiB per wave-instruction, no staging registers): all pieces are in flight at
@@ -455,9 +455,30 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 const uint32_t m0v = lds0 + (uint32_t)(Ks0 - smem) + (ch & 1) * FKC * 64 + q * 1024;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
             }
+            if constexpr (KDMA == 2) {
+                // V the same way, row-major and unswizzled: the PV operand is fetched with ds_read_b64_tr_b16 (hardware
+                // transpose across 16 lanes), so nothing passes through registers and there is no commit phase at all
+#pragma unroll
+                for (int j = 0; j < (FKC * 64) / (FW * 1024); ++j) {
+                    const int q = wave_u + j * FW;
+                    const int sigma = q * 64 + lane, kk = sigma >> 2, seg = sigma & 3;
+                    int rid;
+                    const int64_t row = key_row(ch, kk, rid);
+                    const bf16* g = (const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8;
+                    const uint32_t m0v = lds0 + (uint32_t)(Vt - smem) + (ch & 1) * FKC * 64 + q * 1024;
+                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
+                }
+                if (p.masked) {
+                    for (int kk = tid; kk < FKC; kk += FW * 64) {
+                        int rid;
+                        key_row(ch, kk, rid);
+                        kreg0[(ch & 1) * FKC + kk] = (unsigned char)rid;
+                    }
+                }
+            }
             // V: a thread owns (key pair, segment) slots so that the transposed LDS writes are 4 bytes (two keys) wide
 #pragma unroll
-            for (int j = 0; j < SPT; ++j) {
+            for (int j = 0; j < (KDMA == 2 ? 0 : SPT); ++j) {
                 const int i2 = tid + (j >> 1) * FW * 64;           // pair slot: pair = i2 >> 2, segment = i2 & 3
                 const int64_t row = key_row(ch, 2 * (i2 >> 2) + (j & 1), prid[j]);
                 pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i2 & 3) * 8);
@@ -473,11 +494,18 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
         long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
         if (tbuf) c0 = __builtin_amdgcn_s_memtime();
         char* Ks = Ks0 + (KDMA ? (ch & 1) * FKC * 64 : 0);
-        if constexpr (KDMA) {
+        const char* Vs = Vt + (ch & 1) * FKC * 64;                              // KDMA 2 only
+        unsigned char* kreg = kreg0 + (KDMA == 2 ? (ch & 1) * FKC : 0);
+        if constexpr (KDMA == 2) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA pieces of chunk ch landed, own LDS traffic retired
+            __builtin_amdgcn_s_barrier();                                  // everybody's; and all are done with the buffers of chunk ch-1
+            if (tbuf) c1 = __builtin_amdgcn_s_memtime();
+            if (ch + 1 < nch) prefetch(ch + 1);
+        } else if constexpr (KDMA == 1) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces (table, K chunk) and V loads have landed
             __builtin_amdgcn_s_barrier();                       // ... everybody's; and all are done reading the previous chunk
             if (tbuf) c1 = __builtin_amdgcn_s_memtime();
-            static_assert(!KDMA || (SPT % 2) == 0, "V slots are key pairs");
+            static_assert(KDMA != 1 || (SPT % 2) == 0, "V slots are key pairs");
 #pragma unroll
             for (int j = 0; j < SPT; j += 2) {
                 const int i2 = tid + (j >> 1) * FW * 64;
@@ -587,18 +615,36 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
             // elsewhere, so they survive.  Only a strip's first key row gathers twice.  LDS bias reads,
             // the dominant cost of the plain loop (tools/ubench: +530 cycles per 32 reads), are halved.
             static_assert(QTN == 2 || PIPE != 2, "fragment reuse is written for two query tiles per wave");
+            static_assert(KDMA != 2 || PIPE == 2, "the transpose-read V path is written for the PIPE == 2 loop");
             auto frags = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], uint32_t (&ids)[4]) {
                 const int kb = kt * 32;
                 const int kk = kb + l31;
                 const int sw = (kk >> 2) & 3;
                 kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
                 kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
+                if constexpr (KDMA == 2) {
+                    // lane (d = l31, half): elements e < 4 = keys 16*s2 + 4*half + e, e >= 4 = keys 16*s2 + 8 + 4*half + e-4.
+                    // ds_read_b64_tr_b16: within a 16-lane group lane i points at row i>>2, columns 4*(i&3) of a [4 keys][16 d]
+                    // block and receives column (i & 15), rows 0..3.
+                    typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+                    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+                    const char* vb = Vs + (kb + 4 * half + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
-                    const bf16x4 lo = *(const bf16x4*)(vp);
-                    const bf16x4 hi = *(const bf16x4*)(vp + 16);
-                    vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (16 * s2) * 64));
+                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (16 * s2 + 8) * 64));
+                        typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8;
+                        const s16x8 both = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                        vf[s2] = __builtin_bit_cast(bf16x8, both);
+                    }
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
+                        const bf16x4 lo = *(const bf16x4*)(vp);
+                        const bf16x4 hi = *(const bf16x4*)(vp + 16);
+                        vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    }
                 }
                 if (border) {
 #pragma unroll
@@ -775,15 +821,17 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     }
 }
 
-size_t fast_lds_bytes(const GrlAttnArgs& p, int frows, int fw = 4, int qtn = 2, bool kdma = false) {
+size_t fast_lds_bytes(const GrlAttnArgs& p, int frows, int fw = 4, int qtn = 2, int kdma = 0) {
     const size_t kc = (size_t)frows * 32;
     const size_t tf = kdma ? (size_t)fast_table_floats(p, fw, qtn) : (size_t)p.trows;
-    return ((tf * 4 + 15) & ~(size_t)15) + (kdma ? 2 : 1) * kc * 64 + 32 * (kc * 2 + 8) + kc;
+    const size_t tab = (tf * 4 + 15) & ~(size_t)15;
+    if (kdma == 2) return tab + 4 * kc * 64 + 2 * kc;
+    return tab + (kdma ? 2 : 1) * kc * 64 + 32 * (kc * 2 + 8) + kc;
 }
 
 long long* g_tbuf = nullptr;  // optional per-workgroup phase timestamps (tools/attn_phases.py)
 
-template <int FW, int QTN, int FROWS, int WPS, int PIPE, bool KDMA = false>
+template <int FW, int QTN, int FROWS, int WPS, int PIPE, int KDMA = 0>
 int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     const int units = (p.q.wh / QTN) * (p.q.ww >> 5);
     const int upw = min(FW, units);
@@ -811,8 +859,16 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
     if (variant == 6) return launch_fast_v<8, 2, 8, 2, 2>(p, st);   // 8 waves share one K/V chunk
     if (variant == 7) return launch_fast_v<8, 2, 16, 2, 2>(p, st);  // ... and 16-row chunks
     if (variant == 9) return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // register-staged K (previous default)
-    if (variant == 10) return launch_fast_v<8, 2, 8, 2, 2, true>(p, st);   // 8 waves share the staged chunks (1 workgroup / CU)
-    const int rc = launch_fast_v<4, 2, 8, 2, 2, true>(p, st);   // bias-fragment reuse + K by DMA, V prefetched one chunk ahead
+    if (variant == 10) return launch_fast_v<8, 2, 8, 2, 2, 1>(p, st);   // 8 waves share the staged chunks (1 workgroup / CU)
+    if (variant == 11) return launch_fast_v<4, 2, 8, 2, 2, 1>(p, st);   // K by DMA, V prefetched in registers + transposed commit
+    if (variant == 12) return launch_fast_v<4, 2, 8, 2, 2, 2>(p, st);   // K and V by DMA (8-row chunks)
+    if (variant == 13) return launch_fast_v<4, 2, 4, 2, 2, 2>(p, st);   // K and V by DMA (4-row chunks)
+    // default: bias-fragment reuse loop; K and V by DMA into double buffers and V through the hardware transpose read when
+    // two workgroups still fit a CU (window, window->anchor: -2 %), else K by DMA + V through registers (anchor->window:
+    // its 27 KB table slice + four 16 KB buffers would leave one workgroup per CU; 4-row chunks are slower)
+    int rc = GRL_ERR_UNSUPPORTED;
+    if (fast_lds_bytes(p, 8, 4, 2, 2) <= 80 * 1024) rc = launch_fast_v<4, 2, 8, 2, 2, 2>(p, st);
+    if (rc == GRL_ERR_UNSUPPORTED) rc = launch_fast_v<4, 2, 8, 2, 2, 1>(p, st);
     return rc == GRL_ERR_UNSUPPORTED ? launch_fast_v<4, 2, 8, 2, 2>(p, st) : rc;
 }
 
