@@ -387,7 +387,10 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
         pool = torch.empty(nwg, CoutP, dtype=torch.float32, device=x.device)
     # at most 192 output channels per launch; larger layers are split on the channel axis
     step = CoutP
-    split = int(os.environ.get("GRL_CONV_SPLIT", "0"))   # experiment: narrower launches -> 2 workgroups per CU
+    # Short-K layers (CAB conv2: 64 -> 192 channels, 9 tap steps in all) are epilogue/store dominated with one 104 KB-LDS
+    # workgroup per CU; two launches of 96 output channels run two workgroups per CU whose store and MFMA phases
+    # overlap (137 -> 101 us per 4 tiles).  Long-K layers (stage convs) lose from the split.  GRL_CONV_SPLIT overrides.
+    split = int(os.environ.get("GRL_CONV_SPLIT", "96" if CinP <= 64 else "0"))
     if split and CoutP > split and CoutP % split == 0 and shuffle_r <= 1:
         step = split
     elif CoutP > 192:
