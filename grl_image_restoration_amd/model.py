@@ -499,14 +499,6 @@ class GRL(nn.Module):
             x = F.pad(x, (0, pw, 0, ph), "constant")
         return x
 
-    def _side_stream(self, dev):
-        if os.environ.get("GRL_SIDE_STREAM", "0") != "1":
-            return None
-        st = getattr(self, "_side", None)
-        if st is None or st.device != dev:
-            st = self._side = torch.cuda.Stream(dev)
-        return st
-
     def _cab(self, r, pk, B, H, W, CP):
         """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output (bf16) and the
         per-image squeeze-excite gate; the gate is applied inside the proj+norm1 epilogue."""
@@ -525,13 +517,6 @@ class GRL(nn.Module):
         dev = r.device
         # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
-        side = self._side_stream(dev) if self.local_connection else None
-        if side is not None:
-            # the CAB branch only reads r: run it on a second HIP stream beside the attention chain
-            main = torch.cuda.current_stream(dev)
-            side.wait_stream(main)
-            with torch.cuda.stream(side):
-                cab, gate = self._cab(r, pk, B, H, W, CP)
         if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
             qkv = ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"])
         else:
@@ -562,12 +547,7 @@ class GRL(nn.Module):
                       fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
         ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
                       table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
-        if side is not None:
-            main.wait_stream(side)
-            cab.record_stream(main)
-            gate.record_stream(main)
-        else:
-            cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
+        cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         if "proj_blob" in pk and "mlp_blob" in pk and H * W >= 128 and os.environ.get("GRL_FUSED_TAIL", "1") != "0":
             return ops.block_tail(att, r, cab, gate, H * W, pk["proj_blob"], pk["proj_b"], pk["n1_g"], pk["n1_b"], pk["mlp_blob"],
                                   pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C, res_scale=self.res_scale)
