@@ -18,6 +18,22 @@ __global__ __launch_bounds__(256) void k(float* out, int iters, int misalign) {
             const float* tp = lds + base - (lane & 31) + 4 * (lane >> 5);
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += tp[(r & 3) + 8 * (r >> 2)];
+        } else if constexpr (MODE == 8) {   // kernel offsets (read2 pairs), ascending lanes, no half offset
+            const float* tp = lds + base + lane;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += tp[(r & 3) + 8 * (r >> 2)];
+        } else if constexpr (MODE == 9) {   // descending lanes + half offset, offsets 64*r (no read2 pairing)
+            const float* tp = lds + base - (lane & 31) + 4 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += tp[64 * r];
+        } else if constexpr (MODE == 10) {  // descending lanes, NO half offset, kernel offsets
+            const float* tp = lds + base - (lane & 31);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += tp[(r & 3) + 8 * (r >> 2)];
+        } else if constexpr (MODE == 11) {  // descending lanes, half offset 32 + 4 (second table copy), kernel offsets
+            const float* tp = lds + base - (lane & 31) + 36 * (lane >> 5);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += tp[(r & 3) + 8 * (r >> 2)];
         } else if constexpr (MODE == 1) {   // 16 x ds_read_b32, ascending lanes (textbook conflict-free)
             const float* tp = lds + base + lane;
 #pragma unroll
@@ -101,9 +117,13 @@ void run(const char* name, int wps, int reads, int bytes_per_lane, int misalign)
 }
 
 int main() {
-    for (int w : {2, 4}) {
+    for (int w : {4}) {
         run<0>("b32 x16 descending+half (kernel pattern)", w, 16, 4, 0);
         run<1>("b32 x16 ascending lanes", w, 16, 4, 0);
+        run<8>("b32 x16 ascending, kernel offsets (read2)", w, 16, 4, 0);
+        run<9>("b32 x16 descending+half, offsets 64r", w, 16, 4, 0);
+        run<10>("b32 x16 descending, no half offset", w, 16, 4, 0);
+        run<11>("b32 x16 descending, half offset 36", w, 16, 4, 0);
         run<2>("b64 x8 lane-consecutive, serial waits", w, 8, 8, 0);
         run<3>("b64 x8 descending pattern", w, 8, 8, 0);
         run<3>("b64 x8 descending pattern", w, 8, 8, 1);
