@@ -334,7 +334,9 @@ __host__ __device__ inline int fast_table_floats(const GrlAttnArgs& p, int fw, i
     const int D = p.q.ww + p.k.ww - 1;
     const int n = (rows - 1 + p.k.wh) * D + 4;
     const int all = (p.trows + 3) & ~3;
-    return n < all ? n : all;
+    // whole 1-KiB DMA pieces: the last piece of the table copy must not reach into the K buffer behind the table,
+    // whose own DMA is in flight at the same time
+    return ((n < all ? n : all) + 255) & ~255;
 }
 
 template <int FW, int QTN, int FROWS, int WPS, int PIPE, int KDMA>
