@@ -31,8 +31,12 @@ struct QkvShape {
     static constexpr int PIECES = BUFP / 1024;
 };
 
-template <int KSTEPS, int SPC, int WV>
+// WV waves per workgroup.  TOK = token groups (16 tokens each) per tile; with WV == 2 * TOK (SPC == 2) the waves w and
+// w + TOK share a token group and take one head slot of every chunk each: twice the waves per SIMD to overlap the LDS
+// read, MFMA, normalise and store phases of a chunk.
+template <int KSTEPS, int SPC, int WV, int TOK>
 __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
+    static_assert(WV == TOK || (WV == 2 * TOK && SPC == 2), "waves either own a token group or half of its slots");
     using S = QkvShape<KSTEPS, SPC>;
     constexpr int CP = S::CP;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -56,13 +60,13 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
         }
     };
     constexpr int XROW = CP * 4 + 16, XSEG = XROW / 16;
-    constexpr int XPIECES = (WV * 16 * XROW + 1023) / 1024;
+    constexpr int XPIECES = (TOK * 16 * XROW + 1023) / 1024;
     const int xoff = 2 * S::BUFP;
     auto fetch_x = [&](int tile, int piece) {
         const int sigma = piece * 64 + lane;
         int row = sigma / XSEG, seg = sigma - row * XSEG;
         seg = seg < XSEG - 1 ? seg : XSEG - 2;
-        int m = tile * (WV * 16) + row;
+        int m = tile * (TOK * 16) + row;
         m = m < p.M ? m : p.M - 1;
         const float* g = p.x + (int64_t)m * p.ldx + seg * 4;
         const uint32_t m0v = lds0 + xoff + piece * 1024;
@@ -70,14 +74,16 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
     };
     const char* xt = smem + xoff;
 
-    const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
+    const int ntiles = (p.M + TOK * 16 - 1) / (TOK * 16);
     if ((int)blockIdx.x >= ntiles) return;
+    const int tg = wave % TOK, sl0 = wave / TOK;          // token group of this wave; first slot it computes
+    constexpr int SLS = WV / TOK;                          // slot stride
     for (int q = wave_u; q < XPIECES; q += WV) fetch_x(blockIdx.x, q);
     fetch(0, 0);
     int it = 0;
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const int m = tile * (WV * 16) + wave * 16 + r16;
+        const int m = tile * (TOK * 16) + tg * 16 + r16;
         const bool valid = m < p.M;
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -85,7 +91,7 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
         // 32s + 16 + 4*g4 + [0..3] (the weight columns are packed in the same order)
         gemm_x8 a[KSTEPS];
         {
-            const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
+            const char* rowp = xt + (tg * 16 + r16) * XROW + 16 * g4;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
                 const float4 v0 = *(const float4*)(rowp + 128 * s), v1 = *(const float4*)(rowp + 128 * s + 64);
@@ -106,7 +112,8 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
             fetch(c + 1 < nchunks ? c + 1 : 0, ((it + 1) & 1) * S::BUFP);
             for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) fetch_x(next_tile, q);
 #pragma unroll
-            for (int sl = 0; sl < SPC; ++sl) {
+            for (int si = 0; si < SPC / SLS; ++si) {
+                const int sl = sl0 + si * SLS;
                 const char* wb = cur + sl * S::SLOT;
                 gemm_x8 wa[KSTEPS], wb_[KSTEPS];
 #pragma unroll
@@ -146,15 +153,15 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
     }
 }
 
-template <int KSTEPS, int SPC, int WV>
+template <int KSTEPS, int SPC, int WV, int TOK = WV>
 int launch_qkv(const GrlQkvArgs& p, hipStream_t st) {
     using S = QkvShape<KSTEPS, SPC>;
-    const size_t lds = 2 * (size_t)S::BUFP + (size_t)((WV * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
-    const int ntiles = (p.M + WV * 16 - 1) / (WV * 16);
+    const size_t lds = 2 * (size_t)S::BUFP + (size_t)((TOK * 16 * (S::CP * 4 + 16) + 1023) / 1024) * 1024;
+    const int ntiles = (p.M + TOK * 16 - 1) / (TOK * 16);
     static const int cap0 = getenv("GRL_PERSIST_GRID") ? atoi(getenv("GRL_PERSIST_GRID")) : 256;   // tuning knob
     const int cap = cap0 * (WV <= 4 ? 2 : 1);       // small workgroups: two per CU (or one beside a workgroup of another kernel)
     const int grid = ntiles < cap ? ntiles : cap;   // persistent workgroups
-    auto kfn = qkv_kernel<KSTEPS, SPC, WV>;
+    auto kfn = qkv_kernel<KSTEPS, SPC, WV, TOK>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3(grid), dim3(WV * 64), lds, st, p);
@@ -165,6 +172,8 @@ int launch_qkv(const GrlQkvArgs& p, hipStream_t st) {
 template <int KSTEPS>
 int launch_qkv_k(const GrlQkvArgs& p, hipStream_t st) {
     static const int small = getenv("GRL_QKV_SMALL") ? atoi(getenv("GRL_QKV_SMALL")) : 0;   // experiment: 64-token workgroups
+    static const int w16 = getenv("GRL_QKV_W16") ? atoi(getenv("GRL_QKV_W16")) : 1;       // 16 waves, slot-split (-5 % vs 8 waves)
+    if (p.nslots % 2 == 0 && w16) return launch_qkv<KSTEPS, 2, 16, 8>(p, st);
     if (p.nslots % 2 == 0) return small ? launch_qkv<KSTEPS, 2, 4>(p, st) : launch_qkv<KSTEPS, 2, 8>(p, st);
     return launch_qkv<KSTEPS, 1, 8>(p, st);
 }
