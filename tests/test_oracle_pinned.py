@@ -121,3 +121,54 @@ def test_engine_restatements():
     assert torch.allclose(E.rgb2ycbcr_y(white), torch.full((1, 1, 4, 4), 235.0 / 255.0))
     a, b = torch.zeros(1, 1, 2, 2), torch.full((1, 1, 2, 2), 0.1)
     assert abs(E.psnr(a, b).item() - 20.0) < 1e-4
+
+
+# ---- training-step gradients (groundwork for the backward kernels) ---------------------------------
+def _load_grad_fixture():
+    import json
+    import os
+
+    import numpy as np
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_grads", "train_base2x2_sr4_64.npz")
+    z = np.load(path, allow_pickle=False)
+    return json.loads(str(z["meta"])), z
+
+
+def test_oracle_gradients_reproduce_golden():
+    """Autograd through the functional oracle reproduces the frozen gradients of the REAL reference (L1 loss, GRL-Base
+    blocks x4 SR, eval mode): loss, input gradient, the norm of all 156 parameter gradients and every small tensor."""
+    import json
+
+    from oracle import make_golden_grads as G
+
+    meta, z = _load_grad_fixture()
+    assert meta["oracle_vs_reference_max_rel_grad"] < 1e-4
+    cfg = meta["cfg"]
+    sd = O.seeded_state_dict(product_shapes(cfg), meta["weight_seed"])
+    loss, gin, grads = G.oracle_step(cfg, sd, torch.from_numpy(z["input"]), torch.from_numpy(z["target"]))
+    assert abs(float(loss) - meta["loss"]) < 1e-6
+    gref = torch.from_numpy(z["grad_input"])
+    assert ((gin - gref).norm() / gref.norm()).item() < 1e-4
+    names = json.loads(str(z["grad_norm_names"]))
+    assert set(names) == set(grads)
+    for k, n in zip(names, z["grad_norms"]):
+        assert abs(grads[k].norm().item() - n) <= 1e-4 * max(n, 1e-8), k
+    small = [k for k in z.files if k.startswith("grad::")]
+    assert len(small) > 50
+    for k in small:
+        g, r = grads[k[6:]], torch.from_numpy(z[k])
+        assert ((g - r).norm() / r.norm().clamp_min(1e-12)).item() < 2e-4, k
+
+
+@needs_ref
+def test_oracle_gradients_match_live_reference():
+    from oracle import make_golden_grads as G
+
+    cfg, sd, lq, gt = G.make_case()
+    loss, gin, grads = G.reference_step(cfg, sd, lq, gt)
+    lo, gio, go = G.oracle_step(cfg, sd, lq, gt)
+    assert abs(float(loss) - float(lo)) < 1e-6 and set(grads) == set(go)
+    assert ((gin - gio).norm() / gin.norm()).item() < 1e-4
+    for k in grads:
+        assert ((grads[k] - go[k]).norm() / grads[k].norm().clamp_min(1e-20)).item() < 1e-4, k
