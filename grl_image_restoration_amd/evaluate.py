@@ -49,7 +49,7 @@ def load_checkpoint(model, path_or_obj, strict: bool = True):
     return model.load_state_dict(sd, strict=strict)
 
 
-# ---- metric (restated here so that the product never imports oracle/) ---------------------------------------------
+# ---- metric (restated here: the product does not depend on the test infrastructure) -------------------------------
 def tensor_round(img: torch.Tensor, data_range: float = 1.0) -> torch.Tensor:
     """utils/utils_image.py:30-33 (out of place)."""
     return (img.clamp(0.0, data_range) * 255.0 / data_range).round() * data_range / 255.0

@@ -180,3 +180,22 @@ def test_mlp_blob_layout():
             assert torch.equal(W1[:, :, s_], ref1.view(32, CP // 32, 32)[:, :, ch].to(torch.float16))
             assert torch.equal(W2[:, s_], ref2[:, ch].to(torch.float16))
         assert torch.equal(B1, refb)
+
+
+def test_product_never_touches_the_oracle_or_the_reference():
+    """The oracle is test infrastructure: nothing under the package (nor the C sources) may import, open or name it,
+    and nothing may read /root/reference at run time."""
+    import re
+
+    pkg = os.path.join(ROOT, "grl_image_restoration_amd")
+    bad = []
+    for d, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".hip", ".h", "Makefile")):
+                txt = open(os.path.join(d, f), errors="ignore").read()
+                if re.search(r"^\s*(from|import)\s+oracle\b", txt, re.M) or "oracle/" in txt or "/root/reference" in txt:
+                    bad.append(os.path.join(d, f))
+    assert not bad, bad
+    for f in ("bench.py", "__graft_entry__.py"):
+        txt = open(os.path.join(ROOT, f)).read()
+        assert "/root/reference" not in txt and "refshim" not in txt
