@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """Throughput benchmark of the GRL hot path on MI355X (contract in the task statement).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1 and no torchrun environment: bench.py spawns the N ranks itself (one process per GPU, RCCL);
+        under `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...` it uses the launcher's ranks.
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): GRL-Base x4 SR,
 released-checkpoint geometry (window 32, stripes 64x64, anchor /2), batches of 256x256 LQ tiles,
@@ -9,16 +11,26 @@ synthetic uniform-random pixels, random-init weights.  One step = one forward of
 per GPU with the tiles already resident in HBM.  Tiles are independent units: ranks shard them
 with no data-path collective (weak scaling); the only collectives are the timing barrier/max.
 
-Prints ONE JSON line on rank 0 with the contract fields plus
-  roofline     : the dominant kernel (cosine window/stripe attention, MFMA-bound): algorithmic
-                 FLOPs per launch / its mean launch duration measured with HIP events on the
-                 launching stream during the timed steps, against the 2.5 PFLOP/s bf16 dense peak
-  cpu_baseline : the CPU oracle (a torch-fp32 port of the reference forward) timed on this box's
-                 host cores on a bounded sample (one 64x64 LQ tile of the same network).
+The timed region contains no probes.  After it, separate untimed passes collect
+  roofline       : the dominant kernel (cosine window / stripe attention, MFMA-bound): algorithmic FLOPs per launch /
+                   its mean launch duration from HIP events on the launching stream over K more steps of the same
+                   schedule (two tile groups on two streams -> residency under overlap) and with the overlap off
+                   (`exclusive_*`), against the 2.5 PFLOP/s fp16/bf16 dense peak
+  trained_scales : the same K steps with every logit scale at / around the clamp exp(ln 100) (what a trained
+                   checkpoint looks like): the fast attention kernels must stay selected (ratio ~ 1)
+  tiled          : (N > 1) strong-scaling leg: tiling.forward_tiled of a fixed 8 x N-tile list, sharded over the ranks
+                   with its RCCL all-gather
+  cpu_baseline   : the CPU oracle (a torch-fp32 port of the reference forward) on this box's host cores: a
+                   128x128 LQ tile of the same network (1/4 of a bench tile), 1 warm-up + median of 2, thread
+                   count picked by a sweep on a 64x64 tile.
+--config 2 / --config 4 measure BASELINE configs[1] / configs[3] (Small denoise 128x128; Base deblur 384x384 tiles) with
+the same harness (their lines are kept under profiles/).
 """
 import argparse
 import json
+import math
 import os
+import socket
 import sys
 import time
 
@@ -29,7 +41,14 @@ if ROOT not in sys.path:
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK_BF16_TFLOPS = 2500.0  # MI355X dense bf16 MFMA (MI355X_MICROARCH.md)
+PEAK_F16_TFLOPS = 2500.0  # MI355X dense fp16 / bf16 MFMA (MI355X_MICROARCH.md)
+
+WORKLOADS = {
+    # config id -> (baseline_config index, tile side, label, GFLOP per tile or None)
+    3: (3, 256, "BASELINE configs[2]: GRL-Base x4 SR, 256x256 LQ tiles, ckpt geometry (window 32, stripe 64x64, anchor /2)", 5468.5),
+    2: (2, 128, "BASELINE configs[1]: GRL-Small denoise sigma 25, 128x128 tiles, dn geometry (window 16, stripe 64x128, anchor /4)", 181.0),
+    4: (4, 384, "BASELINE configs[3]: GRL-Base motion deblur, 384x384 tiles of a 1280x720 frame (window 12, stripe 48x96, anchor /4)", None),
+}
 
 
 def attention_flops_per_launch(cfg, tiles, hw):
@@ -47,117 +66,171 @@ def attention_flops_per_launch(cfg, tiles, hw):
 
 
 def cpu_baseline(cfg):
-    """Reference algorithm on the host cores: oracle/grl_oracle.py (kind 'port'), one 64x64 LQ tile."""
+    """Reference algorithm on the host cores: oracle/grl_oracle.py (kind 'port')."""
     from oracle import grl_oracle as O
 
     from grl_image_restoration_amd import GRL
 
     torch.manual_seed(0)
-    torch.set_num_threads(min(32, os.cpu_count() or 1))  # small per-op work: more threads only add overhead
-    c = dict(cfg)
-    c["img_size"] = 64
-    m = GRL(**c)
-    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    x = torch.rand(1, 3, 64, 64, generator=torch.Generator().manual_seed(1))
-    t0 = time.time()
-    with torch.no_grad():
-        O.grl_forward(x, c, sd)
-    dt = time.time() - t0
+
+    def make(side):
+        c = dict(cfg)
+        c["img_size"] = side
+        m = GRL(**c)
+        return c, {k: v.detach().clone() for k, v in m.state_dict().items()}
+
+    def run(c, sd, side):
+        x = torch.rand(1, 3, side, side, generator=torch.Generator().manual_seed(1))
+        t0 = time.time()
+        with torch.no_grad():
+            O.grl_forward(x, c, sd)
+        return time.time() - t0
+
+    ncpu = os.cpu_count() or 1
+    c64, sd = make(64)
+    sweep = {}
+    for th in sorted({min(ncpu, t) for t in (8, 16, 32, 64)}):
+        torch.set_num_threads(th)
+        run(c64, sd, 64) if not sweep else None   # first call: page-in / allocator warm-up
+        sweep[th] = run(c64, sd, 64)
+    best = min(sweep, key=sweep.get)
+    torch.set_num_threads(best)
+    side = 128
+    c128, _ = make(side)
+    run(c128, sd, side)                                     # warm-up
+    times = sorted(run(c128, sd, side) for _ in range(2))
+    dt = 0.5 * (times[0] + times[1])
     return {
-        "value": round(64 * 64 / dt / 1e6, 6),
+        "value": round(side * side / dt / 1e6, 6),
         "unit": "LQ megapixels/s",
-        "cores": torch.get_num_threads(),
+        "cores": best,
+        "host_cpus": ncpu,
         "kind": "port",
-        "sample": f"1 forward of one 64x64 LQ tile, same network/geometry, fp32 torch CPU, {dt:.1f} s "
-                  "(a 256x256 tile is 16x the pixels)",
+        "thread_sweep_s_per_64x64_tile": {str(k): round(v, 2) for k, v in sweep.items()},
+        "sample": f"one 128x128 LQ tile (1/4 of a bench tile, same network/geometry), fp32 torch CPU, 1 warm-up + median of 2: "
+                  f"{dt:.1f} s per forward on {best} threads",
     }
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--tiles", type=int, default=8, help="256x256 LQ tiles per GPU per step")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
-    torch.cuda.set_device(dev)
-
-    from grl_image_restoration_amd import GRL, baseline_config, ops
-
-    cfg = baseline_config(3)
-    torch.manual_seed(0)
-    model = GRL(**cfg).eval().to(dev)
-    g = torch.Generator(device="cpu").manual_seed(1 + rank)
-    x = torch.rand(args.tiles, 3, 256, 256, generator=g).to(dev)
-
+def timed_steps(model, x, steps, world):
     with torch.no_grad():
-        for _ in range(args.warmup):
-            y = model(x)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
-        ops.profile_begin()
         t0 = time.perf_counter()
-        for _ in range(args.steps):
+        for _ in range(steps):
             y = model(x)
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        prof = ops.profile_end()
-    assert torch.isfinite(y).all()
     if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        t = torch.tensor([dt], device=x.device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    return dt, y
 
-    # Untimed extra pass on rank 0: the same launches with the stream overlap switched off.  With two tile groups in
-    # flight an attention launch shares the CUs with the other group's kernels, so its HIP-event bracket (the
-    # contract's `achieved`) measures residency; the exclusive figure is the kernel's own rate.
-    excl = {}
-    if rank == 0 and model.stream_groups(args.tiles) > 1:
-        os.environ["GRL_SPLIT_STREAMS"] = "1"
-        with torch.no_grad():
+
+def run(args, rank, world, local_rank):
+    if world > 1:
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    from grl_image_restoration_amd import GRL, baseline_config, ops, tiling
+
+    ci, side, label, gflop_tile = WORKLOADS[args.config]
+    cfg = baseline_config(ci)
+    cfg["img_size"] = side
+    torch.manual_seed(0)
+    model = GRL(**cfg).eval().to(dev)
+    g = torch.Generator(device="cpu").manual_seed(1 + rank)
+    x = torch.rand(args.tiles, 3, side, side, generator=g).to(dev)
+    scale = cfg["upscale"]
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            y = model(x)
+    dt, y = timed_steps(model, x, args.steps, world)
+    assert torch.isfinite(y).all()
+
+    # ---- untimed passes (rank 0 measures; every rank runs the same launches so that the barriers match) ----
+    groups = model.stream_groups(args.tiles)   # tile groups advancing on separate HIP streams (one launch = one group)
+    with torch.no_grad():
+        ops.profile_begin()
+        dt_probe, _ = timed_steps(model, x, args.steps, world)
+        prof = ops.profile_end()
+        excl = {}
+        if groups > 1:
+            os.environ["GRL_SPLIT_STREAMS"] = "1"
             model(x)
             torch.cuda.synchronize()
             ops.profile_begin()
             model(x)
             p1 = ops.profile_end()
-        del os.environ["GRL_SPLIT_STREAMS"]
-        a1 = p1.get("attention", [])
-        if a1:
-            ms1 = sum(a1) / len(a1)
-            fl1 = attention_flops_per_launch(cfg, args.tiles, (256, 256))
-            excl = {"exclusive_mean_launch_ms": round(ms1, 4), "exclusive_tiles_per_launch": args.tiles,
-                    "exclusive_achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2),
-                    "exclusive_frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4)}
+            del os.environ["GRL_SPLIT_STREAMS"]
+            a1 = p1.get("attention", [])
+            if a1:
+                ms1 = sum(a1) / len(a1)
+                fl1 = attention_flops_per_launch(cfg, args.tiles, (side, side))
+                excl = {"exclusive_mean_launch_ms": round(ms1, 4), "exclusive_tiles_per_launch": args.tiles,
+                        "exclusive_achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2),
+                        "exclusive_frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4)}
+
+    # trained-scale leg: logit scales around the clamp (same seeded draw as the *_hiscale parity fixtures)
+    trained = None
+    if not args.no_trained_scales:
+        gs = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for n, p_ in model.named_parameters():
+                if n.endswith("logit_scale"):
+                    p_.copy_((math.log(100.0) + 0.3 * torch.randn(p_.shape, generator=gs)).to(dev))
+            for _ in range(max(1, args.warmup)):
+                yt = model(x)
+        dt_t, yt = timed_steps(model, x, args.steps, world)
+        assert torch.isfinite(yt).all()
+        trained = {"ms_per_step": round(dt_t / args.steps * 1e3, 3), "ratio_to_random_init": round(dt_t / dt, 4),
+                   "logit_scales": "exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at the clamp"}
+
+    # strong-scaling leg: one fixed tile list sharded over the ranks, stitched through the RCCL all-gather
+    tiled = None
+    if world > 1 and not args.no_tiled:
+        n_t = 8 * world
+        cols = 8
+        rows = n_t // cols
+        frame = torch.rand(1, 3, rows * side, cols * side, generator=torch.Generator().manual_seed(3)).to(dev)   # same on every rank
+        with torch.no_grad():
+            tiling.forward_tiled(model, frame, side, 0, scale, tile_batch=args.tiles)
+            dt_s, _ = timed_steps(lambda f: tiling.forward_tiled(model, f, side, 0, scale, tile_batch=args.tiles), frame, 3, world)
+        tiled = {"tiles": n_t, "ms_per_frame": round(dt_s / 3 * 1e3, 3),
+                 "value": round(n_t * side * side * 3 / dt_s / 1e6, 4), "unit": "LQ megapixels/s", "scaling": "strong",
+                 "collective": f"all_gather_into_tensor of {n_t // world} x (3, {side * scale}, {side * scale}) fp32 tiles per rank (RCCL)"}
 
     if rank == 0:
-        mp = world * args.tiles * 256 * 256 * args.steps / dt / 1e6
+        mp = world * args.tiles * side * side * args.steps / dt / 1e6
         att = prof.get("attention", [])
         att_ms = sum(att) / max(len(att), 1)
-        groups = model.stream_groups(args.tiles)   # tile groups advancing on separate HIP streams (one launch = one group)
-        fl = attention_flops_per_launch(cfg, args.tiles // groups, (256, 256))
+        fl = attention_flops_per_launch(cfg, args.tiles // groups, (side, side))
         ach = fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "attention_traffic.json")
-        if os.path.isfile(tpath):
+        if args.config == 3 and os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_tile")  # PMC pass (profiles/), per tile
             traffic = traffic * (args.tiles // groups) if traffic else None
+        conf = {
+            "workload": label + ", random-init weights",
+            "tiles_per_gpu_per_step": args.tiles,
+            "hr_megapixels_per_s": round(mp * scale * scale, 2),
+            "parallelism": f"tile-sharded x{world}, no data-path collective",
+            "precision_mode": model.precision,
+        }
+        if gflop_tile:
+            conf.update(gflop_per_tile=gflop_tile, model_tflops=round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12, 2))
         line = {
-            "metric": "LQ megapixels/s, GRL-Base x4 SR, 256x256 LQ tiles",
+            "metric": "LQ megapixels/s, " + label.split(":")[1].split(",")[0].strip() + f", {side}x{side} LQ tiles",
             "value": round(mp, 4),
             "unit": "LQ megapixels/s",
             "n_gpus": world,
@@ -167,39 +240,77 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "bf16 (attention) / f16 (linear, conv) MFMA operands, f32 accumulate + residual",
+            "dtype": "f16 MFMA operands (attention, linear, conv), f32 accumulate + residual stream",
             "data": "synthetic",
-            "config": {
-                "workload": "BASELINE configs[2]: GRL-Base x4 SR, 256x256 LQ tiles, ckpt geometry "
-                            "(window 32, stripe 64x64, anchor /2), random-init weights",
-                "tiles_per_gpu_per_step": args.tiles,
-                "hr_megapixels_per_s": round(mp * 16, 2),
-                "gflop_per_tile": 5468.5,
-                "model_tflops": round(5468.5e9 * world * args.tiles * args.steps / dt / 1e12, 2),
-                "parallelism": f"tile-sharded x{world}, no data-path collective",
-            },
+            "config": conf,
             "roofline": {
-                "kernel": "attn_kernel (cosine window / anchored-stripe attention)",
+                "kernel": "attn_fast_kernel (cosine window / anchored-stripe attention)",
                 "bound": "mfma",
                 "achieved": round(ach, 2),
-                "peak": PEAK_BF16_TFLOPS,
+                "peak": PEAK_F16_TFLOPS,
                 "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_BF16_TFLOPS, 4),
+                "frac": round(ach / PEAK_F16_TFLOPS, 4),
                 "traffic": traffic,
                 "launches_timed": len(att),
                 "mean_launch_ms": round(att_ms, 4),
                 "flops_per_launch": fl,
-                "time_share_of_step": round(sum(att) / (dt * 1e3), 3) if att else None,
+                "probe_pass_ms_per_step": round(dt_probe / args.steps * 1e3, 3),
+                "time_share_of_step": round(sum(att) / (dt_probe * 1e3), 3) if att else None,
                 "concurrent_streams": groups,
                 "tiles_per_launch": args.tiles // groups,
                 **excl,
             },
         }
+        if trained:
+            line["trained_scales"] = trained
+        if tiled:
+            line["tiled"] = tiled
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
-        print(json.dumps(line))
+        print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
+
+
+def _spawned(local_rank, args, world, port):
+    os.environ.update(RANK=str(local_rank), LOCAL_RANK=str(local_rank), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    run(args, local_rank, world, local_rank)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--tiles", type=int, default=8, help="LQ tiles per GPU per step")
+    ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS), help="BASELINE config (3 = the metric's)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-trained-scales", action="store_true")
+    ap.add_argument("--no-tiled", action="store_true")
+    args = ap.parse_args()
+
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is not None:                       # launched by torch.distributed.run
+        world = int(env_world)
+        if world != args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks")
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        run(args, int(os.environ.get("RANK", "0")), world, int(os.environ.get("LOCAL_RANK", "0")))
+    elif args.gpus > 1:                             # plain `python bench.py --gpus N`: spawn the ranks here
+        n_dev = torch.cuda.device_count()
+        if n_dev < args.gpus:
+            raise SystemExit(f"bench.py: --gpus {args.gpus} but only {n_dev} GPU(s) visible")
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        import torch.multiprocessing as mp
+
+        mp.spawn(_spawned, args=(args, args.gpus, port), nprocs=args.gpus, join=True)
+    else:
+        run(args, 0, 1, 0)
 
 
 if __name__ == "__main__":

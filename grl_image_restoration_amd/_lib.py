@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -25,6 +25,7 @@ EXPORTS = [
     "grl_qkv_blob_bytes",
     "grl_attention_fwd",
     "grl_layernorm_fwd",
+    "grl_layernorm_res_fwd",
     "grl_conv3x3_fwd",
     "grl_conv3x3_num_workgroups",
     "grl_se_scale_fwd",
@@ -71,6 +72,7 @@ class GrlLinearArgs(_Strict):
         ("ldadd2", C.c_int64),
         ("add2_scale", C.c_void_p),
         ("rows_per_image", C.c_int32),
+        ("a_split", C.c_int32),
         ("out", C.c_void_p),
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
@@ -168,10 +170,13 @@ class GrlAttnArgs(_Strict):
         ("trows", C.c_int32),
         ("tstride", C.c_int32),
         ("masked", C.c_int32),
-        ("fixed_max", C.c_int32),
         ("ones_col", C.c_int32),
         ("head_dim", C.c_int32),
         ("out_dtype", C.c_int32),
+        ("k_one31", C.c_int32),
+        ("lazy_floor", C.c_void_p),
+        ("lse", C.c_void_p),
+        ("lse_stride", C.c_int64),
     ]
 
 
@@ -188,6 +193,7 @@ class GrlConvArgs(_Strict):
         ("W", C.c_int32),
         ("CinP", C.c_int32),
         ("CoutP", C.c_int32),
+        ("x_split", C.c_int32),
         ("act", C.c_int32),
         ("slope", C.c_float),
         ("resid", C.c_void_p),
@@ -200,6 +206,29 @@ class GrlConvArgs(_Strict):
         ("shuffle_r", C.c_int32),
         ("shuffle_cg", C.c_int32),
         ("shuffle_ij0", C.c_int32),
+    ]
+
+
+class GrlLnResArgs(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("resid", C.c_void_p),
+        ("ldr", C.c_int64),
+        ("gamma", C.c_void_p),
+        ("beta", C.c_void_p),
+        ("add2", C.c_void_p),
+        ("add2_dtype", C.c_int32),
+        ("ldadd2", C.c_int64),
+        ("add2_scale", C.c_void_p),
+        ("rows_per_image", C.c_int32),
+        ("M", C.c_int32),
+        ("n_real", C.c_int32),
+        ("n_pad", C.c_int32),
+        ("eps", C.c_float),
+        ("res_scale", C.c_float),
+        ("y", C.c_void_p),
+        ("ldy", C.c_int64),
     ]
 
 
@@ -243,6 +272,8 @@ def lib():
         C.c_int32, C.c_int32, C.c_int32, C.c_float,
     ]
     L.grl_layernorm_fwd.restype = C.c_int
+    L.grl_layernorm_res_fwd.argtypes = [C.c_void_p, C.POINTER(GrlLnResArgs)]
+    L.grl_layernorm_res_fwd.restype = C.c_int
     L.grl_conv3x3_fwd.argtypes = [C.c_void_p, C.POINTER(GrlConvArgs)]
     L.grl_conv3x3_fwd.restype = C.c_int
     L.grl_conv3x3_num_workgroups.argtypes = [C.c_int32, C.c_int32, C.c_int32]

@@ -1,6 +1,6 @@
 // Cosine window / anchored-stripe attention for GRL on gfx950 (MI355X).
 //
-// One kernel serves the three attentions of a GRL block:
+// One kernel family serves the three attentions of a GRL block:
 //   window   : q,k,v = window tokens                 (mixed_attn_block_efficient.py:128-165)
 //   a2w      : q = anchors,  k,v = stripe tokens     (:256-258)
 //   w2a      : q = stripe tokens, k = anchors, v = a2w output   (:259)
@@ -8,20 +8,27 @@
 // window masks of the reference (ops.py:36-157,352-375) never touch memory here: they are index
 // arithmetic on the token grids described by GrlTokenGrid.
 //
-// Formulation (flash-style, nothing of size Nq x Nk is materialised):
-//   S^T tile (32 keys x 32 queries) = mfma_32x32x16_bf16(K_tile, Q_tile), accumulator
-//   *initialised with the relative-position bias* gathered from an LDS table, so that
-//   S^T = log2e * (scale * cos(q,k) + bias [- bound]) comes straight out of the matrix core
-//   (scale*log2e is folded into q by the QKV epilogue).  P = exp2(S^T) is packed to bf16 in
-//   registers in exactly the order the PV product wants its B operand (a permutation of the
-//   key index inside a tile, mirrored when V^T fragments are read), and O^T += V^T P^T runs on
-//   the matrix core again.  With `ones_col`, the softmax denominator is row `ones_col` of O^T.
-//   fixed_max=1 uses the per-head bound scale+max(bias) instead of a running maximum (valid
-//   because |cos| <= 1); fixed_max=0 is ordinary online softmax.
+// Formulation (flash-style, nothing of size Nq x Nk is materialised), all operands fp16, fp32 accumulation:
+//   S^T tile (32 keys x 32 queries) = mfma_32x32x16_f16(K_tile, Q_tile), accumulator *initialised with the
+//   relative-position bias* gathered from an LDS table, so that S^T = log2e * (scale * cos(q,k) + bias) - offset
+//   comes straight out of the matrix core (scale*log2e is folded into q by the QKV epilogue).  P = exp2(S^T) is
+//   packed to fp16 in registers in exactly the order the PV product wants its B operand (a permutation of the key
+//   index inside a tile, mirrored when V^T fragments are read), and O^T += V^T P^T runs on the matrix core again.
+//   With `ones_col`, the softmax denominator is row `ones_col` of O^T.
 //
-// Work decomposition: one workgroup = (window, head, block of up to 256 queries); each wave
-// owns 2 query tiles (64 queries) whose Q fragments and O^T accumulators stay in registers;
-// K (XOR-swizzled rows) and V^T chunks of 256 keys are staged in LDS and shared by the waves.
+// The softmax offset.  P is an fp16 MFMA operand and sub-normal halves are lost to the matrix core, so the weights of a
+// row must sit high in the fp16 range: largest weight of a row between 2^6 and 2^14 leaves >= 20 binades (14 nats) below it.
+// The logit scale is clamped at 100 (efficient.py:39), i.e. logits span +-144 in the log2 domain, and q / k are different
+// projections, so no a-priori bound of the row maximum is tight enough: the offset must follow the data.
+//   lazy   (fast kernel): a running per-query offset m, integer valued, kept in the spare head-dim slot 31 of the Q
+//           fragment (K carries 1.0 there), i.e. it costs no instruction in the loop: S^T = K.Q + bias - m comes out of the
+//           matrix core.  A tile whose largest packed weight reaches 2^14 (packed 16-bit max over the tile + one compare)
+//           takes a rare wave-uniform slow path that raises m so that the tile maximum lands at 2^6, rescales O and redoes
+//           the tile -- flash-attention's running maximum, evaluated only when needed;
+//   online (generic kernel): ordinary running maximum per tile, weights = exp2(S - max + 14).
+//
+// Work decomposition: one workgroup = (window, head, block of up to 256 queries); each wave owns 2 query tiles (64
+// queries) whose Q fragments and O^T accumulators stay in registers; K and V chunks of 256 keys are staged in LDS.
 #include "common.h"
 #include "grl_hip_internal.h"
 #include <stdlib.h>
@@ -33,10 +40,10 @@ constexpr int KC = 256;          // keys per LDS chunk
 constexpr int VROW = KC * 2 + 8; // V^T row stride in bytes (pad: conflict-free ds_read_b64)
 constexpr float MASK_L2 = -100.0f * LOG2E_F;
 constexpr float NEG_BIG = -1.0e30f;
-
-struct GridGeo {
-    int Himg, Wimg, wh, ww, shy, shx;
-};
+constexpr float P_TOP = 14.0f;           // log2 of the largest fp16 weight the kernels produce (fp16 max is 2^16)
+constexpr float LAZY_REST = 6.0f;        // lazy offset: after a rescale the tile maximum sits in (2^5, 2^6]
+constexpr unsigned short LAZY_TRIP = 0x7400;   // fp16 bit pattern of 2^14: a packed weight >= this moves the offset
+constexpr unsigned short F16_INF = 0x7C00;
 
 // Workgroup -> work item map that keeps consecutive work items (the query blocks of one window and
 // head, which share K/V) on ONE XCD: the dispatcher places block b on XCD b % 8 and every XCD has a
@@ -46,8 +53,7 @@ __device__ __forceinline__ int xcd_remap(int bid, int n) {
     return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
 }
 
-// global -> LDS copy of one head's bias table with 4 x 16 B loads in flight per thread (a plain
-// element loop serialises on global-memory latency: 35 round trips for a 95 x 95 table)
+// global -> LDS copy of one head's bias table with 4 x 16 B loads in flight per thread
 __device__ __forceinline__ void load_table(float* tab, const float* src, int trows, int tid, int nthreads) {
     const int n4 = (trows + 3) >> 2;  // the per-head stride is padded to a multiple of 4 floats
     const float4* s4 = (const float4*)src;
@@ -79,7 +85,40 @@ __device__ __forceinline__ void locate(const GrlTokenGrid& g, int b, int wy, int
     rid = 3 * region1d(ry, g.Himg, g.wh, g.shy) + region1d(rx, g.Wimg, g.ww, g.shx);
 }
 
-template <bool FIXED, bool ONES, bool KW4>
+// normalised O^T fragment of one query tile -> global (lane holds head dims 8*g + 4*half + [0..3] of query l31)
+__device__ __forceinline__ void store_o(const GrlAttnArgs& p, const f32x16& O, float inv, int64_t qrow, int head, int half) {
+    if (p.out_dtype == GRL_DT_F32) {
+        float* dst = (float*)p.o.ptr + qrow * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(dst + 8 * g) = float4{O[4 * g + 0] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
+    } else {
+        f16* dst = (f16*)p.o.ptr + qrow * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            uint2 pk;
+            pk.x = pack_f16(O[4 * g + 0] * inv, O[4 * g + 1] * inv);
+            pk.y = pack_f16(O[4 * g + 2] * inv, O[4 * g + 3] * inv);
+            *(uint2*)(dst + 8 * g) = pk;
+        }
+    }
+}
+
+// row `oc` of an O^T fragment (the ones-column of V: the softmax denominator), valid in both half-waves
+__device__ __forceinline__ float ones_row(const f32x16& O, int oc, int half) {
+    const int base_row = oc & ~4;  // row index with the half bit cleared
+    float cand = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (mfma32_row(r, 0) == base_row) cand = O[r];
+    const float other = xhalf(cand);
+    return (half == ((oc >> 2) & 1)) ? cand : other;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Generic kernel: any window shape (12x12 windows, 8-anchor stripes, ragged key counts, head_dim 32), online softmax.
+// ------------------------------------------------------------------------------------------------
+template <bool ONES, bool KW4>
 __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -112,7 +151,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     int U[QT], idq[QT];
     int64_t qrow[QT];
     bool qvalid[QT];
-    bf16x8 qf[QT][2];
+    f16x8 qf[QT][2];
     f32x16 O[QT];
     float mrun[QT], lrun[QT];
 #pragma unroll
@@ -123,9 +162,9 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         locate(p.q, b, wy, wx, n, qrow[t], idq[t]);
         const int hq = n / p.q.ww, wq = n - hq * p.q.ww;
         U[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1));  // reversed table: index = U + v
-        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
-        qf[t][0] = *(const bf16x8*)(src);
-        qf[t][1] = *(const bf16x8*)(src + 16);
+        const f16* src = (const f16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
+        qf[t][0] = *(const f16x8*)(src);
+        qf[t][1] = *(const f16x8*)(src + 16);
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
         mrun[t] = NEG_BIG;
@@ -145,14 +184,14 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             const bool valid = n < Nk;
             int64_t row; int rid;
             locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
-            bf16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
+            f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
             if (valid) {
-                kv = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
-                vv = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
+                kv = *(const f16x8*)((const f16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
+                vv = *(const f16x8*)((const f16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
             }
-            *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
+            *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
+            for (int e = 0; e < 8; ++e) *(f16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
             if (seg == 0) {
                 const int nn = valid ? n : 0;
                 const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
@@ -165,12 +204,12 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         for (int kt = 0; kt < ntiles; ++kt) {
             const int kb = kt * 32;
             // K fragments: A operand rows = keys kb + l31, k-slots = head dims 8*half (+16 for step 1)
-            bf16x8 kf[2];
+            f16x8 kf[2];
             {
                 const int kk = kb + l31;
                 const int sw = (kk >> 2) & 3;
-                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
-                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
+                kf[0] = *(const f16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
+                kf[1] = *(const f16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
             }
             // bias gather -> accumulator init
             f32x16 S[QT];
@@ -195,8 +234,8 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], S[t], 0, 0, 0);
-                S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S[t], 0, 0, 0);
+                S[t] = mfma32_f16(kf[0], qf[t][0], S[t]);
+                S[t] = mfma32_f16(kf[1], qf[t][1], S[t]);
             }
             if (need_mask) {
 #pragma unroll
@@ -215,86 +254,66 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                     }
                 }
             }
-            // softmax numerators, packed straight into the PV B-operand order
-            bf16x8 pb[QT][2];
+            // online softmax; numerators packed straight into the PV B-operand order
+            f16x8 pb[QT][2];
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                float sub = 0.f;
-                if constexpr (!FIXED) {
-                    float mx = S[t][0];
+                float mx = S[t][0];
 #pragma unroll
-                    for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
-                    mx = fmaxf(mx, xhalf(mx));
-                    const float mnew = fmaxf(mrun[t], mx);
-                    const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
-                    mrun[t] = mnew;
+                for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
+                mx = fmaxf(mx, xhalf(mx));
+                const float mnew = fmaxf(mrun[t], mx);
+                const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
+                mrun[t] = mnew;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
-                    lrun[t] *= alpha;
-                    sub = mnew;
-                }
+                for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
+                lrun[t] *= alpha;
                 float ps = 0.f;
+                const float sub = mnew - P_TOP;   // weights <= 2^14: 28 binades of fp16 normals below the row maximum
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const float pr = __builtin_amdgcn_exp2f(S[t][r] - sub);
                     if constexpr (!ONES) ps += pr;
-                    pb[t][r >> 3][r & 7] = (bf16)pr;
+                    pb[t][r >> 3][r & 7] = (f16)pr;
                 }
                 if constexpr (!ONES) lrun[t] += ps;
             }
             // V^T fragments: rows = head dim l31; k-slot e <-> key kb + 16*s + 8*(e>>2) + 4*half + (e&3)
-            bf16x8 vf[2];
+            f16x8 vf[2];
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
                 const char* vp = Vt + l31 * VROW + (kb + 16 * s + 4 * half) * 2;
-                const bf16x4 lo = *(const bf16x4*)(vp);
-                const bf16x4 hi = *(const bf16x4*)(vp + 16);
-                vf[s] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                const f16x4 lo = *(const f16x4*)(vp);
+                const f16x4 hi = *(const f16x4*)(vp + 16);
+                vf[s] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             }
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
-                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[t][0], O[t], 0, 0, 0);
-                O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[t][1], O[t], 0, 0, 0);
+                O[t] = mfma32_f16(vf[0], pb[t][0], O[t]);
+                O[t] = mfma32_f16(vf[1], pb[t][1], O[t]);
             }
         }
     }
 
-    // ---- normalise and store: lane holds head dims 8*g + 4*half + [0..3] of query l31 ----
+    // ---- normalise and store ----
 #pragma unroll
     for (int t = 0; t < QT; ++t) {
         float l;
-        if constexpr (ONES) {
-            const int oc = p.ones_col;
-            const int base_row = oc & ~4;  // row index with the half bit cleared
-            float cand = 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r)
-                if (mfma32_row(r, 0) == base_row) cand = O[t][r];
-            const float other = xhalf(cand);
-            l = (half == ((oc >> 2) & 1)) ? cand : other;
-        } else {
-            l = lrun[t] + xhalf(lrun[t]);
-        }
-        const float inv = 1.0f / l;
+        if constexpr (ONES) l = ones_row(O[t], p.ones_col, half);
+        else l = lrun[t] + xhalf(lrun[t]);
         if (qvalid[t]) {
-            bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                uint2 pk;
-                pk.x = pack16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv, p.out_dtype);
-                pk.y = pack16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv, p.out_dtype);
-                *(uint2*)(dst + 8 * g) = pk;
-            }
+            store_o(p, O[t], 1.0f / l, qrow[t], head, half);
+            if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + qrow[t]] = mrun[t] - P_TOP + __builtin_amdgcn_logf(l);
         }
     }
 }
 
-template <bool FIXED, bool ONES>
+template <bool ONES>
 int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t st) {
     const bool kw4 = (p.k.ww % 4) == 0;
 #define GRL_ATTN_GO(KW4V)                                                                                   \
     {                                                                                                       \
-        auto kfn = attn_kernel<FIXED, ONES, KW4V>;                                                          \
+        auto kfn = attn_kernel<ONES, KW4V>;                                                                 \
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                            (int)lds);                                                       \
         if (e != hipSuccess) return (int)e;                                                                 \
@@ -308,29 +327,32 @@ int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t
 
 
 // ------------------------------------------------------------------------------------------------
-// Fast path: 32-aligned windows (q.ww % 32 == 0, k.ww % 32 == 0, q.wh % QTN == 0, k.wh % 8 == 0),
-// fixed softmax bound, ones column.  Covers the released-checkpoint geometries (window 32;
-// stripes 64x64 / 64x128 and their anchor grids) -- the MFMA-bound regime of SURVEY 8(d).
+// Fast path: 32-aligned windows (q.ww % 32 == 0, k.ww % 32 == 0, q.wh % 2 == 0, k.wh % 8 == 0), ones column, lazy offset.  Covers the released-checkpoint geometries (window 32; stripes 64x64 / 64x128 and their anchor grids)
+// -- the MFMA-bound regime of SURVEY 8(d).
 //
-//   * FW waves per workgroup share one K / V^T chunk (8 key rows x 32 keys of one 32-wide strip)
-//     and the bias table; loads of a chunk are issued back to back, then committed to LDS;
-//   * a wave owns QTN query tiles: the same 32-wide column segment of QTN consecutive window rows,
-//     so K / V^T fragments are read once per QTN tiles and QTN independent MFMA chains are in
-//     flight per wave;
-//   * a key tile is a 32-wide segment of one key row: the bias of (query lane, key row i) is
-//     tab[U + i] with the table stored reversed, i.e. plain ascending LDS reads that initialise the
-//     accumulator; S^T = mfma(K, Q, bias) is the log2-domain logit, P = exp2(S^T) goes to bf16 in
-//     the PV operand order, O^T += V^T P^T.  No running maximum (fixed bound) -> key order is free.
+//   * 4 waves per workgroup share one K / V chunk (8 key rows x 32 keys of one 32-wide strip) and the bias table;
+//     K chunks go global -> LDS by DMA into a double buffer one chunk ahead (XOR swizzle applied on the source side);
+//     V either the same way, read back with the hardware transpose (ds_read_b64_tr_b16; KDMA 2), or -- where the table
+//     slice leaves no room for four chunk buffers at two workgroups per CU -- through registers, written transposed
+//     as key pairs (KDMA 1);
+//   * a wave owns 2 query tiles: the same 32-wide column segment of 2 consecutive window rows, so K / V^T fragments
+//     are read once per 2 tiles and 2 independent MFMA chains are in flight per wave;
+//   * a key tile is a 32-wide segment of one key row: the bias of (query lane, key row i) is tab[U + i] with the table
+//     stored reversed, i.e. plain ascending LDS reads that initialise the accumulator.  The bias fragment of (query
+//     row hq+1, key row hk+1) equals that of (hq, hk), so tile 1 takes the fragment tile 0 gathered one key row
+//     earlier: two fragment registers HA / HB swap roles every row and LDS bias reads are halved.
 // ------------------------------------------------------------------------------------------------
+constexpr int FW = 4, QTN = 2, FROWS = 8;
+constexpr int FKC = FROWS * 32;
+constexpr int FVROW = FKC * 2 + 8;
 
-// FROWS = key rows per LDS chunk (chunk = FROWS x 32 keys of one strip); WPS = waves per SIMD to allocate for
-// Upper bound of the bias-table entries one workgroup of the fast kernel needs (KDMA layout): its queries span at most
+// Upper bound of the bias-table entries one workgroup of the fast kernel needs: its queries span at most
 // QTN * (units_per_wg / segments_per_row + 2) rows, every key row of the window, all column offsets.
-__host__ __device__ inline int fast_table_floats(const GrlAttnArgs& p, int fw, int qtn) {
+__host__ __device__ inline int fast_table_floats(const GrlAttnArgs& p) {
     const int qseg = p.q.ww >> 5;
-    const int units = (p.q.wh / qtn) * qseg;
-    const int upw = fw < units ? fw : units;
-    const int rows = qtn * (upw / qseg + 2);
+    const int units = (p.q.wh / QTN) * qseg;
+    const int upw = FW < units ? FW : units;
+    const int rows = QTN * (upw / qseg + 2);
     const int D = p.q.ww + p.k.ww - 1;
     const int n = (rows - 1 + p.k.wh) * D + 4;
     const int all = (p.trows + 3) & ~3;
@@ -339,12 +361,8 @@ __host__ __device__ inline int fast_table_floats(const GrlAttnArgs& p, int fw, i
     return ((n < all ? n : all) + 255) & ~255;
 }
 
-template <int FW, int QTN, int FROWS, int WPS, int PIPE, int KDMA>
-__global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, int dbg, long long* tbuf) {
-    long long tm[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (tbuf) tm[0] = __builtin_amdgcn_s_memtime();
-    constexpr int FKC = FROWS * 32;
-    constexpr int FVROW = FKC * 2 + 8;
+template <int KDMA>
+__global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
@@ -360,30 +378,27 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     const int b = bid / p.nwy;
     const int D = p.q.ww + p.k.ww - 1;
 
-    // LDS: bias table (KDMA: only the rows this workgroup's queries can reach) | K chunk (KDMA: two) | V^T chunk | region ids
+    // LDS: bias table slice (the rows this workgroup's queries can reach) | two K chunks | V (KDMA 2: two row-major chunks,
+    // KDMA 1: one transposed chunk [32][FVROW]) | key region ids
     float* tab = (float*)smem;
-    const int tab_floats = KDMA ? fast_table_floats(p, FW, QTN) : p.trows;
+    const int tab_floats = fast_table_floats(p);
     char* Ks0 = smem + (((size_t)tab_floats * 4 + 15) & ~(size_t)15);
-    char* Vt = Ks0 + (KDMA ? 2 : 1) * FKC * 64;                 // KDMA 0/1: V^T [32][FVROW]; KDMA 2: V row-major [2][FKC][64 B]
+    char* Vt = Ks0 + 2 * FKC * 64;
     unsigned char* kreg0 = (unsigned char*)(Vt + (KDMA == 2 ? 2 * FKC * 64 : 32 * FVROW));   // KDMA 2: two buffers of FKC bytes
 
     // the table arrives REVERSED (see grl_hip.h) so that a lane's 16 key rows read ascending addresses.
     // It is DMA'd (global_load_lds, 1 KiB per wave-instruction, no staging registers): all pieces are in flight at
-    // once and overlap the first K/V chunk's loads; the barrier in front of the first LDS commit waits for them.
-    // A last partial piece re-reads the final 16 bytes; its tail lands in the K staging area, which is written later.
+    // once and overlap the first K/V chunk's loads; the barrier in front of the first LDS use waits for them.
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
     int tab_lo = 0;   // first table entry (reversed order, multiple of 4) held in LDS
     {
-        int n4 = (p.trows + 3) >> 2, first4 = 0;
-        if constexpr (KDMA) {
-            // queries of this workgroup: rows hq_lo .. hq_hi  ->  reversed entries trows - (hq_hi + k.wh) * D .. trows - 1 - hq_lo * D
-            const int u0 = qs * upw, u1 = min(u0 + upw, units) - 1;
-            const int hq_lo = QTN * (u0 / qseg), hq_hi = QTN * (u1 / qseg) + QTN - 1;
-            const int pos_lo = p.trows - (hq_hi + p.k.wh) * D, pos_hi = p.trows - 1 - hq_lo * D;
-            tab_lo = pos_lo & ~3;
-            first4 = tab_lo >> 2;
-            n4 = ((pos_hi - tab_lo) >> 2) + 1;
-        }
+        // queries of this workgroup: rows hq_lo .. hq_hi  ->  reversed entries trows - (hq_hi + k.wh) * D .. trows - 1 - hq_lo * D
+        const int u0 = qs * upw, u1 = min(u0 + upw, units) - 1;
+        const int hq_lo = QTN * (u0 / qseg), hq_hi = QTN * (u1 / qseg) + QTN - 1;
+        const int pos_lo = p.trows - (hq_hi + p.k.wh) * D, pos_hi = p.trows - 1 - hq_lo * D;
+        tab_lo = pos_lo & ~3;
+        const int first4 = tab_lo >> 2;
+        const int n4 = ((pos_hi - tab_lo) >> 2) + 1;
         const int last4 = ((p.trows + 3) >> 2) - 1;
         const float4* s4 = (const float4*)(p.table + (int64_t)head * p.tstride);
         for (int q = wave_u; q * 64 < n4; q += FW) {
@@ -402,8 +417,9 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
     const int pr = unit / qseg, sg = unit - pr * qseg;
     int Ub[QTN], idq[QTN];
     int64_t qrow[QTN];
-    bf16x8 qf[QTN][2];
+    f16x8 qf[QTN][2];
     f32x16 O[QTN];
+    float mq[QTN];   // the query's softmax offset (integer valued, log2 domain); mirrored as -mq in q slot 31
 #pragma unroll
     for (int t = 0; t < QTN; ++t) {
         const int hq = QTN * pr + t, wq = 32 * sg + l31;
@@ -411,26 +427,28 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
         // table index of (query, key (hk, wk)) = U - hk*D - wk, reversed: (trows-1-U) + hk*D + wk;
         // lane's key rows are wk = 32*sk + i, i = (r&3) + 8*(r>>2) + 4*half
         Ub[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1)) + 4 * half - tab_lo;
-        const bf16* src = (const bf16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
-        qf[t][0] = *(const bf16x8*)(src);
-        qf[t][1] = *(const bf16x8*)(src + 16);
+        const f16* src = (const f16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
+        qf[t][0] = *(const f16x8*)(src);
+        qf[t][1] = *(const f16x8*)(src + 16);
+        // start at the floor of the head's logits (every weight >= 1): the slow path raises it as larger logits appear
+        mq[t] = p.lazy_floor[head];
+        if (half) qf[t][1][7] = (f16)(-mq[t]);   // head-dim slot 31 (K holds 1.0 there)
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
     }
 
-    f32x16 HA, HB, H1, H2, H3;  // bias fragments carried across key rows (PIPE == 2: HA/HB, PIPE == 3: ring HA,H1,H2,H3)
+    f32x16 HA, HB;  // bias fragments carried across key rows
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { HA[r] = 0.f; HB[r] = 0.f; H1[r] = 0.f; H2[r] = 0.f; H3[r] = 0.f; }
+    for (int r = 0; r < 16; ++r) { HA[r] = 0.f; HB[r] = 0.f; }
     const int kseg = p.k.ww >> 5;
     const int nrc = p.k.wh / FROWS;  // chunks per strip
     const int nch = kseg * nrc;
 
-    // ---- K / V staging: each thread owns SPT fixed (key, 16-B segment) slots of a chunk ----
-    if (tbuf) tm[1] = __builtin_amdgcn_s_memtime();
-    constexpr int SPT = (FKC * 4) / (FW * 64);
-    static_assert(SPT * FW * 64 == FKC * 4, "chunk must divide evenly over the workgroup");
+    // ---- K / V staging ----
+    constexpr int SPT = (FKC * 4) / (FW * 64);   // (key, 16-B segment) slots per thread and chunk
+    static_assert(SPT * FW * 64 == FKC * 4 && (SPT % 2) == 0, "chunk must divide evenly over the workgroup in key pairs");
 
-    // slot (key kk, 16-B segment seg) of chunk ch -> row of the token matrix (+ region id of the key)
+    // key kk of chunk ch -> row of the token matrix (+ region id of the key)
     auto key_row = [&](int ch, int kk, int& rid) -> int64_t {
         const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
         const int ry = wy * p.k.wh + hk0 + (kk >> 5), rx = wx * p.k.ww + 32 * sk + (kk & 31);
@@ -439,145 +457,115 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
         rid = 3 * region1d(ry, p.k.Himg, p.k.wh, p.k.shy) + region1d(rx, p.k.Wimg, p.k.ww, p.k.shx);
         return ((int64_t)b * p.k.Himg + oy) * p.k.Wimg + ox;
     };
-    bf16x8 pv_[SPT];
+    f16x8 pv_[SPT];
     int prid[SPT];
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    // KDMA: the K chunk goes global -> LDS by DMA (the XOR swizzle is applied on the source side: LDS segment sigma holds
-    // segment (sigma & 3) ^ ((kk >> 2) & 3) of key kk = sigma >> 2), V by registers (it is transposed on the way); both
-    // are issued one chunk ahead, while the previous chunk is in the matrix cores.
+    // The K chunk goes global -> LDS by DMA (LDS segment sigma holds segment (sigma & 3) ^ ((kk >> 2) & 3) of key
+    // kk = sigma >> 2); both K and V are issued one chunk ahead, while the previous chunk is in the matrix cores.
     auto prefetch = [&](int ch) {
-        if constexpr (KDMA) {
+#pragma unroll
+        for (int j = 0; j < (FKC * 64) / (FW * 1024); ++j) {
+            const int q = wave_u + j * FW;
+            const int sigma = q * 64 + lane, kk = sigma >> 2, seg = (sigma & 3) ^ ((kk >> 2) & 3);
+            int rid;
+            const int64_t row = key_row(ch, kk, rid);
+            const f16* g = (const f16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8;
+            const uint32_t m0v = lds0 + (uint32_t)(Ks0 - smem) + (ch & 1) * FKC * 64 + q * 1024;
+            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
+        }
+        if constexpr (KDMA == 2) {
+            // V the same way, row-major and unswizzled: the PV operand is fetched with ds_read_b64_tr_b16 (hardware
+            // transpose across 16 lanes), so nothing passes through registers and there is no commit phase at all
 #pragma unroll
             for (int j = 0; j < (FKC * 64) / (FW * 1024); ++j) {
                 const int q = wave_u + j * FW;
-                const int sigma = q * 64 + lane, kk = sigma >> 2, seg = (sigma & 3) ^ ((kk >> 2) & 3);
+                const int sigma = q * 64 + lane, kk = sigma >> 2, seg = sigma & 3;
                 int rid;
                 const int64_t row = key_row(ch, kk, rid);
-                const bf16* g = (const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8;
-                const uint32_t m0v = lds0 + (uint32_t)(Ks0 - smem) + (ch & 1) * FKC * 64 + q * 1024;
+                const f16* g = (const f16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8;
+                const uint32_t m0v = lds0 + (uint32_t)(Vt - smem) + (ch & 1) * FKC * 64 + q * 1024;
                 asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
             }
-            if constexpr (KDMA == 2) {
-                // V the same way, row-major and unswizzled: the PV operand is fetched with ds_read_b64_tr_b16 (hardware
-                // transpose across 16 lanes), so nothing passes through registers and there is no commit phase at all
-#pragma unroll
-                for (int j = 0; j < (FKC * 64) / (FW * 1024); ++j) {
-                    const int q = wave_u + j * FW;
-                    const int sigma = q * 64 + lane, kk = sigma >> 2, seg = sigma & 3;
+            if (p.masked) {
+                for (int kk = tid; kk < FKC; kk += FW * 64) {
                     int rid;
-                    const int64_t row = key_row(ch, kk, rid);
-                    const bf16* g = (const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8;
-                    const uint32_t m0v = lds0 + (uint32_t)(Vt - smem) + (ch & 1) * FKC * 64 + q * 1024;
-                    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
-                }
-                if (p.masked) {
-                    for (int kk = tid; kk < FKC; kk += FW * 64) {
-                        int rid;
-                        key_row(ch, kk, rid);
-                        kreg0[(ch & 1) * FKC + kk] = (unsigned char)rid;
-                    }
+                    key_row(ch, kk, rid);
+                    kreg0[(ch & 1) * FKC + kk] = (unsigned char)rid;
                 }
             }
+        } else {
             // V: a thread owns (key pair, segment) slots so that the transposed LDS writes are 4 bytes (two keys) wide
 #pragma unroll
-            for (int j = 0; j < (KDMA == 2 ? 0 : SPT); ++j) {
+            for (int j = 0; j < SPT; ++j) {
                 const int i2 = tid + (j >> 1) * FW * 64;           // pair slot: pair = i2 >> 2, segment = i2 & 3
                 const int64_t row = key_row(ch, 2 * (i2 >> 2) + (j & 1), prid[j]);
-                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i2 & 3) * 8);
+                pv_[j] = *(const f16x8*)((const f16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i2 & 3) * 8);
             }
         }
     };
-    if constexpr (KDMA) prefetch(0);
+    prefetch(0);
 
 #pragma unroll 1
     for (int ch = 0; ch < nch; ++ch) {
         const int sk = ch / nrc, hk0 = (ch - sk * nrc) * FROWS;
-        if ((dbg & 16) && ch > 0) break;
-        long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
-        if (tbuf) c0 = __builtin_amdgcn_s_memtime();
-        char* Ks = Ks0 + (KDMA ? (ch & 1) * FKC * 64 : 0);
+        const char* Ks = Ks0 + (ch & 1) * FKC * 64;
         const char* Vs = Vt + (ch & 1) * FKC * 64;                              // KDMA 2 only
         unsigned char* kreg = kreg0 + (KDMA == 2 ? (ch & 1) * FKC : 0);
         if constexpr (KDMA == 2) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own DMA pieces of chunk ch landed, own LDS traffic retired
             __builtin_amdgcn_s_barrier();                                  // everybody's; and all are done with the buffers of chunk ch-1
-            if (tbuf) c1 = __builtin_amdgcn_s_memtime();
             if (ch + 1 < nch) prefetch(ch + 1);
-        } else if constexpr (KDMA == 1) {
+        } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces (table, K chunk) and V loads have landed
             __builtin_amdgcn_s_barrier();                       // ... everybody's; and all are done reading the previous chunk
-            if (tbuf) c1 = __builtin_amdgcn_s_memtime();
-            static_assert(KDMA != 1 || (SPT % 2) == 0, "V slots are key pairs");
 #pragma unroll
             for (int j = 0; j < SPT; j += 2) {
                 const int i2 = tid + (j >> 1) * FW * 64;
                 const int kk0 = 2 * (i2 >> 2), seg = i2 & 3;
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
-                    bf16x2 two;
+                    f16x2 two;
                     two[0] = pv_[j][e];
                     two[1] = pv_[j + 1][e];
-                    *(bf16x2*)(Vt + (seg * 8 + e) * FVROW + kk0 * 2) = two;
+                    *(f16x2*)(Vt + (seg * 8 + e) * FVROW + kk0 * 2) = two;
                 }
                 if (seg == 0) *(unsigned short*)(kreg + kk0) = (unsigned short)(prid[j] | (prid[j + 1] << 8));
             }
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();                       // V^T / region ids visible
             if (ch + 1 < nch) prefetch(ch + 1);                 // issued behind the barrier: its address math delays nobody
-        } else {
-            bf16x8 pk_[SPT];
-            if (!(dbg & 32) || ch == 0)
-#pragma unroll
-            for (int j = 0; j < SPT; ++j) {
-                const int i = tid + j * FW * 64;
-                const int64_t row = key_row(ch, i >> 2, prid[j]);
-                pk_[j] = *(const bf16x8*)((const bf16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + (i & 3) * 8);
-                pv_[j] = *(const bf16x8*)((const bf16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + (i & 3) * 8);
-            }
-            __syncthreads();   // everyone is done reading the previous chunk
-            if (tbuf) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); c1 = __builtin_amdgcn_s_memtime(); }
-            if (!(dbg & 1) || ch == 0)
-#pragma unroll
-            for (int j = 0; j < SPT; ++j) {
-                const int i = tid + j * FW * 64;
-                const int kk = i >> 2, seg = i & 3;
-                *(bf16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = pk_[j];
-#pragma unroll
-                for (int e = 0; e < 8; ++e) *(bf16*)(Vt + (seg * 8 + e) * FVROW + kk * 2) = pv_[j][e];
-                if (seg == 0) kreg[kk] = (unsigned char)prid[j];
-            }
-            __syncthreads();
         }
-        if (tbuf) c2 = __builtin_amdgcn_s_memtime();
         if (!active) continue;
-        if (dbg & 64) __builtin_amdgcn_s_setprio(1);   // experiment: MFMA phase outranks the other workgroup's staging phase
 
-        // LDS reads of one key tile: K fragments, V^T fragments, bias fragments (accumulator init), key region ids
-        auto lds_tile = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], f32x16 (&S)[QTN], uint32_t (&ids)[4]) {
+        // LDS reads of one key tile: K fragments, V^T fragments, key region ids
+        auto frags = [&](int kt, f16x8 (&kf)[2], f16x8 (&vf)[2], uint32_t (&ids)[4]) {
             const int kb = kt * 32;
-            const int toff = (hk0 + kt) * D + 32 * sk;
-            {
-                const int kk = kb + l31;
-                const int sw = (kk >> 2) & 3;
-                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
-                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
-            }
+            const int kk = kb + l31;
+            const int sw = (kk >> 2) & 3;
+            kf[0] = *(const f16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
+            kf[1] = *(const f16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
+            if constexpr (KDMA == 2) {
+                // lane (d = l31, half): elements e < 4 = keys 16*s2 + 4*half + e, e >= 4 = keys 16*s2 + 8 + 4*half + e-4.
+                // ds_read_b64_tr_b16: within a 16-lane group lane i points at row i>>2, columns 4*(i&3) of a [4 keys][16 d]
+                // block and receives column (i & 15), rows 0..3.
+                typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
+                typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
+                const char* vb = Vs + (kb + 4 * half + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
-                const bf16x4 lo = *(const bf16x4*)(vp);
-                const bf16x4 hi = *(const bf16x4*)(vp + 16);
-                vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (16 * s2) * 64));
+                    const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (16 * s2 + 8) * 64));
+                    typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8;
+                    const s16x8 both = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                    vf[s2] = __builtin_bit_cast(f16x8, both);
+                }
+            } else {
 #pragma unroll
-            for (int t = 0; t < QTN; ++t) {
-                const float* tp = tab + (Ub[t] + toff);
-                if (dbg & 2) {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[t][r] = -1.0f;
-                } else {
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) S[t][r] = tp[(r & 3) + 8 * (r >> 2)];
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
+                    const f16x4 lo = *(const f16x4*)(vp);
+                    const f16x4 hi = *(const f16x4*)(vp + 16);
+                    vf[s2] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 }
             }
             if (border) {
@@ -585,298 +573,162 @@ __global__ __launch_bounds__(FW * 64, WPS) void attn_fast_kernel(GrlAttnArgs p, 
                 for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
             }
         };
-        auto compute_tile = [&](bf16x8 (&kf)[2], bf16x8 (&vf)[2], f32x16 (&S)[QTN], uint32_t (&ids)[4]) {
+        auto gather = [&](int t, int hk, f32x16& dst) {
+            const float* tp = tab + (Ub[t] + hk * D + 32 * sk);
 #pragma unroll
-            for (int t = 0; t < QTN; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t][0], S[t], 0, 0, 0);
+            for (int r = 0; r < 16; ++r) dst[r] = tp[(r & 3) + 8 * (r >> 2)];
+        };
+        auto logits = [&](const f16x8 (&kf)[2], const f32x16& C0, const f32x16& C1, const uint32_t (&ids)[4], f32x16 (&S)[2]) {
+            S[0] = mfma32_f16(kf[0], qf[0][0], C0);
+            S[1] = mfma32_f16(kf[0], qf[1][0], C1);
+            S[0] = mfma32_f16(kf[1], qf[0][1], S[0]);
+            S[1] = mfma32_f16(kf[1], qf[1][1], S[1]);
+            if (border) {
 #pragma unroll
-            for (int t = 0; t < QTN; ++t) S[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t][1], S[t], 0, 0, 0);
-#pragma unroll
-            for (int t = 0; t < QTN; ++t) {
-                if (border) {
+                for (int t = 0; t < 2; ++t)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
                         S[t][r] += idk != idq[t] ? MASK_L2 : 0.f;
                     }
-                }
-                bf16x8 pb[2];
+            }
+        };
+        auto pair = [&](f16x8 (&kf)[2], f16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
+            f32x16 S[2];
+            logits(kf, C0, C1, ids, S);
+            // weights as packed fp16 pairs (word i of a tile = accumulator registers 2i, 2i+1: the PV B-operand order)
+            typedef __attribute__((__vector_size__(2 * sizeof(unsigned short)))) unsigned short u16x2;
+            typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t u32x4;
+            uint32_t pw[2][8];
+            auto weights = [&](float sub0, float sub1) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)((dbg & 4) ? S[t][r] : __builtin_amdgcn_exp2f(S[t][r]));
-                if (dbg & 8) {
-                    asm volatile("" ::"v"(pb[0]), "v"(pb[1]));
+                for (int t = 0; t < 2; ++t)
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const float sub = t ? sub1 : sub0;
+                        f16x2 h;
+                        h[0] = (f16)__builtin_amdgcn_exp2f(S[t][2 * i] - sub);
+                        h[1] = (f16)__builtin_amdgcn_exp2f(S[t][2 * i + 1] - sub);
+                        pw[t][i] = __builtin_bit_cast(uint32_t, h);
+                    }
+            };
+            weights(0.f, 0.f);
+            // largest packed weight of each tile: 7 v_pk_max_u16 (positive halves order like integers) + 1 to fold the pair
+            unsigned short top[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                u16x2 m2 = __builtin_bit_cast(u16x2, pw[t][0]);
+#pragma unroll
+                for (int i = 1; i < 8; ++i) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, pw[t][i]));
+                top[t] = m2[0] > m2[1] ? m2[0] : m2[1];
+            }
+            bool post = false;   // wave-uniform: raise the offsets after this tile's PV product
+            if (__builtin_amdgcn_ballot_w64(top[0] >= LAZY_TRIP || top[1] >= LAZY_TRIP) != 0ull) {
+                if (__builtin_amdgcn_ballot_w64(top[0] >= F16_INF || top[1] >= F16_INF) != 0ull) {
+                    // a weight overflowed fp16: raise the offsets of the queries concerned so that their tile maximum lands at
+                    // 2^REST, rescale their accumulators, redo the tile's weights
+                    logits(kf, C0, C1, ids, S);
+                    float delta[2];
+#pragma unroll
+                    for (int t = 0; t < 2; ++t) {
+                        float mx = S[t][0];
+#pragma unroll
+                        for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
+                        mx = fmaxf(mx, xhalf(mx));
+                        delta[t] = fmaxf(0.f, __builtin_ceilf(mx) - LAZY_REST);
+                        mq[t] += delta[t];
+                        if (half) qf[t][1][7] = (f16)(-mq[t]);
+                        const float f = __builtin_amdgcn_exp2f(-delta[t]);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) O[t][r] *= f;
+                    }
+                    weights(delta[0], delta[1]);
                 } else {
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t], 0, 0, 0);
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t], 0, 0, 0);
+                    post = true;   // weights in [2^14, 2^16): still exact -- use them, move the offset afterwards
+                }
+            }
+            f16x8 pb[2][2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    pb[t][j] = __builtin_bit_cast(f16x8, u32x4{pw[t][4 * j], pw[t][4 * j + 1], pw[t][4 * j + 2], pw[t][4 * j + 3]});
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                O[t] = mfma32_f16(vf[0], pb[t][0], O[t]);
+                O[t] = mfma32_f16(vf[1], pb[t][1], O[t]);
+            }
+            if (post) {
+                // cheap offset move: the row's largest weight is known from its fp16 exponent; bring it down to 2^REST
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int mine = top[t];
+                    const int row = max(mine, __shfl_xor(mine, 32, 64));
+                    const int e = (row >> 10) - 15;                          // floor(log2(largest weight)); sub-normals give < -14
+                    const float delta = (float)max(0, e - (int)LAZY_REST);
+                    mq[t] += delta;
+                    if (half) qf[t][1][7] = (f16)(-mq[t]);
+                    const float f = __builtin_amdgcn_exp2f(-delta);
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) O[t][r] *= f;
                 }
             }
         };
-        if constexpr (PIPE == 2) {
-            // Bias-fragment reuse (QTN == 2): the fragment of (query row hq+1, key row hk+1) equals that of
-            // (hq, hk), so tile 1 takes the fragment tile 0 gathered one key row earlier.  Two fragment
-            // registers HA / HB swap roles every row (no moves); the MFMA reads them as C and writes S
-            // elsewhere, so they survive.  Only a strip's first key row gathers twice.  LDS bias reads,
-            // the dominant cost of the plain loop (tools/ubench: +530 cycles per 32 reads), are halved.
-            static_assert(QTN == 2 || PIPE != 2, "fragment reuse is written for two query tiles per wave");
-            static_assert(KDMA != 2 || PIPE == 2, "the transpose-read V path is written for the PIPE == 2 loop");
-            auto frags = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], uint32_t (&ids)[4]) {
-                const int kb = kt * 32;
-                const int kk = kb + l31;
-                const int sw = (kk >> 2) & 3;
-                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
-                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
-                if constexpr (KDMA == 2) {
-                    // lane (d = l31, half): elements e < 4 = keys 16*s2 + 4*half + e, e >= 4 = keys 16*s2 + 8 + 4*half + e-4.
-                    // ds_read_b64_tr_b16: within a 16-lane group lane i points at row i>>2, columns 4*(i&3) of a [4 keys][16 d]
-                    // block and receives column (i & 15), rows 0..3.
-                    typedef __attribute__((__vector_size__(4 * sizeof(short)))) short s16x4;
-                    typedef __attribute__((address_space(3))) s16x4* lds_s16x4;
-                    const char* vb = Vs + (kb + 4 * half + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (16 * s2) * 64));
-                        const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4)(vb + (16 * s2 + 8) * 64));
-                        typedef __attribute__((__vector_size__(8 * sizeof(short)))) short s16x8;
-                        const s16x8 both = s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                        vf[s2] = __builtin_bit_cast(bf16x8, both);
-                    }
-                } else {
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
-                        const bf16x4 lo = *(const bf16x4*)(vp);
-                        const bf16x4 hi = *(const bf16x4*)(vp + 16);
-                        vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                    }
-                }
-                if (border) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
-                }
-            };
-            auto gather = [&](int t, int hk, f32x16& dst) {
-                const float* tp = tab + (Ub[t] + hk * D + 32 * sk);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dst[r] = tp[(r & 3) + 8 * (r >> 2)];
-            };
-            auto pair = [&](bf16x8 (&kf)[2], bf16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
-                f32x16 S[2];
-                S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[0][0], C0, 0, 0, 0);
-                S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[1][0], C1, 0, 0, 0);
-                S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[0][1], S[0], 0, 0, 0);
-                S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[1][1], S[1], 0, 0, 0);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) {
-                    if (border) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
-                            S[t][r] += idk != idq[t] ? MASK_L2 : 0.f;
-                        }
-                    }
-                    bf16x8 pb[2];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[t][r]);
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t], 0, 0, 0);
-                    O[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t], 0, 0, 0);
-                }
-            };
 #pragma unroll 1
-            for (int kt = 0; kt < FROWS; kt += 2) {
-                bf16x8 kf[2], vf[2];
-                uint32_t ids[4] = {0, 0, 0, 0};
-                frags(kt, kf, vf, ids);
-                if (hk0 + kt == 0) gather(1, 0, HB);      // strip start: tile 1 has no predecessor fragment
-                gather(0, hk0 + kt, HA);
-                pair(kf, vf, HA, HB, ids);
-                frags(kt + 1, kf, vf, ids);
-                gather(0, hk0 + kt + 1, HB);              // HB (tile 1 @ row kt) is consumed
-                pair(kf, vf, HB, HA, ids);                // tile 1 @ row kt+1 == tile 0 @ row kt
-            }
-        } else if constexpr (PIPE == 3) {
-            // Fragment ring for four query tiles per wave: fragment(tile t, key row hk) = fragment(tile 0,
-            // row hk - t).  Tile 0's gather at row hk lands in ring[(-hk) & 3]; tile t reads ring[(t - hk) & 3].
-            // A strip's first row gathers all four, every other row gathers one: 4x fewer LDS bias reads and
-            // K / V^T fragments shared by four tiles.
-            static_assert(QTN == 4 || PIPE != 3, "ring reuse is written for four query tiles per wave");
-            auto frags = [&](int kt, bf16x8 (&kf)[2], bf16x8 (&vf)[2], uint32_t (&ids)[4]) {
-                const int kb = kt * 32;
-                const int kk = kb + l31;
-                const int sw = (kk >> 2) & 3;
-                kf[0] = *(const bf16x8*)(Ks + kk * 64 + (((0 + half) ^ sw) << 4));
-                kf[1] = *(const bf16x8*)(Ks + kk * 64 + (((2 + half) ^ sw) << 4));
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const char* vp = Vt + l31 * FVROW + (kb + 16 * s2 + 4 * half) * 2;
-                    const bf16x4 lo = *(const bf16x4*)(vp);
-                    const bf16x4 hi = *(const bf16x4*)(vp + 16);
-                    vf[s2] = bf16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
-                if (border) {
-#pragma unroll
-                    for (int g = 0; g < 4; ++g) ids[g] = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
-                }
-            };
-            auto gather = [&](int t, int hk, f32x16& dst) {
-                const float* tp = tab + (Ub[t] + hk * D + 32 * sk);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) dst[r] = tp[(r & 3) + 8 * (r >> 2)];
-            };
-            auto two = [&](int t0, bf16x8 (&kf)[2], bf16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
-                f32x16 S[2];
-                S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t0][0], C0, 0, 0, 0);
-                S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[0], qf[t0 + 1][0], C1, 0, 0, 0);
-                S[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t0][1], S[0], 0, 0, 0);
-                S[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[1], qf[t0 + 1][1], S[1], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 2; ++u) {
-                    if (border) {
-#pragma unroll
-                        for (int r = 0; r < 16; ++r) {
-                            const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
-                            S[u][r] += idk != idq[t0 + u] ? MASK_L2 : 0.f;
-                        }
-                    }
-                    bf16x8 pb[2];
-#pragma unroll
-                    for (int r = 0; r < 16; ++r) pb[r >> 3][r & 7] = (bf16)__builtin_amdgcn_exp2f(S[u][r]);
-                    O[t0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[0], pb[0], O[t0 + u], 0, 0, 0);
-                    O[t0 + u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[1], pb[1], O[t0 + u], 0, 0, 0);
-                }
-            };
-#define GRL_RING_ROW(J, R0, R1, R2, R3)                                                        \
-    {                                                                                          \
-        bf16x8 kf[2], vf[2];                                                                   \
-        uint32_t ids[4] = {0, 0, 0, 0};                                                        \
-        frags(kt + J, kf, vf, ids);                                                            \
-        gather(0, hk0 + kt + J, R0);                                                           \
-        two(0, kf, vf, R0, R1, ids);                                                           \
-        two(2, kf, vf, R2, R3, ids);                                                           \
-    }
-#pragma unroll 1
-            for (int kt = 0; kt < FROWS; kt += 4) {
-                if (hk0 + kt == 0) {  // strip start: rows -1..-3 do not exist, gather tiles 1..3 for row 0
-                    gather(1, 0, H1);
-                    gather(2, 0, H2);
-                    gather(3, 0, H3);
-                }
-                // row j: tile t reads ring[(t - j) & 3]; the new fragment goes to ring[(-j) & 3]
-                GRL_RING_ROW(0, HA, H1, H2, H3)
-                GRL_RING_ROW(1, H3, HA, H1, H2)
-                GRL_RING_ROW(2, H2, H3, HA, H1)
-                GRL_RING_ROW(3, H1, H2, H3, HA)
-            }
-#undef GRL_RING_ROW
-        } else if constexpr (PIPE == 1) {
-            // two register sets (A, B): while one key tile is in the matrix core the next one's LDS reads are in flight
-            bf16x8 kfA[2], vfA[2], kfB[2], vfB[2];
-            f32x16 SA[QTN], SB[QTN];
-            uint32_t idA[4] = {0, 0, 0, 0}, idB[4] = {0, 0, 0, 0};
-            lds_tile(0, kfA, vfA, SA, idA);
-#pragma unroll 1
-            for (int kt = 0; kt < FROWS; kt += 2) {
-                lds_tile(kt + 1, kfB, vfB, SB, idB);
-                compute_tile(kfA, vfA, SA, idA);
-                if (kt + 2 < FROWS) lds_tile(kt + 2, kfA, vfA, SA, idA);
-                compute_tile(kfB, vfB, SB, idB);
-            }
-        } else {
-#pragma unroll 1
-            for (int kt = 0; kt < FROWS; ++kt) {
-                bf16x8 kf[2], vf[2];
-                f32x16 S[QTN];
-                uint32_t ids[4] = {0, 0, 0, 0};
-                lds_tile(kt, kf, vf, S, ids);
-                compute_tile(kf, vf, S, ids);
-            }
+        for (int kt = 0; kt < FROWS; kt += 2) {
+            f16x8 kf[2], vf[2];
+            uint32_t ids[4] = {0, 0, 0, 0};
+            frags(kt, kf, vf, ids);
+            if (hk0 + kt == 0) gather(1, 0, HB);      // strip start: tile 1 has no predecessor fragment
+            gather(0, hk0 + kt, HA);
+            pair(kf, vf, HA, HB, ids);
+            frags(kt + 1, kf, vf, ids);
+            gather(0, hk0 + kt + 1, HB);              // HB (tile 1 @ row kt) is consumed
+            pair(kf, vf, HB, HA, ids);                // tile 1 @ row kt+1 == tile 0 @ row kt
         }
-        if (dbg & 64) __builtin_amdgcn_s_setprio(0);
-        if (tbuf) { c3 = __builtin_amdgcn_s_memtime(); tm[2] += c1 - c0; tm[3] += c2 - c1; tm[4] += c3 - c2; }
     }
-    if (tbuf) tm[5] = __builtin_amdgcn_s_memtime();
     if (!active) return;
 
 #pragma unroll
     for (int t = 0; t < QTN; ++t) {
-        const int oc = p.ones_col;
-        const int base_row = oc & ~4;
-        float cand = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r)
-            if (mfma32_row(r, 0) == base_row) cand = O[t][r];
-        const float other = xhalf(cand);
-        const float l = (half == ((oc >> 2) & 1)) ? cand : other;
-        const float inv = 1.0f / l;
-        bf16* dst = (bf16*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            uint2 pk;
-            pk.x = pack16(O[t][4 * g + 0] * inv, O[t][4 * g + 1] * inv, p.out_dtype);
-            pk.y = pack16(O[t][4 * g + 2] * inv, O[t][4 * g + 3] * inv, p.out_dtype);
-            *(uint2*)(dst + 8 * g) = pk;
-        }
-    }
-    if (tbuf && tid == 0) {
-        const long long t_end = __builtin_amdgcn_s_memtime();
-        long long* o = tbuf + (long long)blockIdx.x * 8;
-        o[0] = tm[0]; o[1] = tm[1] - tm[0]; o[2] = tm[2]; o[3] = tm[3]; o[4] = tm[4]; o[5] = t_end - tm[5]; o[6] = t_end - tm[0];
-        o[7] = __builtin_amdgcn_s_getreg(((1 - 1) << 11) | (0 << 6) | 20);  // HW_REG_XCC_ID
+        const float l = ones_row(O[t], p.ones_col, half);
+        store_o(p, O[t], 1.0f / l, qrow[t], head, half);
+        if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + qrow[t]] = mq[t] + __builtin_amdgcn_logf(l);
     }
 }
 
-size_t fast_lds_bytes(const GrlAttnArgs& p, int frows, int fw = 4, int qtn = 2, int kdma = 0) {
-    const size_t kc = (size_t)frows * 32;
-    const size_t tf = kdma ? (size_t)fast_table_floats(p, fw, qtn) : (size_t)p.trows;
-    const size_t tab = (tf * 4 + 15) & ~(size_t)15;
+size_t fast_lds_bytes(const GrlAttnArgs& p, int kdma) {
+    const size_t kc = (size_t)FKC;
+    const size_t tab = ((size_t)fast_table_floats(p) * 4 + 15) & ~(size_t)15;
     if (kdma == 2) return tab + 4 * kc * 64 + 2 * kc;
-    return tab + (kdma ? 2 : 1) * kc * 64 + 32 * (kc * 2 + 8) + kc;
+    return tab + 2 * kc * 64 + 32 * (kc * 2 + 8) + kc;
 }
 
-long long* g_tbuf = nullptr;  // optional per-workgroup phase timestamps (tools/attn_phases.py)
-
-template <int FW, int QTN, int FROWS, int WPS, int PIPE, int KDMA = 0>
+template <int KDMA>
 int launch_fast_v(const GrlAttnArgs& p, hipStream_t st) {
     const int units = (p.q.wh / QTN) * (p.q.ww >> 5);
     const int upw = min(FW, units);
     const int nqs = (units + upw - 1) / upw;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
-    const size_t lds = fast_lds_bytes(p, FROWS, FW, QTN, KDMA);
+    const size_t lds = fast_lds_bytes(p, KDMA);
     if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
-    auto kfn = attn_fast_kernel<FW, QTN, FROWS, WPS, PIPE, KDMA>;
+    auto kfn = attn_fast_kernel<KDMA>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    static const int dbg = getenv("GRL_ATTN_DEBUG") ? atoi(getenv("GRL_ATTN_DEBUG")) : 0;  // timing ablations only
-    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p, dbg, g_tbuf);
+    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(FW * 64), lds, st, p);
     GRL_CHECK_LAUNCH();
     return 0;
 }
 
 int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
-    static const int variant = getenv("GRL_ATTN_VARIANT") ? atoi(getenv("GRL_ATTN_VARIANT")) : 0;
-    if (variant == 1) return launch_fast_v<4, 2, 8, 2, 0>(p, st);
-    if (variant == 2) return launch_fast_v<4, 2, 4, 3, 0>(p, st);   // 3 workgroups per CU
-    if (variant == 3 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 0>(p, st);
-    if (variant == 4) return launch_fast_v<4, 2, 8, 2, 1>(p, st);
-    if (variant == 5 && (p.q.wh % 4) == 0) return launch_fast_v<4, 4, 8, 2, 3>(p, st);   // 4-tile fragment ring
-    if (variant == 6) return launch_fast_v<8, 2, 8, 2, 2>(p, st);   // 8 waves share one K/V chunk
-    if (variant == 7) return launch_fast_v<8, 2, 16, 2, 2>(p, st);  // ... and 16-row chunks
-    if (variant == 9) return launch_fast_v<4, 2, 8, 2, 2>(p, st);   // register-staged K (previous default)
-    if (variant == 10) return launch_fast_v<8, 2, 8, 2, 2, 1>(p, st);   // 8 waves share the staged chunks (1 workgroup / CU)
-    if (variant == 11) return launch_fast_v<4, 2, 8, 2, 2, 1>(p, st);   // K by DMA, V prefetched in registers + transposed commit
-    if (variant == 12) return launch_fast_v<4, 2, 8, 2, 2, 2>(p, st);   // K and V by DMA (8-row chunks)
-    if (variant == 13) return launch_fast_v<4, 2, 4, 2, 2, 2>(p, st);   // K and V by DMA (4-row chunks)
-    // default: bias-fragment reuse loop; K and V by DMA into double buffers and V through the hardware transpose read when
-    // two workgroups still fit a CU (window, window->anchor: -2 %), else K by DMA + V through registers (anchor->window:
-    // its 27 KB table slice + four 16 KB buffers would leave one workgroup per CU; 4-row chunks are slower)
-    int rc = GRL_ERR_UNSUPPORTED;
-    if (fast_lds_bytes(p, 8, 4, 2, 2) <= 80 * 1024) rc = launch_fast_v<4, 2, 8, 2, 2, 2>(p, st);
-    if (rc == GRL_ERR_UNSUPPORTED) rc = launch_fast_v<4, 2, 8, 2, 2, 1>(p, st);
-    return rc == GRL_ERR_UNSUPPORTED ? launch_fast_v<4, 2, 8, 2, 2>(p, st) : rc;
+    // K and V by DMA into double buffers and V through the hardware transpose read when two workgroups still fit a CU
+    // (window, window->anchor), else K by DMA + V through registers (anchor->window: its 27 KB table slice + four 16 KB
+    // buffers would leave one workgroup per CU)
+    return fast_lds_bytes(p, 2) <= 80 * 1024 ? launch_fast_v<2>(p, st) : launch_fast_v<1>(p, st);
 }
 
 }  // namespace
-
-extern "C" void grl_debug_attention_timestamps(long long* buf) { g_tbuf = buf; }
 
 extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     const GrlAttnArgs& p = *args;
@@ -886,14 +738,17 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (p.k.Himg != p.nwy * p.k.wh || p.k.Wimg != p.nwx * p.k.ww) return GRL_ERR_BAD_ARG;
     if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1) || p.tstride < p.trows || (p.tstride & 3)) return GRL_ERR_BAD_ARG;
     if (p.head_dim > 32 || p.ones_col >= 32) return GRL_ERR_BAD_ARG;
-    if (p.out_dtype != GRL_DT_BF16 && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
+    if (p.out_dtype != GRL_DT_F32 && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
     if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 4) || (p.q.col0 % 8) || (p.k.col0 % 8) ||
         (p.v.col0 % 8) || (p.o.col0 % 4) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 4))
         return GRL_ERR_BAD_ARG;
+    if (p.lse != nullptr && p.lse_stride <= 0) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    // fast path: 32-aligned geometry with the fixed softmax bound and the ones column
-    if (p.fixed_max && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
-        (p.k.wh % 8) == 0 && fast_lds_bytes(p, 8) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
+    // fast path: 32-aligned geometry with the ones column and the lazy running offset (needs the spare head-dim slot 31:
+    // K carries 1.0 there, `k_one31`)
+    const bool lazy_ok = p.k_one31 && p.head_dim <= 30 && p.ones_col != 31 && p.lazy_floor != nullptr;
+    if (lazy_ok && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
+        (p.k.wh % 8) == 0 && fast_lds_bytes(p, 1) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
         return launch_fast(p, st);
     const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
     const int qblk = waves * QT * 32;
@@ -902,9 +757,5 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
     const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC * 4 + KC;
     if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
-    const bool ones = p.ones_col >= 0;
-    if (p.fixed_max) return ones ? launch_kw<true, true>(p, (int)grid, waves * 64, lds, st)
-                                 : launch_kw<true, false>(p, (int)grid, waves * 64, lds, st);
-    return ones ? launch_kw<false, true>(p, (int)grid, waves * 64, lds, st)
-                : launch_kw<false, false>(p, (int)grid, waves * 64, lds, st);
+    return p.ones_col >= 0 ? launch_kw<true>(p, (int)grid, waves * 64, lds, st) : launch_kw<false>(p, (int)grid, waves * 64, lds, st);
 }

@@ -42,12 +42,19 @@ typedef f16x4 gemm_x4;
 __device__ __forceinline__ f32x4 mfma16_gemm(gemm_x8 a, gemm_x8 b, f32x4 c) {
     return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0);
 }
+typedef __attribute__((__vector_size__(2 * sizeof(_Float16)))) _Float16 f16x2;
+// fp32 -> fp16 with saturation: a residual-stream value beyond +-65504 becomes the largest finite half instead of inf
+// (one v_med3_f32; NaN propagates).  Every fp32 -> fp16 staging / store point of the kernels goes through this.
+__device__ __forceinline__ float sat16(float x) { return __builtin_amdgcn_fmed3f(x, -65504.0f, 65504.0f); }
+__device__ __forceinline__ f16 to_f16(float x) { return (f16)sat16(x); }
 __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
-    typedef __attribute__((__vector_size__(2 * sizeof(_Float16)))) _Float16 f16x2;
     f16x2 v;
-    v[0] = (f16)lo;
-    v[1] = (f16)hi;
+    v[0] = to_f16(lo);
+    v[1] = to_f16(hi);
     return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
 // 16-bit storage kinds of the C ABI: GRL_DT_BF16 / GRL_DT_F16 (include/grl_hip.h)
 __device__ __forceinline__ uint32_t pack16(float lo, float hi, int kind) {

@@ -78,22 +78,30 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
         }
     };
 
+    // x_split == 3: the virtual input channels are [hi(x) | lo(x) | hi(x)] over CinP / 3 source channels (grl_hip.h)
+    const int csrc = p.x_split == 3 ? p.CinP / 3 : p.CinP;
     auto stage_input = [&](int kc) {
 #pragma unroll 2
         for (int s = tid; s < HALO_H * HALO_W * SEG_ROW; s += CWAVES * 64) {
             const int pix = s / SEG_ROW, cc = s % SEG_ROW;
+            const int vch = kc * KC + cc * 8;             // first virtual channel of this 16-B segment
+            const int part = vch / csrc, ch0 = vch - part * csrc;
             const int hy = pix / HALO_W, hx = pix % HALO_W;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             gemm_x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
             if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
                 const int64_t row = ((int64_t)b * p.H + gy) * p.W + gx;
                 if (p.x_dtype == GRL_DT_F16) {
-                    v = *(const gemm_x8*)((const gemm_t*)p.x + row * p.ldx + kc * KC + cc * 8);
+                    v = *(const gemm_x8*)((const gemm_t*)p.x + row * p.ldx + ch0);
                 } else {
-                    const float4* q = (const float4*)((const float*)p.x + row * p.ldx + kc * KC + cc * 8);
+                    const float4* q = (const float4*)((const float*)p.x + row * p.ldx + ch0);
                     const float4 a0 = q[0], a1 = q[1];
-                    v[0] = (gemm_t)a0.x; v[1] = (gemm_t)a0.y; v[2] = (gemm_t)a0.z; v[3] = (gemm_t)a0.w;
-                    v[4] = (gemm_t)a1.x; v[5] = (gemm_t)a1.y; v[6] = (gemm_t)a1.z; v[7] = (gemm_t)a1.w;
+                    const float e[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const f16 h = to_f16(e[i]);
+                        v[i] = part == 1 ? (f16)(e[i] - (float)h) : h;
+                    }
                 }
             }
             *(gemm_x8*)(in_s + pix * ROWB + cc * 16) = v;
@@ -208,8 +216,8 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
                     for (int e = 0; e < 4; ++e) psum[nt][e] += v[e];
                 }
                 uint2 pk;
-                pk.x = pack16(v[0], v[1], p.out_dtype);
-                pk.y = pack16(v[2], v[3], p.out_dtype);
+                pk.x = pack_f16(v[0], v[1]);
+                pk.y = pack_f16(v[2], v[3]);
                 *(uint2*)(prow + c * 2) = pk;
             }
         }
@@ -271,8 +279,8 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
                 if (!keep) {
                 } else if (p.out_dtype != GRL_DT_F32) {
                     uint2 pk;
-                    pk.x = pack16(v[0], v[1], p.out_dtype);
-                    pk.y = pack16(v[2], v[3], p.out_dtype);
+                    pk.x = pack_f16(v[0], v[1]);
+                    pk.y = pack_f16(v[2], v[3]);
                     *(uint2*)((gemm_t*)p.out + orow * p.ldo + oc) = pk;
                 } else {
                     *(float4*)((float*)p.out + orow * p.ldo + oc) = float4{v[0], v[1], v[2], v[3]};
@@ -405,6 +413,8 @@ extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     const GrlConvArgs& p = *args;
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return GRL_ERR_BAD_ARG;
     if (p.CinP % 32 || p.CoutP % 16 || p.CoutP > 192 || (p.ldx % 8) || (p.ldo % 4)) return GRL_ERR_BAD_ARG;
+    if (p.x_split != 0 && p.x_split != 1 && p.x_split != 3) return GRL_ERR_BAD_ARG;
+    if (p.x_split == 3 && (p.x_dtype != GRL_DT_F32 || p.CinP % 24 != 0)) return GRL_ERR_BAD_ARG;   // parts are whole 8-channel segments
     if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;
     if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -30,9 +30,18 @@ namespace {
 //   MT = 1, WV = 16 : 256 rows / workgroup, <= 128 VGPRs -> 4 waves per SIMD hide the load / epilogue latency
 //                     of these HBM-bound layers better (measured), at twice the LDS fragment reads per MFMA
 
+// hi / lo halves of a split-precision operand: hi = fp16(x), lo = fp16(x - hi)
+__device__ __forceinline__ f16 split_part(float x, bool lo) {
+    const f16 h = to_f16(x);
+    return lo ? (f16)(x - (float)h) : h;
+}
+
 template <int KSTEPS, int MT>
 __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, int lane, gemm_x8 (&a)[MT][KSTEPS]) {
     const int r = lane & 15, kg = lane >> 4;
+    // a_split == 3: virtual K = [hi | lo | hi] over a source of KS3 k-steps (KSTEPS = 3 * KS3)
+    const bool split = p.a_split == 3;
+    constexpr int KS3 = KSTEPS / 3;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int m = row0 + 16 * mt + r;
@@ -47,16 +56,17 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
             const float* base = (const float*)p.a + ((int64_t)(b * p.pool_H + ya * df) * p.pool_W + xa * df) * p.lda;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
+                const int ss = split ? s % KS3 : s;
                 float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
                 for (int dy = 0; dy < df; ++dy)
                     for (int dx = 0; dx < df; ++dx) {
-                        const float4* q = (const float4*)(base + ((int64_t)dy * p.pool_W + dx) * p.lda + 32 * s + 8 * kg);
+                        const float4* q = (const float4*)(base + ((int64_t)dy * p.pool_W + dx) * p.lda + 32 * ss + 8 * kg);
                         float4 v0 = q[0], v1 = q[1];
                         acc[0] += v0.x; acc[1] += v0.y; acc[2] += v0.z; acc[3] += v0.w;
                         acc[4] += v1.x; acc[5] += v1.y; acc[6] += v1.z; acc[7] += v1.w;
                     }
 #pragma unroll
-                for (int e = 0; e < 8; ++e) a[mt][s][e] = (gemm_t)(valid ? acc[e] * inv : 0.0f);
+                for (int e = 0; e < 8; ++e) a[mt][s][e] = split_part(valid ? acc[e] * inv : 0.0f, split && s / KS3 == 1);
             }
         } else if (p.a_dtype == GRL_DT_F16) {
             const gemm_t* base = (const gemm_t*)p.a + (int64_t)m * p.lda;
@@ -70,12 +80,14 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
             const float* base = (const float*)p.a + (int64_t)m * p.lda;
 #pragma unroll
             for (int s = 0; s < KSTEPS; ++s) {
-                const float4* q = (const float4*)(base + 32 * s + 8 * kg);
+                const int ss = split ? s % KS3 : s;
+                const bool lo = split && s / KS3 == 1;
+                const float4* q = (const float4*)(base + 32 * ss + 8 * kg);
                 float4 v0 = q[0], v1 = q[1];
                 if (!valid) { v0 = float4{0, 0, 0, 0}; v1 = v0; }
                 gemm_x8 v;
-                v[0] = (gemm_t)v0.x; v[1] = (gemm_t)v0.y; v[2] = (gemm_t)v0.z; v[3] = (gemm_t)v0.w;
-                v[4] = (gemm_t)v1.x; v[5] = (gemm_t)v1.y; v[6] = (gemm_t)v1.z; v[7] = (gemm_t)v1.w;
+                v[0] = split_part(v0.x, lo); v[1] = split_part(v0.y, lo); v[2] = split_part(v0.z, lo); v[3] = split_part(v0.w, lo);
+                v[4] = split_part(v1.x, lo); v[5] = split_part(v1.y, lo); v[6] = split_part(v1.z, lo); v[7] = split_part(v1.w, lo);
                 a[mt][s] = v;
             }
         }
@@ -86,7 +98,7 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
 template <int NT, int NCH, int MT, int EPI, bool ADD2, int mt>
 __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NCH][MT][NT], int m, bool valid, int n0, int g4) {
     if constexpr (EPI == GRL_EPI_GROUPNORM) {
-        // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * gscale[g];
+        // per 32-channel group (= one attention head slot): x / max(|x|,1e-12) * |gscale[g]|;
         // gscale == 0 marks a pass-through group (v).  F.normalize eps: efficient.py:85.
 #pragma unroll
         for (int g = 0; g < NT / 2; ++g) {
@@ -99,9 +111,10 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
             ss += __shfl_xor(ss, 16, 64);
             ss += __shfl_xor(ss, 32, 64);
             const float gs = p.gscale[(n0 >> 5) + g];
-            const float f = gs != 0.0f ? gs / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+            const float f = gs != 0.0f ? fabsf(gs) / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
 #pragma unroll
             for (int e = 0; e < 4; ++e) { acc[0][mt][2 * g][e] *= f; acc[0][mt][2 * g + 1][e] *= f; }
+            if (gs < 0.0f && g4 == 3) acc[0][mt][2 * g + 1][3] = 1.0f;   // column 31 of a K plane (grl_hip.h)
         }
     } else if constexpr (EPI == GRL_EPI_GELU) {
 #pragma unroll
@@ -201,10 +214,10 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 #pragma unroll
             for (int nt = 0; nt < NT; nt += 2) {
                 uint2 lo, hi;  // this lane's 4 channels of tile nt / tile nt+1
-                lo.x = pack16(acc[c][mt][nt][0], acc[c][mt][nt][1], p.out_dtype);
-                lo.y = pack16(acc[c][mt][nt][2], acc[c][mt][nt][3], p.out_dtype);
-                hi.x = pack16(acc[c][mt][nt + 1][0], acc[c][mt][nt + 1][1], p.out_dtype);
-                hi.y = pack16(acc[c][mt][nt + 1][2], acc[c][mt][nt + 1][3], p.out_dtype);
+                lo.x = pack_f16(acc[c][mt][nt][0], acc[c][mt][nt][1]);
+                lo.y = pack_f16(acc[c][mt][nt][2], acc[c][mt][nt][3]);
+                hi.x = pack_f16(acc[c][mt][nt + 1][0], acc[c][mt][nt + 1][1]);
+                hi.y = pack_f16(acc[c][mt][nt + 1][2], acc[c][mt][nt + 1][3]);
                 const uint2 send = odd ? lo : hi;       // even lanes keep tile nt, odd lanes keep tile nt+1
                 uint2 recv;
                 recv.x = __shfl_xor(send.x, 16, 64);
@@ -214,7 +227,7 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
                 const int col = n0 + 16 * (c * NT + nt + (odd ? 1 : 0)) + 4 * (g4 & ~1);
                 const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
                                                            : (int64_t)m * p.ldo + col;
-                if (valid) *(uint4*)((bf16*)p.out + off) = v;
+                if (valid) *(uint4*)((f16*)p.out + off) = v;
             }
         return;
     }
@@ -345,6 +358,8 @@ int launch_one(const GrlLinearArgs& p, hipStream_t st) {
     if (shape == 0) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 2, 8>(p, st);
     if (shape == 1) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
     if (shape == 2) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
+    // split-precision layers: the operand slab alone is 4 * KSTEPS VGPRs -> 8 waves (256 VGPRs each)
+    if constexpr (KSTEPS >= 18) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 8>(p, st);
     // default: LayerNorm epilogues need ~150 VGPRs -> 12 waves (3 per SIMD); the others fit 16 waves
     if constexpr (EPI == GRL_EPI_LN_RES) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
     return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
@@ -389,12 +404,18 @@ int launch_split(const GrlLinearArgs& p0, hipStream_t st) {
     // weight matrices larger than the LDS budget are processed as several column slabs (whole 32-column
     // groups, so head planes / group norms stay intact); the activations are re-read per slab
     const size_t rowb = KSTEPS * 64 + 16;
-    int max_rows = (int)(LDS_BUDGET / rowb) / 96 * 96;
+    const int max_rows = (int)(LDS_BUDGET / rowb) / 32 * 32;
     if (max_rows <= 0) return GRL_ERR_UNSUPPORTED;
     if ((size_t)p0.Npad * rowb <= LDS_BUDGET) return launch_k<KSTEPS>(p0, st);
     if (p0.epi == GRL_EPI_LN_RES) return GRL_ERR_UNSUPPORTED;
+    // equal slabs of whole 32-column groups whose n-tile count launch_k can chunk (multiples of 64 or 96 columns)
     int nslabs = (p0.Npad + max_rows - 1) / max_rows;
-    while (p0.Npad % nslabs || (p0.Npad / nslabs) % 32) ++nslabs;
+    for (;; ++nslabs) {
+        if (nslabs > p0.Npad / 32) return GRL_ERR_UNSUPPORTED;
+        if (p0.Npad % nslabs) continue;
+        const int nc = p0.Npad / nslabs;
+        if (nc <= max_rows && (nc % 64 == 0 || nc % 96 == 0)) break;
+    }
     const int ncol = p0.Npad / nslabs;
     for (int sidx = 0; sidx < nslabs; ++sidx) {
         GrlLinearArgs p = p0;
@@ -422,12 +443,18 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
     if (p.add2 != nullptr && (p.add2_dtype != GRL_DT_F16 || p.add2_scale == nullptr || p.rows_per_image <= 0)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (p.a_split == 3 && ((p.Kpad / 32) % 3 != 0 || p.a_dtype != GRL_DT_F32)) return GRL_ERR_BAD_ARG;
+    if (p.a_split != 0 && p.a_split != 1 && p.a_split != 3) return GRL_ERR_BAD_ARG;
     switch (p.Kpad / 32) {
         case 2: return launch_split<2>(p, st);
+        case 3: return launch_split<3>(p, st);
         case 4: return launch_split<4>(p, st);
         case 6: return launch_split<6>(p, st);
         case 8: return launch_split<8>(p, st);
         case 12: return launch_split<12>(p, st);
+        case 18: return launch_split<18>(p, st);   // split-precision operands of the 192- and 256-wide layers
+        case 24: return launch_split<24>(p, st);
+        case 36: return launch_split<36>(p, st);
         default: return GRL_ERR_UNSUPPORTED;
     }
 }

@@ -42,7 +42,67 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const float* __restrict_
     }
 }
 
+// y = resid + res_scale * LayerNorm(x) (+ add2 * gate[image])  -- the un-fused form of the linear kernel's LN_RES epilogue,
+// used by the split-precision path (its projections are slab-split and cannot carry the row norm in their epilogue)
+__global__ __launch_bounds__(256) void layernorm_res_kernel(GrlLnResArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= p.M) return;
+    const int c = lane * 4;
+    const bool in = c < p.n_pad;
+    float4 v = float4{0, 0, 0, 0};
+    if (in) v = *(const float4*)(p.x + (int64_t)row * p.ldx + c);
+    float e[4] = {v.x, v.y, v.z, v.w};
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) s += (c + i) < p.n_real ? e[i] : 0.f;
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o, 64);
+    const float mean = s / (float)p.n_real;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float d = e[i] - mean;
+        q += (c + i) < p.n_real ? d * d : 0.f;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) q += __shfl_xor(q, o, 64);
+    const float rstd = rsqrtf(q / (float)p.n_real + p.eps);
+    if (!in) return;
+    const float4 r4 = *(const float4*)(p.resid + (int64_t)row * p.ldr + c);
+    const float r[4] = {r4.x, r4.y, r4.z, r4.w};
+    float a[4] = {0, 0, 0, 0};
+    if (p.add2 != nullptr) {
+        const float4 g4 = *(const float4*)(p.add2_scale + (int64_t)(row / p.rows_per_image) * p.n_pad + c);
+        if (p.add2_dtype == GRL_DT_F32) {
+            const float4 a4 = *(const float4*)((const float*)p.add2 + (int64_t)row * p.ldadd2 + c);
+            a[0] = a4.x * g4.x; a[1] = a4.y * g4.y; a[2] = a4.z * g4.z; a[3] = a4.w * g4.w;
+        } else {
+            const f16x4 a4 = *(const f16x4*)((const f16*)p.add2 + (int64_t)row * p.ldadd2 + c);
+            a[0] = (float)a4[0] * g4.x; a[1] = (float)a4[1] * g4.y; a[2] = (float)a4[2] * g4.z; a[3] = (float)a4[3] * g4.w;
+        }
+    }
+    float o4[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+        o4[i] = (c + i) < p.n_real ? r[i] + p.res_scale * ((e[i] - mean) * rstd * p.gamma[c + i] + p.beta[c + i]) + a[i] : 0.f;
+    *(float4*)(p.y + (int64_t)row * p.ldy + c) = float4{o4[0], o4[1], o4[2], o4[3]};
+}
+
 }  // namespace
+
+extern "C" int grl_layernorm_res_fwd(void* stream, const GrlLnResArgs* args) {
+    const GrlLnResArgs& p = *args;
+    if (p.M <= 0) return 0;
+    if (p.n_pad > 256 || (p.n_pad & 3) || p.n_real > p.n_pad || (p.ldx & 3) || (p.ldy & 3) || (p.ldr & 3) || p.resid == nullptr)
+        return GRL_ERR_BAD_ARG;
+    if (p.add2 != nullptr && (p.add2_scale == nullptr || p.rows_per_image <= 0 || (p.ldadd2 & 3) ||
+                              (p.add2_dtype != GRL_DT_F32 && p.add2_dtype != GRL_DT_F16)))
+        return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(layernorm_res_kernel, dim3((p.M + 3) / 4), dim3(256), 0, (hipStream_t)stream, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
 
 extern "C" int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
                                  const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps) {

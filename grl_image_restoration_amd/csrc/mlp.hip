@@ -243,8 +243,8 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
 #pragma unroll
         for (int s = 0; s < KSTEPS; ++s) {
             gemm_x8 v;
-            v[0] = (gemm_t)xs[s][0].x; v[1] = (gemm_t)xs[s][0].y; v[2] = (gemm_t)xs[s][0].z; v[3] = (gemm_t)xs[s][0].w;
-            v[4] = (gemm_t)xs[s][1].x; v[5] = (gemm_t)xs[s][1].y; v[6] = (gemm_t)xs[s][1].z; v[7] = (gemm_t)xs[s][1].w;
+            v[0] = to_f16(xs[s][0].x); v[1] = to_f16(xs[s][0].y); v[2] = to_f16(xs[s][0].z); v[3] = to_f16(xs[s][0].w);
+            v[4] = to_f16(xs[s][1].x); v[5] = to_f16(xs[s][1].y); v[6] = to_f16(xs[s][1].z); v[7] = to_f16(xs[s][1].w);
             a[s] = v;
         }
         f32x4 acc[NT2];
@@ -292,10 +292,10 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
             for (int j = 0; j < QB; ++j) w2[0][j] = *(const gemm_x8*)(cur + S::W1B + (16 * j + r16) * S::W2ROW + 16 * g4);
             __builtin_amdgcn_sched_barrier(0);
             gemm_x8 hb;   // k-slots 8*g4 + [0..7] of this chunk for token r16 (see the header comment)
-            hb[0] = (gemm_t)gelu_erf(h0[0] + bA.x); hb[1] = (gemm_t)gelu_erf(h0[1] + bA.y);
-            hb[2] = (gemm_t)gelu_erf(h0[2] + bA.z); hb[3] = (gemm_t)gelu_erf(h0[3] + bA.w);
-            hb[4] = (gemm_t)gelu_erf(h1[0] + bB.x); hb[5] = (gemm_t)gelu_erf(h1[1] + bB.y);
-            hb[6] = (gemm_t)gelu_erf(h1[2] + bB.z); hb[7] = (gemm_t)gelu_erf(h1[3] + bB.w);
+            hb[0] = to_f16(gelu_erf(h0[0] + bA.x)); hb[1] = to_f16(gelu_erf(h0[1] + bA.y));
+            hb[2] = to_f16(gelu_erf(h0[2] + bA.z)); hb[3] = to_f16(gelu_erf(h0[3] + bA.w));
+            hb[4] = to_f16(gelu_erf(h1[0] + bB.x)); hb[5] = to_f16(gelu_erf(h1[1] + bB.y));
+            hb[6] = to_f16(gelu_erf(h1[2] + bB.z)); hb[7] = to_f16(gelu_erf(h1[3] + bB.w));
             __builtin_amdgcn_sched_barrier(0);
             // ---- acc += W2[:, chunk] . h ----
 #pragma unroll

@@ -1,6 +1,6 @@
 // Streaming QKV projection with the cosine-attention prologue fused (gfx950).
 //
-//   planes[slot][m][0..31] = groupnorm_slot( x[m, :] . W_slot^T + b_slot )        bf16 head planes
+//   planes[slot][m][0..31] = groupnorm_slot( x[m, :] . W_slot^T + b_slot )        fp16 head planes
 //
 // Replaces QKVProjection.forward (models/common/mixed_attn_block.py:669-676) + the F.normalize / logit-scale of
 // Attention.attn (models/common/mixed_attn_block_efficient.py:85-90, :39) exactly like the GRL_EPI_GROUPNORM path of
@@ -96,13 +96,13 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
             for (int s = 0; s < KSTEPS; ++s) {
                 const float4 v0 = *(const float4*)(rowp + 128 * s), v1 = *(const float4*)(rowp + 128 * s + 64);
                 gemm_x8 v;
-                v[0] = (gemm_t)v0.x; v[1] = (gemm_t)v0.y; v[2] = (gemm_t)v0.z; v[3] = (gemm_t)v0.w;
-                v[4] = (gemm_t)v1.x; v[5] = (gemm_t)v1.y; v[6] = (gemm_t)v1.z; v[7] = (gemm_t)v1.w;
+                v[0] = to_f16(v0.x); v[1] = to_f16(v0.y); v[2] = to_f16(v0.z); v[3] = to_f16(v0.w);
+                v[4] = to_f16(v1.x); v[5] = to_f16(v1.y); v[6] = to_f16(v1.z); v[7] = to_f16(v1.w);
                 a[s] = v;
             }
         }
         const int next_tile = tile + (int)gridDim.x;
-        bf16* orow = (bf16*)p.out + (int64_t)(valid ? m : 0) * 32 + 4 * g4;
+        f16* orow = (f16*)p.out + (int64_t)(valid ? m : 0) * 32 + 4 * g4;
 
 #pragma unroll 1
         for (int c = 0; c < nchunks; ++c, ++it) {
@@ -134,17 +134,19 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 h0[0] += bA.x; h0[1] += bA.y; h0[2] += bA.z; h0[3] += bA.w;
                 h1[0] += bB.x; h1[1] += bB.y; h1[2] += bB.z; h1[3] += bB.w;
-                // per-slot L2 normalisation times gscale (F.normalize eps 1e-12, efficient.py:85); gscale 0 = pass through (v)
+                // per-slot L2 normalisation times |gscale| (F.normalize eps 1e-12, efficient.py:85); gscale 0 = pass through (v);
+                // gscale < 0: column 31 of the slot is written as 1.0 (K planes: partner of the attention kernel's offset slot)
                 float ss = h0[0] * h0[0] + h0[1] * h0[1] + h0[2] * h0[2] + h0[3] * h0[3] + h1[0] * h1[0] + h1[1] * h1[1] +
                            h1[2] * h1[2] + h1[3] * h1[3];
                 ss += __shfl_xor(ss, 16, 64);
                 ss += __shfl_xor(ss, 32, 64);
-                const float f = gs != 0.0f ? gs / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+                const float f = gs != 0.0f ? fabsf(gs) / fmaxf(sqrtf(ss), 1e-12f) : 1.0f;
+                const float c31 = (gs < 0.0f && g4 == 3) ? 1.0f : h1[3] * f;
                 uint2 lo, hi;
-                lo.x = pack_bf16(h0[0] * f, h0[1] * f); lo.y = pack_bf16(h0[2] * f, h0[3] * f);
-                hi.x = pack_bf16(h1[0] * f, h1[1] * f); hi.y = pack_bf16(h1[2] * f, h1[3] * f);
+                lo.x = pack_f16(h0[0] * f, h0[1] * f); lo.y = pack_f16(h0[2] * f, h0[3] * f);
+                hi.x = pack_f16(h1[0] * f, h1[1] * f); hi.y = pack_f16(h1[2] * f, c31);
                 if (valid) {
-                    bf16* o = orow + (int64_t)(c * SPC + sl) * p.out_plane_stride;
+                    f16* o = orow + (int64_t)(c * SPC + sl) * p.out_plane_stride;
                     *(uint2*)(o) = lo;           // channels 4*g4 + [0..3]
                     *(uint2*)(o + 16) = hi;      // channels 16 + 4*g4 + [0..3]
                 }

@@ -163,6 +163,7 @@ class GRL(nn.Module):
         fairscale_checkpoint=False,
         offload_to_cpu=False,
         euclidean_dist=False,
+        precision="auto",  # not a reference option: "fast" | "high" | "auto" (operand precision of the HIP path, see below)
         **kwargs,  # name, double_window, stripe_square, separable_conv_act, use_buffer, ... (swallowed, grl.py:255)
     ):
         super().__init__()
@@ -202,6 +203,17 @@ class GRL(nn.Module):
         self.res_scale = 0.1 if init_method == "r" else 1.0
         self.input_resolution = to_2tuple(img_size)
         self.pad_size = pad_multiple(self.window_size[0], self.stripe_size, self.stripe_groups, self.df)
+        # Operand precision of the linear / conv contractions (attention always runs on fp16 operands):
+        #   fast : fp16 operands (2^-11 relative rounding), fused block-tail / streaming kernels
+        #   high : split operands a = hi + lo, w = hi + lo (3 MFMA terms, ~22 mantissa bits), fp32 intermediates
+        #   auto : high for the narrow models (embed_dim < 160: GRL-Tiny / GRL-Small), whose few channels average the
+        #          rounding noise least, and for the same-resolution tasks (no upsampler: denoising / deblurring), whose
+        #          output is x + conv_last(body) with no smoothing tail -- with fp16 operands both sit AT the 1e-3 parity bar
+        #          (tools/precision_sites.py: 0.9e-3 .. 1.1e-3 max-abs from operand rounding alone); fast for GRL-Base SR (2e-4).
+        precision = os.environ.get("GRL_PRECISION", precision)
+        if precision not in ("auto", "fast", "high"):
+            raise ValueError(f"precision={precision!r}: expected 'auto', 'fast' or 'high'")
+        self.precision = precision if precision != "auto" else ("high" if (embed_dim < 160 or not upsampler) else "fast")
         if embed_dim % 2 or any((embed_dim // 2) % h for h in self.num_heads_window + self.num_heads_stripe):
             raise ValueError("embed_dim/2 must be divisible by the number of heads")
         if max((embed_dim // 2) // h for h in self.num_heads_window + self.num_heads_stripe) > 32:
@@ -251,6 +263,8 @@ class GRL(nn.Module):
         self._init_method_rescale(init_method)
         self._plan_cache: Dict = {}
         self._register_load_state_dict_pre_hook(self._drop_reference_buffers)
+        # fires on the recursive path too (a parent module's load_state_dict, tools/trainer.py:108-111)
+        self.register_load_state_dict_post_hook(lambda module, incompatible_keys: module.invalidate_plan())
 
     # ---- init / checkpoint contract ------------------------------------------------------------
     @staticmethod
@@ -303,14 +317,20 @@ class GRL(nn.Module):
                 state_dict.pop(k)
         return state_dict
 
-    def load_state_dict(self, state_dict, strict=True, **kw):
-        out = super().load_state_dict(state_dict, strict=strict, **kw)
-        self.invalidate_plan()
-        return out
-
     def invalidate_plan(self):
-        """Call after changing parameters in place; packed weights/tables are rebuilt lazily."""
+        """Drops the packed weights / tables (rebuilt lazily) and every captured graph that points at them.  Called by the
+        load_state_dict post-hook; in-place parameter updates (optimizer, EMA copy) are caught by the version stamp
+        in ``_plan``."""
         self._plan_cache = {}
+        if getattr(self, "_graphs", None):
+            self._graphs = {}
+
+    def _param_stamp(self):
+        """Changes whenever a parameter is modified in place or replaced (torch bumps ``_version`` on every in-place op)."""
+        plist = getattr(self, "_plist", None)
+        if plist is None:
+            plist = self._plist = list(self.parameters())
+        return sum(p._version for p in plist)
 
     def train(self, mode: bool = True):
         if mode:
@@ -338,7 +358,10 @@ class GRL(nn.Module):
             return tables.clamped_scale(m.logit_scale).to(dev)
 
         sc_w, sc_1, sc_2 = aff(a.window_attn.attn_transform), aff(a.stripe_attn.attn_transform1), aff(a.stripe_attn.attn_transform2)
-        fixed = bool(tables.fixed_max_is_safe(torch.cat([sc_w, sc_1, sc_2])))
+        # K planes carry 1.0 in the spare head-dim slot 31 (negative gscale): partner of the attention kernel's running
+        # softmax offset, which lives in slot 31 of its Q fragments (include/grl_hip.h)
+        one_w, one_s = d_w <= 30, d_s <= 30
+        hi = self.precision == "high"
 
         # --- QKV: one 32-wide slot per (branch, q|k|v, head); v slots carry a constant-1 column ---
         W = a.qkv.body.weight.detach().float()
@@ -359,10 +382,13 @@ class GRL(nn.Module):
                     if which == 0:
                         gs[g] = (sc_w[h] if br == 0 else sc_2[h]) * LOG2E
                     elif which == 1:
-                        gs[g] = 1.0 if br == 0 else sc_1[h] * LOG2E
+                        one = one_w if br == 0 else one_s
+                        gs[g] = (1.0 if br == 0 else sc_1[h] * LOG2E) * (-1.0 if one else 1.0)
         G16 = ops.GEMM_DTYPE
-        pk = dict(qkv_w=Wp.to(G16), qkv_b=bp, qkv_gs=gs, fixed=fixed)
-        if CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
+        pk = dict(qkv_b=bp, qkv_gs=gs, one_w=one_w, one_s=one_s, floor_w=tables.lazy_floor(sc_w),
+                  floor_a2w=tables.lazy_floor(sc_1), floor_w2a=tables.lazy_floor(sc_2))
+        pk["qkv_w"] = ops.split3_weight(Wp) if hi else Wp.to(G16)
+        if not hi and CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
             pk.update(qkv_blob=ops.pack_qkv(Wp, bp, gs), qkv_slots=G)
 
         # --- anchor projection (avg-pool fused in the kernel) ---
@@ -373,7 +399,8 @@ class GRL(nn.Module):
         for h in range(nh_s):
             Wap[h * 32 : h * 32 + d_s, :C] = Wa[h * d_s : (h + 1) * d_s]
             bap[h * 32 : h * 32 + d_s] = ba[h * d_s : (h + 1) * d_s]
-        pk.update(anc_w=Wap.to(G16), anc_b=bap, anc_gs=torch.ones(nh_s, **f32))
+        pk.update(anc_w=ops.split3_weight(Wap) if hi else Wap.to(G16), anc_b=bap,
+                  anc_gs=torch.full((nh_s,), -1.0 if one_s else 1.0, **f32))
 
         # --- output projection over the slotted attention output + norm1 ---
         Wo = a.proj.weight.detach().float()
@@ -389,7 +416,8 @@ class GRL(nn.Module):
             out[: v.numel()] = v.detach().float()
             return out
 
-        pk.update(proj_w=Wop.to(G16), proj_b=padv(a.proj.bias), n1_g=padv(blk.norm1.weight), n1_b=padv(blk.norm1.bias))
+        pk.update(proj_w=ops.split3_weight(Wop) if hi else Wop.to(G16), proj_b=padv(a.proj.bias), n1_g=padv(blk.norm1.weight),
+                  n1_b=padv(blk.norm1.bias))
 
         # --- MLP + norm2 ---
         Hd = blk.mlp.fc1.weight.shape[0]
@@ -398,23 +426,24 @@ class GRL(nn.Module):
         W1[:Hd, :C] = blk.mlp.fc1.weight.detach().float()
         W2 = torch.zeros(CP, HP, **f32)
         W2[:C, :Hd] = blk.mlp.fc2.weight.detach().float()
-        pk.update(fc1_w=W1.to(G16), fc1_b=padv(blk.mlp.fc1.bias, HP), fc2_w=W2.to(G16),
+        pk.update(fc1_w=ops.split3_weight(W1) if hi else W1.to(G16), fc1_b=padv(blk.mlp.fc1.bias, HP),
+                  fc2_w=ops.split3_weight(W2) if hi else W2.to(G16),
                   fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
-        if CP in (64, 128, 192) and KA == CP and self.local_connection:   # + proj/norm1/CAB in front: one kernel per block tail
+        if not hi and CP in (64, 128, 192) and KA == CP and self.local_connection:   # + proj/norm1/CAB in front: one kernel per block tail
             pk["proj_blob"] = ops.pack_proj(Wop)
-        if CP in (64, 128, 192):  # fused fc1 -> GELU -> fc2 -> norm2 -> residual kernel (csrc/mlp.hip)
+        if not hi and CP in (64, 128, 192):  # fused fc1 -> GELU -> fc2 -> norm2 -> residual kernel (csrc/mlp.hip)
             pk.update(mlp_blob=ops.pack_mlp(blk.mlp.fc1.weight.to(dev), blk.mlp.fc1.bias.to(dev), blk.mlp.fc2.weight.to(dev), CP, HP),
                       mlp_hp=HP)
 
         # --- relative-position bias tables in the kernel's exp2 domain ---
-        def table(m: _Affine, win, df, scale):
+        def table(m: _Affine, win, df):
             coords = tables.coords_table(win, df, device=dev)
             bias = tables.bias_rows(m.cpb_mlp[0].weight.to(dev), m.cpb_mlp[0].bias.to(dev), m.cpb_mlp[2].weight.to(dev), coords)
-            return tables.kernel_table(bias, scale, fixed)
+            return tables.kernel_table(bias)
 
-        pk["tab_w"] = table(a.window_attn.attn_transform, geo.window, 1, sc_w)
-        pk["tab_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df, sc_1)
-        pk["tab_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df, sc_2)
+        pk["tab_w"] = table(a.window_attn.attn_transform, geo.window, 1)
+        pk["tab_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df)
+        pk["tab_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df)
         assert pk["tab_w"].shape[1] == (table_rows(geo.window, geo.window) + 3) // 4 * 4
         assert pk["tab_a2w"].shape[1] == (table_rows(geo.anchor_stripe, geo.stripe) + 3) // 4 * 4
 
@@ -424,9 +453,12 @@ class GRL(nn.Module):
             se = blk.conv.cab[3].attention
             Cm = c0.weight.shape[0]
             CmO, CmI = (Cm + 15) // 16 * 16, _pad32(Cm)  # conv1 writes CmO channels of a zeroed CmI-wide matrix
+            if hi:
+                CmO = CmI   # fp32 mid tensor written by the plain store path: every channel of its row comes from the conv
+            sp = 3 if hi else 1
             pk.update(
-                cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
-                cab2_w=ops.pack_conv_weight(c2.weight.to(dev), CmI, CP), cab2_b=ops.pack_conv_bias(c2.bias.to(dev), CP),
+                cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO, split=sp), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
+                cab2_w=ops.pack_conv_weight(c2.weight.to(dev), CmI, CP, split=sp), cab2_b=ops.pack_conv_bias(c2.bias.to(dev), CP),
                 cab_mid=CmI,
                 se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).contiguous().to(dev),
                 se1_b=se[1].bias.detach().float().to(dev),
@@ -436,10 +468,12 @@ class GRL(nn.Module):
         return pk
 
     def _plan(self, x_size, dev):
-        key = (tuple(x_size), str(dev))
+        key = (tuple(x_size), str(dev), self._param_stamp())
         plan = self._plan_cache.get(key)
         if plan is not None:
             return plan
+        hi = self.precision == "high"
+        sp = 3 if hi else 1
         C, CP = self.embed_dim, _pad32(self.embed_dim)
         f32 = dict(dtype=torch.float32, device=dev)
         sched = block_schedule(self.depths, self.num_heads_window, self.num_heads_stripe, self.window_size,
@@ -451,7 +485,7 @@ class GRL(nn.Module):
             return out
 
         def pconv(conv, cin_pad, cout_pad, r=0, cg=0):
-            return (ops.pack_conv_weight(conv.weight.to(dev), cin_pad, cout_pad, r, cg),
+            return (ops.pack_conv_weight(conv.weight.to(dev), cin_pad, cout_pad, r, cg, split=sp),
                     ops.pack_conv_bias(conv.bias.to(dev), cout_pad, r, cg))
 
         with torch.no_grad():
@@ -461,7 +495,7 @@ class GRL(nn.Module):
                 cw, cb = pconv(stage.conv, CP, CP)
                 stages.append(dict(blocks=blocks, conv_w=cw, conv_b=cb))
             plan = dict(
-                sched=sched, stages=stages,
+                sched=sched, stages=stages, split=sp,
                 ns_g=padv(self.norm_start.weight), ns_b=padv(self.norm_start.bias),
                 ne_g=padv(self.norm_end.weight), ne_b=padv(self.norm_end.bias),
                 first=pconv(self.conv_first, _pad32(self.in_channels), CP), after=pconv(self.conv_after_body, CP, CP),
@@ -484,7 +518,7 @@ class GRL(nn.Module):
                 plan["hr"], plan["last"] = pconv(self.conv_hr, 64, 64), pconv(self.conv_last, 64, out_p)
             else:
                 plan["last"] = pconv(self.conv_last, CP, out_p)
-        self._plan_cache = {key: plan}  # one geometry at a time keeps memory bounded
+        self._plan_cache = {key: plan}  # one geometry at a time keeps memory bounded (captured graphs hold their own plan)
         return plan
 
     # ---- forward -------------------------------------------------------------------------------
@@ -500,40 +534,33 @@ class GRL(nn.Module):
         return x
 
     def _cab(self, r, pk, B, H, W, CP):
-        """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output (bf16) and the
-        per-image squeeze-excite gate; the gate is applied inside the proj+norm1 epilogue."""
-        mid = torch.empty(B * H * W, pk["cab_mid"], dtype=ops.GEMM_DTYPE, device=r.device)  # pad channels zero-filled by the conv store
-        ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid)
-        raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=ops.GEMM_DTYPE)
+        """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output and the per-image squeeze-excite
+        gate; the gate is applied inside the proj+norm1 epilogue.  fast: fp16 intermediates; high: fp32 + split operands."""
+        hi = self.precision == "high"
+        sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
+        mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
+        ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=sp)
+        raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=dt, x_split=sp)
         gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])
         return raw, gate
 
-    def _block(self, r, pk, geo: BlockGeo, B, H, W):
-        C, CP = self.embed_dim, r.shape[1]
-        M = B * H * W
+    def _attention(self, qkv, anc, att, pk, geo: BlockGeo, B, H, W, lse=None):
+        """The three attention launches of a block on head planes: window (efficient.py:128-165), anchors -> stripe tokens
+        and stripe tokens -> anchors (:215-270).  ``att``: [M, (nh_w+nh_s)*32] output (fp16 or fp32)."""
+        C = self.embed_dim
         nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
         d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
         Ha, Wa = H // df, W // df
-        dev = r.device
-        # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
-        # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
-        if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
-            qkv = ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"])
-        else:
-            qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
-        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
-        att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
-        y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=torch.bfloat16, device=dev)
+        y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=ops.PLANE_DTYPE, device=att.device)
         ws, sh = geo.window, geo.window_shift
         TG = ops.TokenGrid
-        # window attention (mixed_attn_block_efficient.py:128-165)
+        ls = lse if lse is not None else (None, None, None)
         ops.attention(
             TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w, H, W, ws[0], ws[1], sh, sh),
             TG(qkv, 2 * nh_w, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
-            B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0, fixed_max=pk["fixed"],
-            ones_col=d_w if d_w < 32 else -1, head_dim=d_w,
+            B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0,
+            ones_col=d_w if d_w < 32 else -1, head_dim=d_w, k_one31=pk["one_w"], lazy_floor=pk["floor_w"], lse=ls[0],
         )
-        # anchored stripe attention (mixed_attn_block_efficient.py:215-270)
         s0 = 3 * nh_w
         st, ss = geo.stripe, geo.stripe_shift_size
         ast, ass = geo.anchor_stripe, geo.anchor_shift_size
@@ -544,9 +571,28 @@ class GRL(nn.Module):
         g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         oc = d_s if d_s < 32 else -1
         ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
-                      fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
-        ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s,
-                      table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=oc, head_dim=d_s)
+                      ones_col=oc, head_dim=d_s, k_one31=pk["one_s"], lazy_floor=pk["floor_a2w"], lse=ls[1])
+        ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s, table=pk["tab_w2a"],
+                      masked=geo.stripe_shift, ones_col=oc, head_dim=d_s, k_one31=pk["one_s"],
+                      lazy_floor=pk["floor_w2a"], lse=ls[2])
+        return y
+
+    def _block(self, r, pk, geo: BlockGeo, B, H, W):
+        C, CP = self.embed_dim, r.shape[1]
+        M = B * H * W
+        nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
+        dev = r.device
+        if self.precision == "high":
+            return self._block_high(r, pk, geo, B, H, W)
+        # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
+        # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
+        if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
+            qkv = ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"])
+        else:
+            qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
+        att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
+        self._attention(qkv, anc, att, pk, geo, B, H, W)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         if "proj_blob" in pk and "mlp_blob" in pk and H * W >= 128 and os.environ.get("GRL_FUSED_TAIL", "1") != "0":
             return ops.block_tail(att, r, cab, gate, H * W, pk["proj_blob"], pk["proj_b"], pk["n1_g"], pk["n1_b"], pk["mlp_blob"],
@@ -563,6 +609,26 @@ class GRL(nn.Module):
         return ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n2_g"],
                           ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1)
 
+    def _block_high(self, r, pk, geo: BlockGeo, B, H, W):
+        """precision='high': every linear / conv contraction on split operands (activation hi+lo staged in-kernel from fp32,
+        weights packed hi|hi|lo), fp32 intermediates, the row norms as separate launches.  Attention as in the fast path
+        (fp16 operands) with an fp32 output."""
+        C, CP = self.embed_dim, r.shape[1]
+        M = B * H * W
+        f32 = torch.float32
+        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3)
+        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(geo.df, H, W), planes=True,
+                         a_split=3)
+        att = torch.empty(M, (geo.nh_w + geo.nh_s) * 32, dtype=f32, device=r.device)
+        self._attention(qkv, anc, att, pk, geo, B, H, W)
+        cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
+        p1 = ops.linear(att, pk["proj_w"], pk["proj_b"], out_dtype=f32, a_split=3)
+        r1 = ops.layernorm_res(p1, r, pk["n1_g"], pk["n1_b"], C, res_scale=self.res_scale, add2=cab, add2_scale=gate,
+                               rows_per_image=H * W)
+        h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out_dtype=f32, a_split=3)
+        p2 = ops.linear(h, pk["fc2_w"], pk["fc2_b"], out_dtype=f32, a_split=3)
+        return ops.layernorm_res(p2, r1, pk["n2_g"], pk["n2_b"], C, res_scale=self.res_scale)
+
     def forward_features(self, f, plan, B, H, W):
         """grl.py:491-504 on the token matrix f [B*H*W, CP] (fp32) -> [B*H*W, CP]."""
         C = self.embed_dim
@@ -575,7 +641,7 @@ class GRL(nn.Module):
             for bi, pk in enumerate(st["blocks"]):
                 r = self._block(r, pk, plan["sched"][si][bi], B, H, W)
             # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
-            t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t)
+            t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t, x_split=plan["split"])
         return ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
 
     @staticmethod
@@ -606,7 +672,7 @@ class GRL(nn.Module):
                         r[g] = self._block(r[g], pk, plan["sched"][si][bi], Bg, H, W)
             for g in range(n):
                 with torch.cuda.stream(pool[g]):
-                    parts[g] = ops.conv3x3(r[g], st["conv_w"], st["conv_b"], Bg, H, W, resid=parts[g])
+                    parts[g] = ops.conv3x3(r[g], st["conv_w"], st["conv_b"], Bg, H, W, resid=parts[g], x_split=plan["split"])
         out = torch.empty_like(t)
         for g in range(n):
             with torch.cuda.stream(pool[g]):
@@ -629,7 +695,8 @@ class GRL(nn.Module):
     def enable_graph(self, flag: bool = True):
         """Replay the whole forward as one captured HIP graph per input shape.  A forward is ~500
         kernel launches; at one 256x256 tile the eager path is bound by the host issuing them, the graph is not.
-        Weights must not change while graphs are cached (call ``enable_graph(False)`` / ``enable_graph()`` to drop them).
+        Every cached graph owns the plan (packed weights / tables) it was captured with; ``load_state_dict`` and in-place
+        parameter updates drop the graphs (post-hook / version stamp).
         """
         self._use_graph = bool(flag)
         self._graphs = {}
@@ -642,7 +709,11 @@ class GRL(nn.Module):
         if not (self._use_graph and x.is_cuda) or ops.profiling():
             return self._forward_eager(x)
         key = (tuple(x.shape), x.dtype, str(x.device))
+        stamp = self._param_stamp()
         ent = self._graphs.get(key)
+        if ent is not None and ent[4] != stamp:            # parameters changed in place since the capture
+            self.invalidate_plan()
+            ent = None
         if ent is None:
             with torch.no_grad():
                 self._forward_eager(x)                     # builds the plan, warms the allocator and kernel attributes
@@ -651,8 +722,10 @@ class GRL(nn.Module):
                 graph = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph):
                     static_out = self._forward_eager(static_in)
-            ent = self._graphs[key] = (static_in, graph, static_out)
-        static_in, graph, static_out = ent
+            # the captured kernels point at the packed weights / tables of THIS shape's plan: the entry keeps them alive
+            # (the plan cache itself holds one geometry at a time)
+            ent = self._graphs[key] = (static_in, graph, static_out, next(iter(self._plan_cache.values())), stamp)
+        static_in, graph, static_out = ent[:3]
         static_in.copy_(x)
         graph.replay()
         return static_out.clone()                          # the engine clamps its output in place (utils_image.py:31)
@@ -673,10 +746,15 @@ class GRL(nn.Module):
         B, _, H, W = x.shape
         s, oc = self.upscale, self.out_channels
         plan = self._plan((H, W), x.device)
-        conv = ops.conv3x3
-        bf = ops.GEMM_DTYPE  # 16-bit intermediates of the tail feed fp16-operand convolutions
+        sp = plan["split"]
 
-        f = conv(self._tokens(x, plan["first"][0].shape[2]), *plan["first"], B, H, W)           # conv_first
+        def conv(*a, **kw):
+            return ops.conv3x3(*a, x_split=sp, **kw)
+
+        # fast: 16-bit intermediates of the tail feed fp16-operand convolutions; high: fp32 + split operands
+        bf = torch.float32 if sp == 3 else ops.GEMM_DTYPE
+
+        f = conv(self._tokens(x, plan["first"][0].shape[2] // sp), *plan["first"], B, H, W)           # conv_first
         body = conv(self.forward_features(f, plan, B, H, W), *plan["after"], B, H, W, resid=f)  # conv_after_body + f
         if self.upsampler == "pixelshuffle":
             y = conv(body, *plan["cbu"], B, H, W, act=2, slope=0.01, out_dtype=bf)

@@ -13,7 +13,17 @@ import torch
 from . import _lib as L
 
 GEMM_DTYPE = torch.float16  # operand / intermediate type of the linear and conv kernels (csrc/common.h: gemm_t)
-_KIND = {torch.float32: L.DT_F32, torch.bfloat16: L.DT_BF16, torch.float16: L.DT_F16}
+PLANE_DTYPE = torch.float16  # q / k / v / anchor head planes (attention operands)
+_KIND = {torch.float32: L.DT_F32, torch.float16: L.DT_F16}
+
+
+def split3_weight(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [N, K] -> fp16 [N, 3K] = [hi | hi | lo] (hi = fp16(w), lo = fp16(w - hi)): the weight side of the
+    split-precision operands (``a_split`` / ``x_split`` = 3; the kernels stage activations as [hi | lo | hi])."""
+    w = w.detach().float()
+    hi = w.to(GEMM_DTYPE)
+    lo = (w - hi.float()).to(GEMM_DTYPE)
+    return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
 
 # ---- optional per-kernel timing with HIP events on the launching stream (used by bench.py) ----
@@ -91,9 +101,12 @@ def linear(
     pool: Optional[Tuple[int, int, int]] = None,
     M: Optional[int] = None,
     planes: bool = False,
+    a_split: int = 1,
 ) -> torch.Tensor:
-    """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/bf16, row
-    stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first."""
+    """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
+    stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
+    ``a_split=3``: split-precision operands -- ``w`` is packed by ``split3_weight`` ([hi | hi | lo], Kpad = 3 x the
+    source width) and the kernel stages the fp32 ``a`` as [hi | lo | hi]."""
     _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale)
     if add2 is not None:
         assert add2.dtype == GEMM_DTYPE and add2_scale is not None and rows_per_image > 0
@@ -101,7 +114,8 @@ def linear(
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == GEMM_DTYPE
     assert a.dtype in (torch.float32, GEMM_DTYPE) and bias.dtype == torch.float32
     Npad, Kpad = w.shape
-    assert a.shape[1] >= Kpad and bias.numel() == Npad
+    assert a_split in (1, 3) and a.shape[1] >= Kpad // a_split and bias.numel() == Npad
+    assert a_split == 1 or (a.dtype == torch.float32 and Kpad % 96 == 0)
     if pool is not None:
         df, H, W = pool
         assert a.dtype == torch.float32 and a.shape[0] % (H * W) == 0
@@ -111,10 +125,10 @@ def linear(
         rows = a.shape[0]
     M = rows if M is None else M
     if planes:
-        # head-plane layout [Npad/32, M, 32] (bf16): what the attention kernel stages fastest
+        # head-plane layout [Npad/32, M, 32] (fp16): what the attention kernel stages fastest
         if out is None:
-            out = torch.empty(Npad // 32, M, 32, dtype=torch.bfloat16, device=a.device)
-        assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (Npad // 32, M, 32)
+            out = torch.empty(Npad // 32, M, 32, dtype=PLANE_DTYPE, device=a.device)
+        assert out.dtype == PLANE_DTYPE and out.is_contiguous() and out.shape == (Npad // 32, M, 32)
         ldo, plane_stride = 32, M * 32
     else:
         if out is None:
@@ -129,7 +143,7 @@ def linear(
         res_scale=res_scale, resid=_ptr(resid), ldr=resid.stride(0) if resid is not None else 0,
         add2=_ptr(add2), add2_dtype=_KIND[add2.dtype] if add2 is not None else 0,
         ldadd2=add2.stride(0) if add2 is not None else 0,
-        add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image,
+        add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split,
         out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
     )
     if epi == L.EPI_GROUPNORM:
@@ -206,13 +220,13 @@ def pack_qkv(w: torch.Tensor, bias: torch.Tensor, gscale: torch.Tensor) -> torch
 
 
 def qkv(x: torch.Tensor, blob: torch.Tensor, nslots: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """Head planes [nslots, M, 32] (bf16) of the slotted, normalised QKV projection of x [M, Cpad] (fp32)."""
+    """Head planes [nslots, M, 32] (fp16) of the slotted, normalised QKV projection of x [M, Cpad] (fp32)."""
     _dev_check(x, blob, out)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and blob.dtype == torch.uint8 and blob.is_contiguous()
     M, Cpad = x.shape
     if out is None:
-        out = torch.empty(nslots, M, 32, dtype=torch.bfloat16, device=x.device)
-    assert out.dtype == torch.bfloat16 and out.is_contiguous() and out.shape == (nslots, M, 32)
+        out = torch.empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
+    assert out.dtype == PLANE_DTYPE and out.is_contiguous() and out.shape == (nslots, M, 32)
     args = L.GrlQkvArgs(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), M=M, Cpad=Cpad, nslots=nslots, out=_ptr(out),
                         out_plane_stride=M * 32)
     with _timed("qkv"):
@@ -276,7 +290,7 @@ def mlp(x: torch.Tensor, blob: torch.Tensor, b2: torch.Tensor, ln_g: torch.Tenso
 
 @dataclass
 class TokenGrid:
-    """A bf16 token tensor viewed as windows: mirrors GrlTokenGrid.
+    """An fp16 token tensor (the output grid may be fp32) viewed as windows: mirrors GrlTokenGrid.
 
     ``t`` is either a token-major matrix [tokens, heads*32 (+...)] (``slot`` = first 32-wide column
     group of head 0) or a stack of head planes [slots, tokens, 32] (``slot`` = plane of head 0)."""
@@ -292,10 +306,10 @@ class TokenGrid:
 
     def c(self) -> L.GrlTokenGrid:
         t = self.t
-        assert t.dtype in (torch.bfloat16, torch.float16) and t.stride(-1) == 1
+        assert t.dtype in (torch.float16, torch.float32) and t.stride(-1) == 1
         if t.dim() == 3:  # head planes
             assert t.shape[2] == 32 and t.is_contiguous()
-            return L.GrlTokenGrid(ptr=C.c_void_p(t.data_ptr() + self.slot * t.stride(0) * 2), ld=32, hstride=t.stride(0),
+            return L.GrlTokenGrid(ptr=C.c_void_p(t.data_ptr() + self.slot * t.stride(0) * t.element_size()), ld=32, hstride=t.stride(0),
                                   col0=0, Himg=self.Himg, Wimg=self.Wimg, wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx)
         assert t.dim() == 2
         return L.GrlTokenGrid(ptr=_ptr(t), ld=t.stride(0), hstride=32, col0=self.slot * 32, Himg=self.Himg, Wimg=self.Wimg,
@@ -307,16 +321,24 @@ class TokenGrid:
 
 
 def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int, nh: int, table: torch.Tensor,
-              masked: bool, fixed_max: bool, ones_col: int, head_dim: int):
+              masked: bool, ones_col: int, head_dim: int, k_one31: bool = False,
+              lazy_floor: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
     """softmax(q k^T + bias(+mask)) v over every window of every image; see grl_attention_fwd.
-    ``table``: (nh, rows padded to 4) from tables.kernel_table (reversed rows)."""
-    _dev_check(q.t, k.t, v.t, o.t, table)
+    ``table``: (nh, rows padded to 4) from tables.kernel_table (reversed rows); ``k_one31`` / ``lazy_floor``: the
+    softmax-offset contract of include/grl_hip.h; ``lse`` (nh, tokens) fp32 optional output."""
+    _dev_check(q.t, k.t, v.t, o.t, table, lazy_floor, lse)
     assert table.dtype == torch.float32 and table.is_contiguous() and table.dim() == 2 and table.shape[0] == nh
+    assert q.t.dtype == PLANE_DTYPE and k.t.dtype == PLANE_DTYPE and v.t.dtype == PLANE_DTYPE
     nwy, nwx = q.Himg // q.wh, q.Wimg // q.ww
     assert q.tokens >= B * q.Himg * q.Wimg and k.tokens >= B * k.Himg * k.Wimg
+    if lazy_floor is not None:
+        assert lazy_floor.dtype == torch.float32 and lazy_floor.is_contiguous() and lazy_floor.numel() == nh
+    if lse is not None:
+        assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape[0] == nh and lse.shape[1] >= q.tokens
     args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
-                         trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), fixed_max=int(fixed_max), ones_col=ones_col,
-                         head_dim=head_dim, out_dtype=_KIND[o.t.dtype])
+                         trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), ones_col=ones_col,
+                         head_dim=head_dim, out_dtype=_KIND[o.t.dtype], k_one31=int(k_one31), lazy_floor=_ptr(lazy_floor),
+                         lse=_ptr(lse), lse_stride=lse.stride(0) if lse is not None else 0)
     with _timed("attention"):
         L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
     return o.t
@@ -336,10 +358,31 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: 
     return out
 
 
-def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: int = 0, shuffle_cg: int = 0) -> torch.Tensor:
+def layernorm_res(x: torch.Tensor, resid: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: int, *,
+                  eps: float = 1e-5, res_scale: float = 1.0, add2: Optional[torch.Tensor] = None,
+                  add2_scale: Optional[torch.Tensor] = None, rows_per_image: int = 0) -> torch.Tensor:
+    """resid + res_scale * LayerNorm(x) (+ add2 * add2_scale[image]) on fp32 token matrices (grl_layernorm_res_fwd)."""
+    _dev_check(x, resid, gamma, beta, add2, add2_scale)
+    assert x.dim() == 2 and x.dtype == torch.float32 and resid.dtype == torch.float32 and x.stride(1) == 1 and resid.stride(1) == 1
+    n_pad = gamma.numel()
+    assert x.shape[1] >= n_pad and resid.shape[1] >= n_pad and beta.numel() == n_pad
+    out = torch.empty(x.shape[0], n_pad, dtype=torch.float32, device=x.device)
+    args = L.GrlLnResArgs(x=_ptr(x), ldx=x.stride(0), resid=_ptr(resid), ldr=resid.stride(0), gamma=_ptr(gamma), beta=_ptr(beta),
+                          add2=_ptr(add2), add2_dtype=_KIND[add2.dtype] if add2 is not None else 0,
+                          ldadd2=add2.stride(0) if add2 is not None else 0, add2_scale=_ptr(add2_scale),
+                          rows_per_image=rows_per_image, M=x.shape[0], n_real=n_real, n_pad=n_pad, eps=eps, res_scale=res_scale,
+                          y=_ptr(out), ldy=out.stride(0))
+    with _timed("layernorm_res"):
+        L.check(L.lib().grl_layernorm_res_fwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_res_fwd")
+    return out
+
+
+def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: int = 0, shuffle_cg: int = 0,
+                     split: int = 1) -> torch.Tensor:
     """torch conv weight [Cout, Cin, 3, 3] -> fp16 [9, cout_pad, cin_pad] (tap = ky*3+kx, K contiguous).
     With ``shuffle_r`` the output channels are re-ordered from PixelShuffle's (c, i, j) to (i, j, c) with
-    ``shuffle_cg`` (>= c, multiple of 4) slots per sub-pixel so the kernel can store whole channel groups."""
+    ``shuffle_cg`` (>= c, multiple of 4) slots per sub-pixel so the kernel can store whole channel groups.
+    ``split=3``: [9, cout_pad, 3*cin_pad] = [hi | hi | lo] along K (split-precision operands, ``x_split=3``)."""
     cout, cin = w.shape[:2]
     w9 = w.detach().float().permute(2, 3, 0, 1).reshape(9, cout, cin)
     out = torch.zeros(9, cout_pad, cin_pad, dtype=torch.float32, device=w.device)
@@ -350,6 +393,8 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: in
         out.view(9, cout_pad // shuffle_cg, shuffle_cg, cin_pad)[:, :r2, :c, :cin] = src
     else:
         out[:, :cout, :cin] = w9
+    if split == 3:
+        return split3_weight(out)
     return out.to(GEMM_DTYPE).contiguous()
 
 
@@ -366,14 +411,16 @@ def pack_conv_bias(b: torch.Tensor, cout_pad: int, shuffle_r: int = 0, shuffle_c
 
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int, *, act: int = 0,
             slope: float = 0.0, resid: Optional[torch.Tensor] = None, want_pool: bool = False,
-            out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0):
+            out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0,
+            x_split: int = 1):
     """3x3 conv (stride 1, pad 1) on a channels-last token matrix x[B*H*W, >=CinP]; w packed by
     pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool)."""
     _dev_check(x, w, bias, resid, out)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, GEMM_DTYPE)
     assert w.dtype == GEMM_DTYPE and w.is_contiguous() and w.dim() == 3 and w.shape[0] == 9
     CoutP, CinP = w.shape[1], w.shape[2]
-    assert x.shape[0] >= B * H * W and x.shape[1] >= CinP and bias.numel() == CoutP
+    assert x_split in (1, 3) and x.shape[0] >= B * H * W and x.shape[1] >= CinP // x_split and bias.numel() == CoutP
+    assert x_split == 1 or x.dtype == torch.float32
     if shuffle_r > 1:
         rows, cols = B * H * W * shuffle_r * shuffle_r, shuffle_cg
     else:
@@ -390,7 +437,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     # Short-K layers (CAB conv2: 64 -> 192 channels, 9 tap steps in all) are epilogue/store dominated with one 104 KB-LDS
     # workgroup per CU; two launches of 96 output channels run two workgroups per CU whose store and MFMA phases
     # overlap (137 -> 101 us per 4 tiles).  Long-K layers (stage convs) lose from the split.  GRL_CONV_SPLIT overrides.
-    split = int(os.environ.get("GRL_CONV_SPLIT", "96" if CinP <= 64 else "0"))
+    split = int(os.environ.get("GRL_CONV_SPLIT", "96" if CinP <= 64 and x_split == 1 else "0"))
     if split and CoutP > split and CoutP % split == 0 and shuffle_r <= 1:
         step = split
     elif CoutP > 192:
@@ -400,7 +447,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             x=_ptr(x), x_dtype=_KIND[x.dtype], ldx=x.stride(0),
             w=C.c_void_p(w.data_ptr() + c0 * CinP * 2), w_tap_stride=CoutP * CinP,
             bias=C.c_void_p(bias.data_ptr() + c0 * 4),
-            B=B, H=H, W=W, CinP=CinP, CoutP=step, act=act, slope=slope,
+            B=B, H=H, W=W, CinP=CinP, CoutP=step, x_split=x_split, act=act, slope=slope,
             resid=C.c_void_p(resid.data_ptr() + c0 * 4) if resid is not None else C.c_void_p(0),
             ldr=resid.stride(0) if resid is not None else 0,
             pool_partial=C.c_void_p(pool.data_ptr() + c0 * 4) if pool is not None else C.c_void_p(0), pool_stride=CoutP,

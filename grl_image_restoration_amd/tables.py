@@ -43,23 +43,17 @@ def bias_rows(cpb0_w, cpb0_b, cpb2_w, coords: torch.Tensor) -> torch.Tensor:
     return 16.0 * torch.sigmoid(F.linear(h, cpb2_w.detach().float()))
 
 
-def kernel_table(bias: torch.Tensor, scale: torch.Tensor, fixed_max: bool) -> torch.Tensor:
+def kernel_table(bias: torch.Tensor) -> torch.Tensor:
     """(rows, nh) natural-log-domain bias -> (nh, rows4) table in the kernel's exp2 domain, stored
-    REVERSED along rows (entry rows-1-i = row i) and zero-padded to a multiple of 4 floats per head.
-    With ``fixed_max`` the per-head bound scale_h + max(bias_h) >= every logit is subtracted, so
-    exp2(acc) <= 1 without tracking a running maximum."""
-    t = bias.t().contiguous() * LOG2E
-    if fixed_max:
-        bound = (scale + bias.max(dim=0).values) * LOG2E
-        t = t - bound[:, None]
-    t = torch.flip(t, dims=(1,))
+    REVERSED along rows (entry rows-1-i = row i) and zero-padded to a multiple of 4 floats per head."""
+    t = torch.flip(bias.t().contiguous() * LOG2E, dims=(1,))
     pad = (-t.shape[1]) % 4
     if pad:
         t = torch.nn.functional.pad(t, (0, pad))
     return t.contiguous()
 
 
-def fixed_max_is_safe(scale: torch.Tensor, limit: float = 60.0) -> bool:
-    """The bound is at most 2*scale + 16 above the smallest unmasked logit of a row; keep the
-    largest softmax numerator of every row far above fp32/bf16 underflow."""
-    return bool((2.0 * scale + 16.0).max().item() <= limit)
+def lazy_floor(scale: torch.Tensor) -> torch.Tensor:
+    """Integer-valued lower bound (log2 domain) of every unmasked logit ``scale*cos + bias`` of a head
+    (|cos| <= 1, bias >= 0): the start value of the attention kernel's running softmax offset."""
+    return (-torch.ceil(scale * LOG2E) - 1.0).float().contiguous()

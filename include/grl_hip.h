@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 9
+#define GRL_ABI_VERSION 10
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -47,8 +47,10 @@ typedef struct GrlLinearArgs {
     const float* bias;      /* [Npad]                                                               */
     int32_t M, Npad, Kpad;
     int32_t epi;            /* GRL_EPI_*                                                            */
-    const float* gscale;    /* GROUPNORM: [Npad/32]; g!=0: L2-normalise the 32-col group, times g;  */
-                            /*            g==0: pass through                                        */
+    const float* gscale;    /* GROUPNORM: [Npad/32]; g!=0: L2-normalise the 32-col group, times |g|;*/
+                            /*            g==0: pass through; g<0: additionally write 1.0 into      */
+                            /*            column 31 of the group (spare head-dim slot of a K plane: */
+                            /*            carries the attention kernel's running softmax offset)    */
     const float* ln_g;      /* LN_RES: gamma/beta [Npad], n_real real channels, eps, residual scale */
     const float* ln_b;
     int32_t n_real;
@@ -61,7 +63,11 @@ typedef struct GrlLinearArgs {
     int64_t ldadd2;
     const float* add2_scale; /* [B, Npad] per-image channel scale applied to add2 (SE gate)           */
     int32_t rows_per_image;  /*          image of row m = m / rows_per_image                          */
-    void* out;              /* [M, ldo]: GRL_DT_F32, GRL_DT_BF16 (attention operands) or GRL_DT_F16  */
+    int32_t a_split;        /* 1 (default, 0 means 1) or 3: split-precision operands.  With 3, Kpad = 3 * Ksrc  */
+                            /* and the kernel stages A (fp32) as [hi(a) | lo(a) | hi(a)], hi = fp16(a),         */
+                            /* lo = fp16(a - hi); the caller packs W as [hi(w) | hi(w) | lo(w)]: the product    */
+                            /* carries ~22 mantissa bits at 3x the MFMA work (small, error-amplifying models)   */
+    void* out;              /* [M, ldo]: GRL_DT_F32 or GRL_DT_F16 (attention operands, planes)       */
     int32_t out_dtype;
     int64_t ldo;
     int64_t out_plane_stride; /* >0: write 32-column groups as planes: element (m, c) goes to          */
@@ -143,21 +149,22 @@ int grl_block_tail_fwd(void* stream, const GrlTailArgs* args);
 int64_t grl_proj_blob_bytes(int32_t Cpad);
 
 /* ---------------------------------------------------------------------------------------------
- * Streaming QKV projection: head planes out[slot][m][0..31] (bf16) = groupnorm(x[m,:] . W_slot^T + b_slot),
+ * Streaming QKV projection: head planes out[slot][m][0..31] (fp16) = groupnorm(x[m,:] . W_slot^T + b_slot),
  * one pass over x for any number of slots (the weights-resident grl_linear_fwd needs column slabs above 160 KB).
  *   replaces  QKVProjection.forward   models/common/mixed_attn_block.py:669-676
  *             F.normalize + logit scale of Attention.attn   models/common/mixed_attn_block_efficient.py:39,85-90
  * A slot = 32 output columns (one head of q, k or v; see grl_attention_fwd).  Weight stream ("blob"): chunks of
  * 2 slots (1 if nslots is odd), each slot image = 32 rows x (2*Cpad + 16) bytes fp16 (columns in the k-slot order
  * of GrlMlpArgs, 16 pad bytes per row) | bias 32 fp32 | gscale fp32 + 12 pad bytes; chunk padded to 1024 bytes.
- * gscale as in GRL_EPI_GROUPNORM: != 0 -> L2-normalise the slot and multiply, == 0 -> pass through.
+ * gscale as in GRL_EPI_GROUPNORM: != 0 -> L2-normalise the slot and multiply by |gscale|, == 0 -> pass through,
+ * < 0 -> additionally column 31 of the slot is written as 1.0 (K planes, see grl_attention_fwd).
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlQkvArgs {
     const float* x;            /* [M, ldx] fp32 tokens                                               */
     int64_t ldx;
     const void* blob;          /* see above; 16-B aligned; grl_qkv_blob_bytes(Cpad, nslots) bytes    */
     int32_t M, Cpad, nslots;   /* Cpad in {64, 128, 192}                                             */
-    void* out;                 /* bf16 planes: element (m, slot, c) at slot*out_plane_stride + m*32 + c */
+    void* out;                 /* fp16 planes: element (m, slot, c) at slot*out_plane_stride + m*32 + c */
     int64_t out_plane_stride;  /* >= M*32                                                            */
 } GrlQkvArgs;
 
@@ -172,14 +179,18 @@ int64_t grl_qkv_blob_bytes(int32_t Cpad, int32_t nslots);
  *             Attention.attn / AffineTransform  :77-94 / :36-58
  *             roll / window_partition / window_reverse / masks / relative index
  *                                            models/common/ops.py:36-157,352-375 (all as index math)
- * Operands are bf16 token tensors with one 32-wide slot per head (fp32 accumulation); the linear
- * and convolution kernels use fp16 operands (same MFMA rate, 8x finer mantissa):
+ * Operands are fp16 token tensors with one 32-wide slot per head (fp32 accumulation):
  *   q: already L2-normalised and multiplied by logit_scale*log2(e); k: L2-normalised;
  *   v: raw values, slot column `ones_col` (>= head_dim) holding 1.0 so that the row sum of the
  *      softmax weights falls out of the PV product (ones_col < 0: summed explicitly).
+ * Softmax offset (keeps the fp16 weights in range for ANY logit scale up to the clamp exp(ln 100)): a running offset that
+ * follows the row maximum.  32-aligned geometries evaluate it lazily (only when a weight reaches 2^14) and keep it in
+ * head-dim slot 31 of q: K must then hold 1.0 in slot 31 (`k_one31`, head_dim <= 30) and `lazy_floor[head]` (an integer
+ * valued lower bound of every unmasked logit, log2 domain) must be given; otherwise the generic kernel runs an ordinary
+ * online softmax.
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlTokenGrid {
-    const void* ptr;      /* bf16 base                                                              */
+    const void* ptr;      /* fp16 base (o: fp16 or fp32 per out_dtype)                              */
     int64_t ld;           /* elements between consecutive tokens                                    */
     int64_t hstride;      /* elements between the 32-wide slots of consecutive heads: 32 for a      */
                           /* token-major matrix [tokens, heads*32]; tokens*32 for head planes       */
@@ -195,16 +206,19 @@ typedef struct GrlAttnArgs {
     GrlTokenGrid q, k, v, o; /* v shares k's grid geometry; o shares q's                            */
     int32_t B, nh;
     int32_t nwy, nwx;        /* windows per image (same on both grids)                              */
-    const float* table;      /* [nh, tstride] fp32: bias*log2e (minus the per-head bound if fixed_max),*/
+    const float* table;      /* [nh, tstride] fp32: bias*log2e,                                     */
                              /* stored REVERSED: entry trows-1-i is row i of the reference's         */
                              /* relative-position table (keys then read ascending addresses)         */
     int32_t trows;           /* (q.wh + k.wh - 1) * (q.ww + k.ww - 1)                               */
     int32_t tstride;         /* floats between heads: trows rounded up to a multiple of 4           */
     int32_t masked;          /* 1: apply the shifted-window region mask (-100)                      */
-    int32_t fixed_max;       /* 1: table carries -(bound); no running max needed                    */
     int32_t ones_col;        /* see above                                                           */
     int32_t head_dim;        /* real head dim (<= 32)                                               */
-    int32_t out_dtype;       /* GRL_DT_BF16 (feeds another attention) or GRL_DT_F16 (feeds the proj)*/
+    int32_t out_dtype;       /* GRL_DT_F16 or GRL_DT_F32                                            */
+    int32_t k_one31;         /* 1: every K row holds 1.0 in head-dim slot 31 (lazy offset possible) */
+    const float* lazy_floor; /* [nh] see above (may be NULL: generic kernel)                        */
+    float* lse;              /* optional [nh][lse_stride] fp32: log2-sum-exp2 of the kernel-domain  */
+    int64_t lse_stride;      /* logits per query token row (what the backward kernel re-normalises with) */
 } GrlAttnArgs;
 
 int grl_attention_fwd(void* stream, const GrlAttnArgs* args);
@@ -226,6 +240,8 @@ typedef struct GrlConvArgs {
     const float* bias;      /* [CoutP]                                                              */
     int32_t B, H, W;
     int32_t CinP, CoutP;    /* CinP % 32 == 0, CoutP % 16 == 0, CoutP <= 192 per call               */
+    int32_t x_split;        /* 1 (0 means 1) or 3: split-precision operands as in GrlLinearArgs.a_split: CinP =     */
+                            /* 3 * CinSrc, x (fp32, CinSrc wide) is staged as [hi | lo | hi], w packed [hi | hi | lo] */
     int32_t act;            /* 0 none, 1 exact GELU, 2 LeakyReLU(slope)                             */
     float slope;
     const float* resid;     /* optional fp32 [B*H*W, ldr] added after the activation                */
@@ -258,6 +274,29 @@ int grl_se_scale_fwd(void* stream, const float* pool_partial, int32_t B, int32_t
  * ------------------------------------------------------------------------------------------- */
 int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, float* y, int64_t ldy, const float* gamma,
                       const float* beta, int32_t M, int32_t n_real, int32_t n_pad, float eps);
+
+/* y = resid + res_scale * LayerNorm(x) (+ add2 * add2_scale[image]): the un-fused form of GRL_EPI_LN_RES
+ *   replaces  norm1 / norm2 + residual (+ CAB branch)   models/common/mixed_attn_block_efficient.py:543-556
+ * used by the split-precision path, whose slab-split projections cannot carry the row norm in their epilogue. */
+typedef struct GrlLnResArgs {
+    const float* x;         /* [M, ldx] fp32 projection output                                       */
+    int64_t ldx;
+    const float* resid;     /* [M, ldr] fp32                                                         */
+    int64_t ldr;
+    const float* gamma;     /* [n_pad]                                                               */
+    const float* beta;
+    const void* add2;       /* optional [M, ldadd2] GRL_DT_F32 or GRL_DT_F16, times add2_scale[image][n_pad] */
+    int32_t add2_dtype;
+    int64_t ldadd2;
+    const float* add2_scale;
+    int32_t rows_per_image;
+    int32_t M, n_real, n_pad; /* n_pad <= 256, multiple of 4; pad channels written as 0              */
+    float eps, res_scale;
+    float* y;               /* [M, ldy] fp32                                                         */
+    int64_t ldy;
+} GrlLnResArgs;
+
+int grl_layernorm_res_fwd(void* stream, const GrlLnResArgs* args);
 
 /* Library self-description (used by the loader to refuse a stale build). */
 int grl_abi_version(void);

@@ -474,14 +474,16 @@ def synthetic_pair(task: str, hw: Tuple[int, int], scale: int = 1, batch: int = 
     return lq.contiguous(), gt.contiguous()
 
 
-def seeded_state_dict(shapes: Dict[str, Sequence[int]], seed: int = 0) -> Dict[str, Tensor]:
+def seeded_state_dict(shapes: Dict[str, Sequence[int]], seed: int = 0, logit_scale_mean: float = math.log(10.0)) -> Dict[str, Tensor]:
     """Deterministic, init-order-independent parameters for a GRL of the given key->shape map.
 
     Every key gets its own generator (seed mixed with crc32 of the key) so the reference module
     (build container) and the product module (GPU box) obtain bit-identical weights without
     either depending on the other's construction order.  Distributions mimic a trained net
     closely enough to exercise every path: Linear/conv weights ~ U(-1/sqrt(fan_in), ..),
-    LayerNorm gamma ~ 1 + 0.1 N, biases ~ 0.02 N, logit_scale ~ ln 10 + 0.3 N.
+    LayerNorm gamma ~ 1 + 0.1 N, biases ~ 0.02 N, logit_scale ~ ``logit_scale_mean`` (ln 10 = the
+    init value) + 0.3 N; ``logit_scale_mean = ln 100`` puts about half of the heads above the clamp
+    of mixed_attn_block_efficient.py:39 (what a trained Swin-V2-style checkpoint looks like).
     Buffer keys (table_/index_/mask_) are skipped.
     """
     import zlib
@@ -493,7 +495,7 @@ def seeded_state_dict(shapes: Dict[str, Sequence[int]], seed: int = 0) -> Dict[s
         shp = tuple(shapes[k])
         g = torch.Generator().manual_seed((seed * 1000003 + zlib.crc32(k.encode())) % (2**31 - 1))
         if k.endswith("logit_scale"):
-            v = math.log(10.0) + 0.3 * torch.randn(shp, generator=g)
+            v = logit_scale_mean + 0.3 * torch.randn(shp, generator=g)
         elif (".norm" in k or k.startswith("norm_")) and k.endswith("weight"):
             v = 1.0 + 0.1 * torch.randn(shp, generator=g)
         elif k.endswith("bias"):

@@ -131,15 +131,15 @@ def test_ctypes_layout_matches_the_c_header(tmp_path):
             assert int(out[f"{name}.{f[0]}"]) == getattr(st, f[0]).offset, (name, f[0])
 
 
-def test_fixed_max_policy_and_table():
-    scale = torch.tensor([10.0, 20.0])
-    assert tables.fixed_max_is_safe(scale)
-    assert not tables.fixed_max_is_safe(torch.tensor([10.0, 100.0]))
+def test_softmax_offset_tables():
+    """Kernel table = reversed bias rows in the log2 domain; lazy floor = an integer below every logit, exact in fp16."""
+    scale = torch.tensor([10.0, 100.0])
     bias = torch.rand(50, 2) * 16
-    t = tables.kernel_table(bias, scale, True)
-    assert t.shape == (2, 52) and t.max().item() <= 1e-4 and torch.equal(t[:, 50:], torch.zeros(2, 2))
-    t0 = tables.kernel_table(bias, scale, False)
+    t0 = tables.kernel_table(bias)
+    assert t0.shape == (2, 52) and torch.equal(t0[:, 50:], torch.zeros(2, 2))
     assert torch.allclose(torch.flip(t0[:, :50], dims=(1,)), bias.t() * tables.LOG2E)
+    fl = tables.lazy_floor(scale)
+    assert torch.equal(fl, torch.round(fl)) and (fl <= -scale * tables.LOG2E).all() and fl.abs().max() < 2048
 
 
 def test_ctypes_structs_refuse_unknown_fields():

@@ -13,18 +13,20 @@ import torch
 from oracle import engine_oracle as E
 from oracle import grl_oracle as O
 from oracle import refshim
-from tests.util import golden_names, load_golden, product_shapes
+from tests.util import golden_names, golden_state_dict, load_golden, product_shapes
 
 needs_ref = pytest.mark.skipif(not refshim.reference_available(), reason="reference tree not mounted")
 
-FAST = ["tiny_sr2_ckpt_64", "tiny_sr2_yaml_64", "base_sr4_yaml_32", "base_deblur_ragged"]
+# the fixtures the oracle re-runs in seconds; the large ones (256x256 bench tiles, 384x384 deblur tiles: minutes of CPU)
+# carry their oracle-vs-reference agreement in their metadata (checked below) and are exercised by the GPU tests
+FAST = ["tiny_sr2_ckpt_64", "tiny_sr2_yaml_64", "base_sr4_yaml_32", "base_deblur_ragged", "tiny_sr2_ckpt_64_hiscale"]
 
 
 @pytest.mark.parametrize("name", FAST)
 def test_oracle_reproduces_golden(name):
     meta, z = load_golden(name)
     cfg = meta["cfg"]
-    sd = O.seeded_state_dict(product_shapes(cfg), meta["weight_seed"])
+    sd = golden_state_dict(meta)
     with torch.no_grad():
         y = O.grl_forward(z["input"], cfg, sd)
     assert y.shape == z["output"].shape
@@ -32,7 +34,8 @@ def test_oracle_reproduces_golden(name):
 
 
 def test_golden_set_complete():
-    assert set(golden_names()) >= {"tiny_sr2_ckpt_64", "small_dn_128", "base_sr4_ckpt_64", "base_deblur_ragged"}
+    assert set(golden_names()) >= {"tiny_sr2_ckpt_64", "small_dn_128", "base_sr4_ckpt_64", "base_deblur_ragged",
+                                   "base_sr4_ckpt_64_hiscale", "tiny_sr2_ckpt_64_hiscale", "base_sr4_ckpt_256", "base_deblur_384"}
     for n in golden_names():
         meta, _ = load_golden(n)
         assert meta["oracle_vs_reference_maxabs"] < 5e-6

@@ -15,9 +15,20 @@ def golden_names():
 
 
 def load_golden(name):
+    """(meta, tensors).  Fixtures with a 16-bit fixed-point output (oracle/make_golden.py: the 256x256 bench tiles) come back
+    with ``output`` = tile 0 de-quantised (|error| <= q_step / 2 <= 1.5e-5) and ``output_b1_sub`` = tile 1, strided."""
     z = np.load(os.path.join(GOLDEN_DIR, name + ".npz"), allow_pickle=False)
     meta = json.loads(str(z["meta"]))
-    return meta, {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+    out = {k: torch.from_numpy(z[k]) for k in z.files if k not in ("meta", "output_q", "q_lo", "q_step")}
+    if "output_q" in z.files:
+        out["output"] = (torch.from_numpy(z["output_q"].astype(np.int32)).double() * float(z["q_step"]) + float(z["q_lo"])).float()
+        meta["q_step"] = float(z["q_step"])
+    return meta, out
+
+
+def golden_state_dict(meta):
+    """The seeded weights a fixture was generated with (reproducible anywhere: grl_oracle.seeded_state_dict)."""
+    return O.seeded_state_dict(product_shapes(meta["cfg"]), meta["weight_seed"], **meta.get("sd_kwargs", {}))
 
 
 def product_shapes(cfg):

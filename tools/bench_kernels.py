@@ -22,11 +22,18 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--only", type=str, default="")
     ap.add_argument("--block", type=int, default=2, help="block index in stage 0 (2: window+stripe shift)")
+    ap.add_argument("--logit-scale", type=float, default=0.0, help="set every logit scale to this value (100 = the clamp)")
     a = ap.parse_args()
     cfg = baseline_config(3)
     cfg.update(depths=[4], num_heads_window=[3], num_heads_stripe=[3])
     torch.manual_seed(0)
     m = GRL(**cfg).eval().cuda()
+    if a.logit_scale > 0:
+        import math
+        with torch.no_grad():
+            for n, p_ in m.named_parameters():
+                if n.endswith("logit_scale"):
+                    p_.fill_(math.log(a.logit_scale))
     B, H, W, C, CP = a.tiles, 256, 256, 180, 192
     M = B * H * W
     plan = m._plan((H, W), torch.device("cuda"))
@@ -40,7 +47,7 @@ def main():
     qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
     anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
     att = torch.zeros(M, 2 * nh * 32, dtype=torch.float16, device="cuda")
-    y = torch.zeros(nh, B * Ha * Wa, 32, dtype=torch.bfloat16, device="cuda")
+    y = torch.zeros(nh, B * Ha * Wa, 32, dtype=torch.float16, device="cuda")
     ws, sh = geo.window, geo.window_shift
     stp, ss = geo.stripe, geo.stripe_shift_size
     ast, ass = geo.anchor_stripe, geo.anchor_shift_size
@@ -67,13 +74,13 @@ def main():
                    L_ * C * C * B // (df * df), M * CP * 4),
         "attn_window": (lambda: ops.attention(TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh, H, W, ws[0], ws[1], sh, sh),
                                               TG(qkv, 2 * nh, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
-                                              B=B, nh=nh, table=pk["tab_w"], masked=sh > 0, fixed_max=pk["fixed"], ones_col=30, head_dim=30),
+                                              B=B, nh=nh, table=pk["tab_w"], masked=sh > 0, ones_col=30, head_dim=30, k_one31=True, lazy_floor=pk["floor_w"]),
                         fl_att, M * 4 * 96 * 2),
         "attn_a2w": (lambda: ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh, table=pk["tab_a2w"], masked=geo.stripe_shift,
-                                           fixed_max=pk["fixed"], ones_col=30, head_dim=30), fl_s, M * 2 * 96 * 2),
+                                           ones_col=30, head_dim=30, k_one31=True, lazy_floor=pk["floor_a2w"]), fl_s, M * 2 * 96 * 2),
         "attn_w2a": (lambda: ops.attention(g_q, g_a, g_y, TG(att, nh, H, W, stp[0], stp[1], ss[0], ss[1]), B=B, nh=nh,
-                                           table=pk["tab_w2a"], masked=geo.stripe_shift, fixed_max=pk["fixed"], ones_col=30,
-                                           head_dim=30), fl_s, M * 2 * 96 * 2),
+                                           table=pk["tab_w2a"], masked=geo.stripe_shift, ones_col=30,
+                                           head_dim=30, k_one31=True, lazy_floor=pk["floor_w2a"]), fl_s, M * 2 * 96 * 2),
         "cab_conv1": (lambda: ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid), 2 * 9 * L_ * C * 45 * B, M * (CP * 4 + 96)),
         "cab_conv2": (lambda: ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out=cab), 2 * 9 * L_ * C * 45 * B, M * (128 + CP * 2)),
         "se": (lambda: ops.se_scale(pool, B, CP, C, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"]), 0, pool.numel() * 4),
