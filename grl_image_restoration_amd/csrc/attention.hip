@@ -606,10 +606,11 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const float sub = t ? sub1 : sub0;
-                        f16x2 h;
-                        h[0] = (f16)__builtin_amdgcn_exp2f(S[t][2 * i] - sub);
-                        h[1] = (f16)__builtin_amdgcn_exp2f(S[t][2 * i + 1] - sub);
-                        pw[t][i] = __builtin_bit_cast(uint32_t, h);
+                        typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
+                        const f32x2 e2 = {__builtin_amdgcn_exp2f(S[t][2 * i] - sub), __builtin_amdgcn_exp2f(S[t][2 * i + 1] - sub)};
+                        uint32_t w = __builtin_bit_cast(uint32_t, __builtin_convertvector(e2, f16x2));   // one v_cvt_pk_f16_f32
+                        asm("" : "+v"(w));   // opaque: keeps the compiler from converting every half a second time for the max below
+                        pw[t][i] = w;
                     }
             };
             weights(0.f, 0.f);
