@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -29,6 +29,9 @@ EXPORTS = [
     "grl_conv3x3_fwd",
     "grl_conv3x3_num_workgroups",
     "grl_se_scale_fwd",
+    "grl_gemm_tn",
+    "grl_attention_bwd",
+    "grl_adamw_step",
     "grl_abi_version",
     "grl_build_info",
 ]
@@ -73,6 +76,8 @@ class GrlLinearArgs(_Strict):
         ("add2_scale", C.c_void_p),
         ("rows_per_image", C.c_int32),
         ("a_split", C.c_int32),
+        ("a_scale", C.c_float),
+        ("out_scale", C.c_float),
         ("out", C.c_void_p),
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
@@ -194,6 +199,8 @@ class GrlConvArgs(_Strict):
         ("CinP", C.c_int32),
         ("CoutP", C.c_int32),
         ("x_split", C.c_int32),
+        ("x_scale", C.c_float),
+        ("out_scale", C.c_float),
         ("act", C.c_int32),
         ("slope", C.c_float),
         ("resid", C.c_void_p),
@@ -229,6 +236,62 @@ class GrlLnResArgs(_Strict):
         ("res_scale", C.c_float),
         ("y", C.c_void_p),
         ("ldy", C.c_int64),
+    ]
+
+
+class GrlGemmTnArgs(_Strict):
+    _fields_ = [
+        ("a", C.c_void_p),
+        ("lda", C.c_int64),
+        ("b", C.c_void_p),
+        ("b_dtype", C.c_int32),
+        ("ldb", C.c_int64),
+        ("M", C.c_int32),
+        ("N", C.c_int32),
+        ("K", C.c_int32),
+        ("taps", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("splits", C.c_int32),
+        ("a_scale", C.c_float),
+        ("out_scale", C.c_float),
+        ("c", C.c_void_p),
+        ("ldc", C.c_int64),
+        ("c_tap_stride", C.c_int64),
+    ]
+
+
+class GrlAttnBwdArgs(_Strict):
+    _fields_ = [
+        ("fwd", GrlAttnArgs),
+        ("d_o", C.c_void_p),
+        ("d_q", C.c_void_p),
+        ("d_k", C.c_void_p),
+        ("d_v", C.c_void_p),
+        ("d_table", C.c_void_p),
+        ("g_scale", C.c_float),
+    ]
+
+
+class GrlAdamWArgs(_Strict):
+    _fields_ = [
+        ("params", C.c_void_p),
+        ("grads", C.c_void_p),
+        ("exp_avg", C.c_void_p),
+        ("exp_avg_sq", C.c_void_p),
+        ("numel", C.c_void_p),
+        ("weight_decay_flags", C.c_void_p),
+        ("chunk_tensor", C.c_void_p),
+        ("chunk_offset", C.c_void_p),
+        ("num_chunks", C.c_int32),
+        ("lr", C.c_float),
+        ("beta1", C.c_float),
+        ("beta2", C.c_float),
+        ("eps", C.c_float),
+        ("weight_decay", C.c_float),
+        ("bias_correction1", C.c_float),
+        ("bias_correction2_sqrt", C.c_float),
+        ("grad_scale", C.c_float),
     ]
 
 
@@ -281,6 +344,12 @@ def lib():
     L.grl_se_scale_fwd.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32,
                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     L.grl_se_scale_fwd.restype = C.c_int
+    L.grl_gemm_tn.argtypes = [C.c_void_p, C.POINTER(GrlGemmTnArgs)]
+    L.grl_gemm_tn.restype = C.c_int
+    L.grl_attention_bwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnBwdArgs)]
+    L.grl_attention_bwd.restype = C.c_int
+    L.grl_adamw_step.argtypes = [C.c_void_p, C.POINTER(GrlAdamWArgs)]
+    L.grl_adamw_step.restype = C.c_int
     _lib = L
     return L
 

@@ -31,6 +31,7 @@
 // queries) whose Q fragments and O^T accumulators stay in registers; K and V chunks of 256 keys are staged in LDS.
 #include "common.h"
 #include "grl_hip_internal.h"
+#include "attn_common.h"
 #include <stdlib.h>
 
 namespace {
@@ -38,52 +39,10 @@ namespace {
 constexpr int QT = 2;            // query tiles per wave
 constexpr int KC = 256;          // keys per LDS chunk
 constexpr int VROW = KC * 2 + 8; // V^T row stride in bytes (pad: conflict-free ds_read_b64)
-constexpr float MASK_L2 = -100.0f * LOG2E_F;
-constexpr float NEG_BIG = -1.0e30f;
 constexpr float P_TOP = 14.0f;           // log2 of the largest fp16 weight the kernels produce (fp16 max is 2^16)
 constexpr float LAZY_REST = 6.0f;        // lazy offset: after a rescale the tile maximum sits in (2^5, 2^6]
 constexpr unsigned short LAZY_TRIP = 0x7400;   // fp16 bit pattern of 2^14: a packed weight >= this moves the offset
 constexpr unsigned short F16_INF = 0x7C00;
-
-// Workgroup -> work item map that keeps consecutive work items (the query blocks of one window and
-// head, which share K/V) on ONE XCD: the dispatcher places block b on XCD b % 8 and every XCD has a
-// private L2 (MI355X guide, T1).  Bijective for any grid size; affects speed only.
-__device__ __forceinline__ int xcd_remap(int bid, int n) {
-    const int q = n >> 3, r = n & 7, x = bid & 7;
-    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
-}
-
-// global -> LDS copy of one head's bias table with 4 x 16 B loads in flight per thread
-__device__ __forceinline__ void load_table(float* tab, const float* src, int trows, int tid, int nthreads) {
-    const int n4 = (trows + 3) >> 2;  // the per-head stride is padded to a multiple of 4 floats
-    const float4* s4 = (const float4*)src;
-    float4* d4 = (float4*)tab;
-    for (int i0 = tid; i0 < n4; i0 += 4 * nthreads) {
-        float4 v[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * nthreads < n4) v[j] = s4[i0 + j * nthreads];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * nthreads < n4) d4[i0 + j * nthreads] = v[j];
-    }
-}
-
-__device__ __forceinline__ int region1d(int p, int n, int s, int sh) {
-    // ops.py:76-100: labels 0 | 1 | 2 split at n-s and n-sh; a zero shift labels the whole axis alike
-    if (sh == 0) return 0;
-    return p < n - s ? 0 : (p < n - sh ? 1 : 2);
-}
-
-// token n of window (wy,wx) of image b -> (row index in the token matrix, region id)
-__device__ __forceinline__ void locate(const GrlTokenGrid& g, int b, int wy, int wx, int n, int64_t& row, int& rid) {
-    const int hq = n / g.ww, wq = n - hq * g.ww;
-    const int ry = wy * g.wh + hq, rx = wx * g.ww + wq;
-    int oy = ry + g.shy; if (oy >= g.Himg) oy -= g.Himg;
-    int ox = rx + g.shx; if (ox >= g.Wimg) ox -= g.Wimg;
-    row = ((int64_t)b * g.Himg + oy) * g.Wimg + ox;
-    rid = 3 * region1d(ry, g.Himg, g.wh, g.shy) + region1d(rx, g.Wimg, g.ww, g.shx);
-}
 
 // normalised O^T fragment of one query tile -> global (lane holds head dims 8*g + 4*half + [0..3] of query l31)
 __device__ __forceinline__ void store_o(const GrlAttnArgs& p, const f32x16& O, float inv, int64_t qrow, int head, int half) {

@@ -1,0 +1,421 @@
+// Backward of the cosine window / anchored-stripe attention (gfx950), flash-style: nothing of size Nq x Nk is stored.
+//
+// Replaces autograd through Attention.attn + AffineTransform (models/common/mixed_attn_block_efficient.py:36-58,77-94)
+// inside WindowAttention / AnchorStripeAttention (:128-165, :215-270) in the reference's training step
+// (engines/base.py:221-236).  Closed form (oracle/backward_math.py, pinned against autograd), in the kernel's own operands
+//   S_ij = q~_i . k^_j + table[idx(i,j)] (+ mask)        (log2 domain; q~ carries scale*log2e)
+//   P_ij = exp2(S_ij - lse_i)                             (lse from the forward kernel)
+//   D_i  = sum_c dO_ic O_ic          dP_ij = dO_i . v_j          dS_ij = ln2 * P_ij (dP_ij - D_i)
+//   dv_j = sum_i P_ij dO_i     dq~_i = sum_j dS_ij k^_j     dk^_j = sum_i dS_ij q~_i     dtable[idx(i,j)] += dS_ij
+// The gradients of the L2 normalisation, the logit scale and the CPB-MLP (table) are taken by the caller.
+//
+// Two kernels, both built like the generic forward kernel (any window shape, index arithmetic instead of partition / roll /
+// mask / index tensors):
+//   dq_kernel  : workgroup = (window, head, 256 queries); S^T = K.Q orientation (lane = query) exactly as the forward, keys
+//                stream through LDS; 6 MFMAs per (32 keys x 32 queries) tile; dtable as an LDS histogram (ds_add_f32)
+//                flushed with global atomics.
+//   dkv_kernel : workgroup = (window, head, 256 keys); S = Q.K^T orientation (lane = key), queries stream through LDS;
+//                8 MFMAs per tile.
+// dO is multiplied by g_scale on its way to fp16 (gradients of an L1 loss are ~1e-6: below the fp16 normal range); all
+// outputs are un-scaled on store.
+#include "common.h"
+#include "grl_hip_internal.h"
+#include "attn_common.h"
+
+namespace {
+
+constexpr int QT = 2;            // tiles (32 queries resp. keys) per wave
+constexpr int KC = 256;          // streamed rows per LDS chunk
+constexpr int TROW = KC * 2 + 8; // transposed staging: row stride in bytes
+constexpr float LN2_F = 0.69314718055994531f;
+
+// a [32-row][32 half] A-operand fragment pair from row-major swizzled LDS rows (64 B per row): rows = kb + l31,
+// k-slots = columns 8*half (+16)
+__device__ __forceinline__ void frag_rows(const char* base, int kb, int l31, int half, f16x8 (&f)[2]) {
+    const int kk = kb + l31;
+    const int sw = (kk >> 2) & 3;
+    f[0] = *(const f16x8*)(base + kk * 64 + (((0 + half) ^ sw) << 4));
+    f[1] = *(const f16x8*)(base + kk * 64 + (((2 + half) ^ sw) << 4));
+}
+
+// a [32 x 32-row] A-operand fragment pair from the TRANSPOSED staging [32 cols][TROW]: rows = column l31 of the source,
+// k-slot e <-> source row kb + 16*s + 8*(e>>2) + 4*half + (e&3)  (the order the packed accumulator registers imply)
+__device__ __forceinline__ void frag_cols(const char* base, int kb, int l31, int half, f16x8 (&f)[2]) {
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+        const char* vp = base + l31 * TROW + (kb + 16 * s + 4 * half) * 2;
+        const f16x4 lo = *(const f16x4*)(vp);
+        const f16x4 hi = *(const f16x4*)(vp + 16);
+        f[s] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    }
+}
+
+__device__ __forceinline__ void pack_acc(const f32x16& a, f16x8 (&o)[2]) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) o[r >> 3][r & 7] = to_f16(a[r]);
+}
+
+__device__ __forceinline__ f16x8 load_f16x8(const GrlTokenGrid& g, int64_t row, int head, int seg) {
+    return *(const f16x8*)((const f16*)g.ptr + row * g.ld + g.col0 + head * g.hstride + seg * 8);
+}
+
+__device__ __forceinline__ f16x8 load_f32x8_as_f16(const float* base, const GrlTokenGrid& g, int64_t row, int head, int seg, float scale) {
+    const float4* q = (const float4*)(base + row * g.ld + g.col0 + head * g.hstride + seg * 8);
+    const float4 a0 = q[0], a1 = q[1];
+    f16x8 v;
+    v[0] = to_f16(a0.x * scale); v[1] = to_f16(a0.y * scale); v[2] = to_f16(a0.z * scale); v[3] = to_f16(a0.w * scale);
+    v[4] = to_f16(a1.x * scale); v[5] = to_f16(a1.y * scale); v[6] = to_f16(a1.z * scale); v[7] = to_f16(a1.w * scale);
+    return v;
+}
+
+// store an accumulator in the (rows = head dim, cols = token) orientation to a [token][32] fp32 slot
+__device__ __forceinline__ void store_cols(float* base, const GrlTokenGrid& g, int64_t row, int head, int half, const f32x16& a, float scale) {
+    float* dst = base + row * g.ld + g.col0 + head * g.hstride + 4 * half;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+        *(float4*)(dst + 8 * q) = float4{a[4 * q + 0] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale};
+}
+
+// ------------------------------------------------------------------------------------------------
+// dq + dtable
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
+    const GrlAttnArgs& p = a.fwd;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
+    const int qblk = (nthreads >> 6) * (QT * 32);
+    const int nqs = (Nq + qblk - 1) / qblk;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int qs = bid % nqs; bid /= nqs;
+    const int head = bid % p.nh; bid /= p.nh;
+    const int wx = bid % p.nwx; bid /= p.nwx;
+    const int wy = bid % p.nwy;
+    const int b = bid / p.nwy;
+    const int D = p.q.ww + p.k.ww - 1;
+    const int tpad = (p.trows + 3) & ~3;
+
+    float* tab = (float*)smem;                         // tpad
+    float* dtab = tab + tpad;                          // tpad (histogram)
+    char* Ks = (char*)(dtab + tpad);                   // KC x 64 B   (rows = keys)
+    char* Vs = Ks + KC * 64;                           // KC x 64 B
+    char* Kt = Vs + KC * 64;                           // 32 x TROW   (rows = head dim)
+    int* koff = (int*)(Kt + 32 * TROW);                // KC
+    unsigned char* kreg = (unsigned char*)(koff + KC); // KC
+
+    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
+    for (int i = tid; i < tpad; i += nthreads) dtab[i] = 0.f;
+
+    const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+
+    int U[QT], idq[QT];
+    int64_t qrow[QT];
+    bool qvalid[QT];
+    f16x8 qf[QT][2], dof[QT][2];
+    f32x16 dQ[QT];
+    float lse[QT], Dq[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int n = qs * qblk + wave * (QT * 32) + t * 32 + l31;
+        qvalid[t] = n < Nq;
+        if (!qvalid[t]) n = Nq - 1;
+        locate(p.q, b, wy, wx, n, qrow[t], idq[t]);
+        const int hq = n / p.q.ww, wq = n - hq * p.q.ww;
+        U[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1));
+        qf[t][0] = load_f16x8(p.q, qrow[t], head, half);
+        qf[t][1] = load_f16x8(p.q, qrow[t], head, 2 + half);
+        // slot 31 of q carries the forward kernel's running offset in registers only: in memory it is a pad column (0)
+        dof[t][0] = load_f32x8_as_f16(a.d_o, p.o, qrow[t], head, half, a.g_scale);
+        dof[t][1] = load_f32x8_as_f16(a.d_o, p.o, qrow[t], head, 2 + half, a.g_scale);
+        // D_i = sum_c dO_ic O_ic (scaled like dO): this lane holds 16 of the 32 columns
+        float d = 0.f;
+        {
+            const float* op = (const float*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride;
+            const float* gp = a.d_o + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride;
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const int c = 16 * s + 8 * half + e;
+                    if (c < p.head_dim) d += op[c] * gp[c];
+                }
+        }
+        d += xhalf(d);
+        Dq[t] = d * a.g_scale;
+        lse[t] = p.lse[(int64_t)head * p.lse_stride + qrow[t]];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) dQ[t][r] = 0.f;
+    }
+
+    const int nchunks = (Nk + KC - 1) / KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int k0 = ch * KC;
+        const int klen = min(KC, Nk - k0);
+        const int ntiles = (klen + 31) >> 5;
+        __syncthreads();
+        for (int i = tid; i < ntiles * 32 * 4; i += nthreads) {
+            const int kk = i >> 2, seg = i & 3;
+            const int n = k0 + kk;
+            const bool valid = n < Nk;
+            int64_t row; int rid;
+            locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
+            f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+            if (valid) {
+                kv = load_f16x8(p.k, row, head, seg);
+                vv = load_f16x8(p.v, row, head, seg);
+            }
+            *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
+            *(f16x8*)(Vs + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = vv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) *(f16*)(Kt + (seg * 8 + e) * TROW + kk * 2) = kv[e];
+            if (seg == 0) {
+                const int nn = valid ? n : 0;
+                const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
+                koff[kk] = hk * D + wk;
+                kreg[kk] = valid ? (unsigned char)rid : (unsigned char)255;
+            }
+        }
+        __syncthreads();
+
+        for (int kt = 0; kt < ntiles; ++kt) {
+            const int kb = kt * 32;
+            f16x8 kf[2], vf[2], ktf[2];
+            frag_rows(Ks, kb, l31, half, kf);
+            frag_rows(Vs, kb, l31, half, vf);
+            frag_cols(Kt, kb, l31, half, ktf);
+            int kofs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) kofs[r] = koff[kb + mfma32_row(r, half)];
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x16 S, dP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { S[r] = tab[U[t] + kofs[r]]; dP[r] = 0.f; }
+                S = mfma32_f16(kf[0], qf[t][0], S);
+                S = mfma32_f16(kf[1], qf[t][1], S);
+                dP = mfma32_f16(vf[0], dof[t][0], dP);
+                dP = mfma32_f16(vf[1], dof[t][1], dP);
+                f32x16 dS;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int idk = kreg[kb + mfma32_row(r, half)];
+                    float s = S[r];
+                    if (idk == 255) s = NEG_BIG;
+                    else if (border && idk != idq[t]) s += MASK_L2;
+                    const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
+                    dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
+                    if (qvalid[t] && idk != 255) atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
+                }
+                f16x8 dsp[2];
+                pack_acc(dS, dsp);
+                dQ[t] = mfma32_f16(ktf[0], dsp[0], dQ[t]);
+                dQ[t] = mfma32_f16(ktf[1], dsp[1], dQ[t]);
+            }
+        }
+    }
+
+    const float inv = 1.0f / a.g_scale;
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+        if (qvalid[t]) store_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
+    __syncthreads();
+    float* gt = a.d_table + (int64_t)head * p.tstride;
+    for (int i = tid; i < p.trows; i += nthreads) {
+        const float v = dtab[i];
+        if (v != 0.f) unsafeAtomicAdd(gt + i, v * inv);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// dk + dv
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void attn_dkv_kernel(GrlAttnBwdArgs a) {
+    const GrlAttnArgs& p = a.fwd;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
+    const int half = lane >> 5, l31 = lane & 31;
+    const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
+    const int kblk = (nthreads >> 6) * (QT * 32);
+    const int nks = (Nk + kblk - 1) / kblk;
+    int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int ks = bid % nks; bid /= nks;
+    const int head = bid % p.nh; bid /= p.nh;
+    const int wx = bid % p.nwx; bid /= p.nwx;
+    const int wy = bid % p.nwy;
+    const int b = bid / p.nwy;
+    const int D = p.q.ww + p.k.ww - 1;
+    const int tpad = (p.trows + 3) & ~3;
+
+    float* tab = (float*)smem;                         // tpad
+    char* Qs = (char*)(tab + tpad);                    // KC x 64 B   (rows = queries)
+    char* Gs = Qs + KC * 64;                           // KC x 64 B   dO rows (scaled fp16)
+    char* Qt = Gs + KC * 64;                           // 32 x TROW   (rows = head dim)
+    char* Gt = Qt + 32 * TROW;                         // 32 x TROW
+    float* qlse = (float*)(Gt + 32 * TROW);            // KC
+    float* qD = qlse + KC;                             // KC
+    int* qoff = (int*)(qD + KC);                       // KC
+    unsigned char* qreg = (unsigned char*)(qoff + KC); // KC
+
+    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
+
+    const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+
+    int Uk[QT], idk[QT];
+    int64_t krow[QT];
+    bool kvalid[QT];
+    f16x8 kfb[QT][2], vfb[QT][2];
+    f32x16 dK[QT], dV[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        int n = ks * kblk + wave * (QT * 32) + t * 32 + l31;
+        kvalid[t] = n < Nk;
+        if (!kvalid[t]) n = Nk - 1;
+        locate(p.k, b, wy, wx, n, krow[t], idk[t]);
+        const int hk = n / p.k.ww, wk = n - hk * p.k.ww;
+        // reversed table entry of (query (hq, wq), key (hk, wk)) = trows-1 - [(hq-hk+KH-1)*D + (wq-wk+KW-1)] = Uk - (hq*D + wq)
+        Uk[t] = p.trows - 1 - ((p.k.wh - 1 - hk) * D + (p.k.ww - 1 - wk));
+        kfb[t][0] = load_f16x8(p.k, krow[t], head, half);
+        kfb[t][1] = load_f16x8(p.k, krow[t], head, 2 + half);
+        if (half && p.head_dim <= 30) kfb[t][1][7] = (f16)0.f;   // slot 31 of k holds 1.0 for the forward kernel's offset: not part of the logit
+        vfb[t][0] = load_f16x8(p.v, krow[t], head, half);
+        vfb[t][1] = load_f16x8(p.v, krow[t], head, 2 + half);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { dK[t][r] = 0.f; dV[t][r] = 0.f; }
+    }
+
+    const int nchunks = (Nq + KC - 1) / KC;
+    for (int ch = 0; ch < nchunks; ++ch) {
+        const int q0 = ch * KC;
+        const int qlen = min(KC, Nq - q0);
+        const int ntiles = (qlen + 31) >> 5;
+        __syncthreads();
+        for (int i = tid; i < ntiles * 32 * 4; i += nthreads) {
+            const int qq = i >> 2, seg = i & 3;
+            const int n = q0 + qq;
+            const bool valid = n < Nq;
+            int64_t row; int rid;
+            locate(p.q, b, wy, wx, valid ? n : 0, row, rid);
+            f16x8 qv = {0, 0, 0, 0, 0, 0, 0, 0}, gv = qv;
+            float dpart = 0.f;
+            if (valid) {
+                qv = load_f16x8(p.q, row, head, seg);
+                gv = load_f32x8_as_f16(a.d_o, p.o, row, head, seg, a.g_scale);
+                const float* op = (const float*)p.o.ptr + row * p.o.ld + p.o.col0 + head * p.o.hstride + seg * 8;
+                const float* gp = a.d_o + row * p.o.ld + p.o.col0 + head * p.o.hstride + seg * 8;
+#pragma unroll
+                for (int e = 0; e < 8; ++e)
+                    if (seg * 8 + e < p.head_dim) dpart += op[e] * gp[e];
+            }
+            // D_i: the four segment owners of a query are four consecutive lanes
+            dpart += __shfl_xor(dpart, 1, 64);
+            dpart += __shfl_xor(dpart, 2, 64);
+            *(f16x8*)(Qs + qq * 64 + ((seg ^ ((qq >> 2) & 3)) << 4)) = qv;
+            *(f16x8*)(Gs + qq * 64 + ((seg ^ ((qq >> 2) & 3)) << 4)) = gv;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                *(f16*)(Qt + (seg * 8 + e) * TROW + qq * 2) = qv[e];
+                *(f16*)(Gt + (seg * 8 + e) * TROW + qq * 2) = gv[e];
+            }
+            if (seg == 0) {
+                const int nn = valid ? n : 0;
+                const int hq = nn / p.q.ww, wq = nn - hq * p.q.ww;
+                qoff[qq] = hq * D + wq;
+                qreg[qq] = valid ? (unsigned char)rid : (unsigned char)255;
+                qlse[qq] = valid ? p.lse[(int64_t)head * p.lse_stride + row] : 1.0e30f;   // invalid query: weight 0
+                qD[qq] = dpart * a.g_scale;
+            }
+        }
+        __syncthreads();
+
+        for (int qt = 0; qt < ntiles; ++qt) {
+            const int qb = qt * 32;
+            f16x8 qfr[2], gfr[2], qtf[2], gtf[2];
+            frag_rows(Qs, qb, l31, half, qfr);     // A operand: rows = queries, k-slots = head dim
+            frag_rows(Gs, qb, l31, half, gfr);
+            frag_cols(Qt, qb, l31, half, qtf);     // A operand: rows = head dim, k-slots = queries
+            frag_cols(Gt, qb, l31, half, gtf);
+            int qofs[16], qids[16];
+            float ql[16], qd[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int qq = qb + mfma32_row(r, half);
+                qofs[r] = qoff[qq]; qids[r] = qreg[qq]; ql[r] = qlse[qq]; qd[r] = qD[qq];
+            }
+#pragma unroll
+            for (int t = 0; t < QT; ++t) {
+                f32x16 S, dP;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) { S[r] = tab[Uk[t] - qofs[r]]; dP[r] = 0.f; }
+                S = mfma32_f16(qfr[0], kfb[t][0], S);
+                S = mfma32_f16(qfr[1], kfb[t][1], S);
+                dP = mfma32_f16(gfr[0], vfb[t][0], dP);
+                dP = mfma32_f16(gfr[1], vfb[t][1], dP);
+                f32x16 P, dS;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    float s = S[r];
+                    if (border && qids[r] != idk[t]) s += MASK_L2;
+                    const float pr = kvalid[t] ? __builtin_amdgcn_exp2f(s - ql[r]) : 0.f;
+                    P[r] = pr;
+                    dS[r] = LN2_F * pr * (dP[r] - qd[r]);
+                }
+                f16x8 pp[2], dsp[2];
+                pack_acc(P, pp);
+                pack_acc(dS, dsp);
+                dV[t] = mfma32_f16(gtf[0], pp[0], dV[t]);
+                dV[t] = mfma32_f16(gtf[1], pp[1], dV[t]);
+                dK[t] = mfma32_f16(qtf[0], dsp[0], dK[t]);
+                dK[t] = mfma32_f16(qtf[1], dsp[1], dK[t]);
+            }
+        }
+    }
+    const float inv = 1.0f / a.g_scale;
+#pragma unroll
+    for (int t = 0; t < QT; ++t)
+        if (kvalid[t]) {
+            store_cols(a.d_k, p.k, krow[t], head, half, dK[t], inv);
+            store_cols(a.d_v, p.v, krow[t], head, half, dV[t], inv);
+        }
+}
+
+}  // namespace
+
+extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
+    const GrlAttnBwdArgs& a = *args;
+    const GrlAttnArgs& p = a.fwd;
+    const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
+    if (Nq <= 0 || Nk <= 0 || p.B <= 0 || p.nh <= 0) return GRL_ERR_BAD_ARG;
+    if (p.q.Himg != p.nwy * p.q.wh || p.q.Wimg != p.nwx * p.q.ww || p.k.Himg != p.nwy * p.k.wh || p.k.Wimg != p.nwx * p.k.ww) return GRL_ERR_BAD_ARG;
+    if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1) || p.tstride < p.trows || (p.tstride & 3)) return GRL_ERR_BAD_ARG;
+    if (p.head_dim > 32 || p.out_dtype != GRL_DT_F32 || p.lse == nullptr || p.lse_stride <= 0) return GRL_ERR_BAD_ARG;
+    if (!a.d_o || !a.d_q || !a.d_k || !a.d_v || !a.d_table || !(a.g_scale > 0.f)) return GRL_ERR_BAD_ARG;
+    if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 8) || (p.q.col0 % 8) || (p.k.col0 % 8) || (p.v.col0 % 8) ||
+        (p.o.col0 % 8) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 8))
+        return GRL_ERR_BAD_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t tpad = (size_t)((p.trows + 3) & ~3) * 4;
+    {
+        const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
+        const int blk = waves * QT * 32;
+        const int64_t grid = (int64_t)((Nq + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
+        const size_t lds = 2 * tpad + 2 * (size_t)KC * 64 + 32 * (size_t)TROW + KC * 4 + KC;
+        if (grid > 0x7fffffff || lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
+        hipError_t e = hipFuncSetAttribute((const void*)attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(attn_dq_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a);
+        GRL_CHECK_LAUNCH();
+    }
+    {
+        const int waves = min(4, (Nk + QT * 32 - 1) / (QT * 32));
+        const int blk = waves * QT * 32;
+        const int64_t grid = (int64_t)((Nk + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
+        const size_t lds = tpad + 2 * (size_t)KC * 64 + 2 * 32 * (size_t)TROW + KC * 4 * 3 + KC;
+        if (grid > 0x7fffffff || lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
+        hipError_t e = hipFuncSetAttribute((const void*)attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL(attn_dkv_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a);
+        GRL_CHECK_LAUNCH();
+    }
+    return 0;
+}

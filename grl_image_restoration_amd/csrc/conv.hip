@@ -80,6 +80,8 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
 
     // x_split == 3: the virtual input channels are [hi(x) | lo(x) | hi(x)] over CinP / 3 source channels (grl_hip.h)
     const int csrc = p.x_split == 3 ? p.CinP / 3 : p.CinP;
+    const float xsc = p.x_scale != 0.0f ? p.x_scale : 1.0f;   // backward pass: gradients pre-scaled into fp16 range
+    const float osc = p.out_scale != 0.0f ? p.out_scale : 1.0f;
     auto stage_input = [&](int kc) {
 #pragma unroll 2
         for (int s = tid; s < HALO_H * HALO_W * SEG_ROW; s += CWAVES * 64) {
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
                 } else {
                     const float4* q = (const float4*)((const float*)p.x + row * p.ldx + ch0);
                     const float4 a0 = q[0], a1 = q[1];
-                    const float e[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+                    const float e[8] = {a0.x * xsc, a0.y * xsc, a0.z * xsc, a0.w * xsc, a1.x * xsc, a1.y * xsc, a1.z * xsc, a1.w * xsc};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) {
                         const f16 h = to_f16(e[i]);
@@ -203,7 +205,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
             for (int nt = 0; nt < NT; ++nt) {
                 const int c = 16 * nt + 4 * g4;
                 const float4 b4 = *(const float4*)(p.bias + c);
-                float v[4] = {acc[mt][nt][0] + b4.x, acc[mt][nt][1] + b4.y, acc[mt][nt][2] + b4.z, acc[mt][nt][3] + b4.w};
+                float v[4] = {fmaf(acc[mt][nt][0], osc, b4.x), fmaf(acc[mt][nt][1], osc, b4.y), fmaf(acc[mt][nt][2], osc, b4.z), fmaf(acc[mt][nt][3], osc, b4.w)};
                 if (p.act == 1) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
         for (int nt = 0; nt < NT; ++nt) {
             const int c = 16 * nt + 4 * g4;
             const float4 b4 = *(const float4*)(p.bias + c);
-            float v[4] = {acc[mt][nt][0] + b4.x, acc[mt][nt][1] + b4.y, acc[mt][nt][2] + b4.z, acc[mt][nt][3] + b4.w};
+            float v[4] = {fmaf(acc[mt][nt][0], osc, b4.x), fmaf(acc[mt][nt][1], osc, b4.y), fmaf(acc[mt][nt][2], osc, b4.z), fmaf(acc[mt][nt][3], osc, b4.w)};
             if (p.act == 1) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);

@@ -41,6 +41,7 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
     const int r = lane & 15, kg = lane >> 4;
     // a_split == 3: virtual K = [hi | lo | hi] over a source of KS3 k-steps (KSTEPS = 3 * KS3)
     const bool split = p.a_split == 3;
+    const float asc = p.a_scale != 0.0f ? p.a_scale : 1.0f;   // backward pass: gradients pre-scaled into fp16 range
     constexpr int KS3 = KSTEPS / 3;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -86,8 +87,8 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
                 float4 v0 = q[0], v1 = q[1];
                 if (!valid) { v0 = float4{0, 0, 0, 0}; v1 = v0; }
                 gemm_x8 v;
-                v[0] = split_part(v0.x, lo); v[1] = split_part(v0.y, lo); v[2] = split_part(v0.z, lo); v[3] = split_part(v0.w, lo);
-                v[4] = split_part(v1.x, lo); v[5] = split_part(v1.y, lo); v[6] = split_part(v1.z, lo); v[7] = split_part(v1.w, lo);
+                v[0] = split_part(v0.x * asc, lo); v[1] = split_part(v0.y * asc, lo); v[2] = split_part(v0.z * asc, lo); v[3] = split_part(v0.w * asc, lo);
+                v[4] = split_part(v1.x * asc, lo); v[5] = split_part(v1.y * asc, lo); v[6] = split_part(v1.z * asc, lo); v[7] = split_part(v1.w * asc, lo);
                 a[mt][s] = v;
             }
         }
@@ -312,12 +313,14 @@ __global__ __launch_bounds__(WV * 64) void linear_kernel(GrlLinearArgs p) {
                     }
                 }
                 // bias: lane holds channels n0 + 16*nt + 4*g4 + [0..3] of token row0 + 16*mt + r16
+                const float osc = p.out_scale != 0.0f ? p.out_scale : 1.0f;
 #pragma unroll
                 for (int nt = 0; nt < NT; ++nt) {
                     const float4 b4 = *(const float4*)(p.bias + n0 + 16 * nt + 4 * g4i);
 #pragma unroll
                     for (int mt = 0; mt < MT; ++mt) {
-                        acc[c][mt][nt][0] += b4.x; acc[c][mt][nt][1] += b4.y; acc[c][mt][nt][2] += b4.z; acc[c][mt][nt][3] += b4.w;
+                        acc[c][mt][nt][0] = fmaf(acc[c][mt][nt][0], osc, b4.x); acc[c][mt][nt][1] = fmaf(acc[c][mt][nt][1], osc, b4.y);
+                        acc[c][mt][nt][2] = fmaf(acc[c][mt][nt][2], osc, b4.z); acc[c][mt][nt][3] = fmaf(acc[c][mt][nt][3], osc, b4.w);
                     }
                 }
             }

@@ -18,6 +18,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import _lib as L
+from . import autograd as AG
 from . import ops, tables
 from .geometry import BlockGeo, block_schedule, pad_multiple, table_rows, to_2tuple
 
@@ -261,6 +262,9 @@ class GRL(nn.Module):
 
         self.apply(self._init_weights)  # grl.py:381,455-469
         self._init_method_rescale(init_method)
+        # stochastic depth decay rule (grl.py:299-300): block j of the whole network drops its branches with probability dpr[j]
+        self.drop_path_rate = float(drop_path_rate)
+        self._dpr = [v.item() for v in torch.linspace(0, drop_path_rate, sum(depths))]
         self._plan_cache: Dict = {}
         self._register_load_state_dict_pre_hook(self._drop_reference_buffers)
         # fires on the recursive path too (a parent module's load_state_dict, tools/trainer.py:108-111)
@@ -680,6 +684,142 @@ class GRL(nn.Module):
             main.wait_stream(pool[g])
         return out
 
+    # ---- training path (BASELINE config 5; reference: engines/base.py:221-236 = autograd through grl.py / efficient.py) --------
+    @staticmethod
+    def _drop_path(x, rows_per_image: int, p: float, training: bool):
+        """timm DropPath (scale_by_keep) on a token matrix: one Bernoulli draw per image (mixed_attn_block_efficient.py:500)."""
+        if p == 0.0 or not training:
+            return x
+        keep = 1.0 - p
+        m = x.new_empty(x.shape[0] // rows_per_image, 1, 1).bernoulli_(keep) / keep
+        return (x.view(-1, rows_per_image, x.shape[1]) * m).view_as(x)
+
+    @staticmethod
+    def _to_planes(t, extra: int = 32):
+        """[tokens, nh, d] -> fp32 head planes [nh, tokens, 32] (zero padded)."""
+        return F.pad(t, (0, extra - t.shape[-1])).permute(1, 0, 2).contiguous()
+
+    def _attn_table(self, m: _Affine, win, df, dev):
+        coords = tables.coords_table(win, df, device=dev)
+        h = F.relu(F.linear(coords, m.cpb_mlp[0].weight, m.cpb_mlp[0].bias))
+        return tables.kernel_table(16.0 * torch.sigmoid(F.linear(h, m.cpb_mlp[2].weight)))     # differentiable w.r.t. the CPB-MLP
+
+    @staticmethod
+    def _scale(m: _Affine):
+        """exp(min(logit_scale, ln 100)) * log2e per head (efficient.py:39), differentiable below the clamp."""
+        return torch.clamp(m.logit_scale.reshape(-1), max=math.log(1.0 / 0.01)).exp() * LOG2E
+
+    def _block_train(self, r, blk: _Block, geo: BlockGeo, B, H, W, dp: float):
+        """EfficientMixAttnTransformerBlock.forward (efficient.py:539-556) on the token matrix r [B*H*W, C] with autograd."""
+        C = self.embed_dim
+        M = B * H * W
+        nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
+        d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
+        Ha, Wa = H // df, W // df
+        a = blk.attn
+        dev = r.device
+        qkv = AG.linear(r, a.qkv.body.weight, a.qkv.body.bias)                                 # QKVProjection (mixed_attn_block.py:669-676)
+        pooled = r.view(B, Ha, df, Wa, df, C).mean(dim=(2, 4)).reshape(B * Ha * Wa, C)          # AnchorLinear avg-pool (:727-736)
+        anc = AG.linear(pooled, a.anchor.body[0].reduction.weight, a.anchor.body[0].reduction.bias).view(-1, nh_s, d_s)
+        qw, kw, vw = qkv[:, : 3 * C // 2].reshape(M, 3, nh_w, d_w).unbind(1)
+        qs, ks, vs = qkv[:, 3 * C // 2 :].reshape(M, 3, nh_s, d_s).unbind(1)
+        P = self._to_planes
+
+        def floor(m):
+            return tables.lazy_floor(tables.clamped_scale(m.logit_scale).to(dev))
+
+        ws, sh = geo.window, geo.window_shift
+        st, ss = geo.stripe, geo.stripe_shift_size
+        ast, ass = geo.anchor_stripe, geo.anchor_shift_size
+        g_tok_w = (H, W, ws[0], ws[1], sh, sh)
+        g_tok_s = (H, W, st[0], st[1], ss[0], ss[1])
+        g_anc = (Ha, Wa, ast[0], ast[1], ass[0], ass[1])
+        # window attention (efficient.py:128-165)
+        tw = a.window_attn.attn_transform
+        ow = AG.AttentionFn.apply(P(F.normalize(qw, dim=-1) * self._scale(tw).view(1, nh_w, 1)), P(F.normalize(kw, dim=-1)), P(vw),
+                                  self._attn_table(tw, geo.window, 1, dev),
+                                  dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh_w, d=d_w, masked=sh > 0, floor=floor(tw)))
+        # anchored stripe attention (efficient.py:215-270): anchors -> stripe tokens, then stripe tokens -> anchors
+        t1, t2 = a.stripe_attn.attn_transform1, a.stripe_attn.attn_transform2
+        an = F.normalize(anc, dim=-1)
+        y = AG.AttentionFn.apply(P(an * self._scale(t1).view(1, nh_s, 1)), P(F.normalize(ks, dim=-1)), P(vs),
+                                 self._attn_table(t1, geo.stripe, df, dev),
+                                 dict(q=g_anc, k=g_tok_s, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(t1)))
+        yv = y * (torch.arange(32, device=dev) < d_s).to(y.dtype)      # real head dims only (the kernel's ones column is not a value)
+        os_ = AG.AttentionFn.apply(P(F.normalize(qs, dim=-1) * self._scale(t2).view(1, nh_s, 1)), P(an), yv,
+                                   self._attn_table(t2, geo.stripe, df, dev),
+                                   dict(q=g_tok_s, k=g_anc, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(t2)))
+        att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
+        x1 = AG.linear(att, a.proj.weight, a.proj.bias)
+        x1 = r + self.res_scale * self._drop_path(F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp, self.training)
+        if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
+            c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention
+            u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
+            pool = u.view(B, H * W, C).mean(dim=1)
+            gate = torch.sigmoid(F.linear(F.relu(F.linear(pool, se[1].weight.flatten(1), se[1].bias)), se[3].weight.flatten(1), se[3].bias))
+            x1 = x1 + (u.view(B, H * W, C) * gate.unsqueeze(1)).view(M, C)
+        m = AG.linear(F.gelu(AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+        return x1 + self.res_scale * self._drop_path(F.layer_norm(m, (C,), blk.norm2.weight, blk.norm2.bias, 1e-5), H * W, dp, self.training)
+
+    def _forward_train(self, x):
+        """GRL.forward (grl.py:506-551) as a differentiable graph over the HIP kernels (autograd.py)."""
+        H0, W0 = x.shape[2:]
+        x = self.check_image_size(x.float())
+        mean = self._mean.to(x.device, x.dtype)
+        x = (x - mean) * self.img_range
+        B, Cin, H, W = x.shape
+        C, s, oc = self.embed_dim, self.upscale, self.out_channels
+        sched = block_schedule(self.depths, self.num_heads_window, self.num_heads_stripe, self.window_size, self.stripe_size,
+                               self.stripe_groups, self.stripe_shift, self.df, (H, W))
+
+        def conv(t, m, b=B, h=H, w=W):
+            return AG.conv3x3(t, m.weight, m.bias, b, h, w)
+
+        def shuffle(t, b, h, w, r):   # PixelShuffle(r) on a token matrix [b*h*w, c*r*r] -> [b*h*r*w*r, c]
+            c = t.shape[1] // (r * r)
+            return t.view(b, h, w, c, r, r).permute(0, 1, 4, 2, 5, 3).reshape(b * h * r * w * r, c)
+
+        def image(t, h, w):
+            return t.view(B, h, w, -1).permute(0, 3, 1, 2)
+
+        f = conv(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin), self.conv_first)
+        z = F.layer_norm(f, (C,), self.norm_start.weight, self.norm_start.bias, 1e-5)
+        j = 0
+        for si, stage in enumerate(self.layers):
+            r = z
+            for bi, blk in enumerate(stage.blocks):
+                r = self._block_train(r, blk, sched[si][bi], B, H, W, self._dpr[j])
+                j += 1
+            z = conv(r, stage.conv) + z
+        z = F.layer_norm(z, (C,), self.norm_end.weight, self.norm_end.bias, 1e-5)
+        body = conv(z, self.conv_after_body) + f
+        if self.upsampler == "pixelshuffle":
+            y = F.leaky_relu(conv(body, self.conv_before_upsample[0]), 0.01)
+            h, w = H, W
+            r = 3 if self.upscale == 3 else 2
+            for m in self.upsample.up:
+                if isinstance(m, nn.Conv2d):
+                    y = shuffle(conv(y, m, B, h, w), B, h, w, r)
+                    h, w = h * r, w * r
+            y = image(conv(y, self.conv_last, B, h, w), h, w)
+        elif self.upsampler == "pixelshuffledirect":
+            y = image(shuffle(conv(body, self.upsample.up[0]), B, H, W, s), H * s, W * s)
+        elif self.upsampler == "nearest+conv":
+            def up2(t, h, w):
+                return t.view(B, h, 1, w, 1, -1).expand(B, h, 2, w, 2, t.shape[1]).reshape(B * 4 * h * w, -1)
+
+            y = F.leaky_relu(conv(body, self.conv_before_upsample[0]), 0.01)
+            y = F.leaky_relu(conv(up2(y, H, W), self.conv_up1, B, 2 * H, 2 * W), 0.2)
+            y = F.leaky_relu(conv(up2(y, 2 * H, 2 * W), self.conv_up2, B, 4 * H, 4 * W), 0.2)
+            y = F.leaky_relu(conv(y, self.conv_hr, B, 4 * H, 4 * W), 0.2)
+            y = image(conv(y, self.conv_last, B, 4 * H, 4 * W), 4 * H, 4 * W)
+        else:
+            y = image(conv(body, self.conv_last), H, W)
+            if self.in_channels == self.out_channels:
+                y = x + y
+        y = y / self.img_range + mean
+        return AG.GradScaleTop.apply(y[:, :, : H0 * s, : W0 * s].contiguous())
+
     @staticmethod
     def _tokens(x, cpad):
         """(B, C, H, W) -> channels-last token matrix [B*H*W, cpad] (zero padded)."""
@@ -706,7 +846,7 @@ class GRL(nn.Module):
         """grl.py:506-551.  Eager launch sequence, or a captured HIP graph (``enable_graph`` / GRL_GRAPH=1)."""
         if getattr(self, "_use_graph", None) is None:
             self._use_graph, self._graphs = os.environ.get("GRL_GRAPH", "0") == "1", {}
-        if not (self._use_graph and x.is_cuda) or ops.profiling():
+        if not (self._use_graph and x.is_cuda) or ops.profiling() or torch.is_grad_enabled():
             return self._forward_eager(x)
         key = (tuple(x.shape), x.dtype, str(x.device))
         stamp = self._param_stamp()
@@ -736,9 +876,9 @@ class GRL(nn.Module):
                 "grl_image_restoration_amd.GRL runs only on an AMD GPU (MI355X/gfx950): got a CPU tensor and "
                 "there is deliberately no CPU fallback"
             )
-        if self.training and torch.is_grad_enabled():
-            raise NotImplementedError("training (backward) through the HIP path is not available yet")
         L.lib()  # fail loudly if the extension is missing
+        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self._forward_train(x)      # autograd path: every contraction, forward and backward, in libgrl_hip.so
         H0, W0 = x.shape[2:]
         x = self.check_image_size(x.float())
         mean = self._mean.to(x.device, x.dtype)

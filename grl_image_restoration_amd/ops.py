@@ -102,6 +102,8 @@ def linear(
     M: Optional[int] = None,
     planes: bool = False,
     a_split: int = 1,
+    a_scale: float = 1.0,
+    out_scale: float = 1.0,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
@@ -143,7 +145,7 @@ def linear(
         res_scale=res_scale, resid=_ptr(resid), ldr=resid.stride(0) if resid is not None else 0,
         add2=_ptr(add2), add2_dtype=_KIND[add2.dtype] if add2 is not None else 0,
         ldadd2=add2.stride(0) if add2 is not None else 0,
-        add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split,
+        add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split, a_scale=a_scale, out_scale=out_scale,
         out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
     )
     if epi == L.EPI_GROUPNORM:
@@ -412,7 +414,7 @@ def pack_conv_bias(b: torch.Tensor, cout_pad: int, shuffle_r: int = 0, shuffle_c
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int, *, act: int = 0,
             slope: float = 0.0, resid: Optional[torch.Tensor] = None, want_pool: bool = False,
             out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0,
-            x_split: int = 1):
+            x_split: int = 1, x_scale: float = 1.0, out_scale: float = 1.0):
     """3x3 conv (stride 1, pad 1) on a channels-last token matrix x[B*H*W, >=CinP]; w packed by
     pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool)."""
     _dev_check(x, w, bias, resid, out)
@@ -447,7 +449,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             x=_ptr(x), x_dtype=_KIND[x.dtype], ldx=x.stride(0),
             w=C.c_void_p(w.data_ptr() + c0 * CinP * 2), w_tap_stride=CoutP * CinP,
             bias=C.c_void_p(bias.data_ptr() + c0 * 4),
-            B=B, H=H, W=W, CinP=CinP, CoutP=step, x_split=x_split, act=act, slope=slope,
+            B=B, H=H, W=W, CinP=CinP, CoutP=step, x_split=x_split, x_scale=x_scale, out_scale=out_scale, act=act, slope=slope,
             resid=C.c_void_p(resid.data_ptr() + c0 * 4) if resid is not None else C.c_void_p(0),
             ldr=resid.stride(0) if resid is not None else 0,
             pool_partial=C.c_void_p(pool.data_ptr() + c0 * 4) if pool is not None else C.c_void_p(0), pool_stride=CoutP,
@@ -470,3 +472,49 @@ def se_scale(pool: torch.Tensor, B: int, CP: int, C_: int, HW: int, w1, b1, w2, 
         "grl_se_scale_fwd",
     )
     return scale
+
+
+# ---- training path (BASELINE config 5): the contractions of the backward pass and the optimizer step --------------------
+def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, hw: Optional[Tuple[int, int]] = None,
+            a_scale: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
+    """c[taps, N, K] = out_scale * sum_m (a_scale * a[m, :N])^T b[row(m, tap), :K]  (grl_gemm_tn): the weight gradient of a
+    token-wise linear (taps=1) or of a 3x3 convolution on channels-last pixel matrices (taps=9, hw=(H, W))."""
+    _dev_check(a, b)
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype in (torch.float32, torch.float16)
+    assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0] and a.shape[1] >= N and b.shape[1] >= K
+    M = a.shape[0]
+    H, W = hw if hw is not None else (0, 0)
+    c = torch.zeros(taps, N, K, dtype=torch.float32, device=a.device)
+    tiles = ((N + 63) // 64) * ((K + 63) // 64) * taps
+    splits = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))   # >= ~1000 workgroups, >= 256 rows each
+    args = L.GrlGemmTnArgs(a=_ptr(a), lda=a.stride(0), b=_ptr(b), b_dtype=_KIND[b.dtype], ldb=b.stride(0), M=M, N=N, K=K, taps=taps,
+                           H=H, W=W, splits=splits, a_scale=a_scale, out_scale=out_scale, c=_ptr(c), ldc=K, c_tap_stride=N * K)
+    with _timed("gemm_tn"):
+        L.check(L.lib().grl_gemm_tn(L.stream_ptr(), C.byref(args)), "grl_gemm_tn")
+    return c
+
+
+def _attn_args(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, B, nh, table, masked, ones_col, head_dim, k_one31, lazy_floor, lse):
+    nwy, nwx = q.Himg // q.wh, q.Wimg // q.ww
+    return L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
+                         trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), ones_col=ones_col,
+                         head_dim=head_dim, out_dtype=_KIND[o.t.dtype], k_one31=int(k_one31), lazy_floor=_ptr(lazy_floor),
+                         lse=_ptr(lse), lse_stride=lse.stride(0) if lse is not None else 0)
+
+
+def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: torch.Tensor, lse: torch.Tensor, *, B: int, nh: int,
+                  table: torch.Tensor, masked: bool, ones_col: int, head_dim: int, g_scale: float):
+    """Gradients of grl_attention_fwd w.r.t. its operands: (d_q, d_k, d_v, d_table), fp32, laid out like q, k, v (fp32 planes of
+    the same shape) and table.  ``o``: the forward output grid (fp32), ``d_o`` its gradient (same layout), ``lse`` from the forward."""
+    _dev_check(q.t, k.t, v.t, o.t, d_o, lse, table)
+    assert o.t.dtype == torch.float32 and d_o.dtype == torch.float32 and d_o.shape == o.t.shape and d_o.is_contiguous() and o.t.is_contiguous()
+    assert q.t.is_contiguous() and k.t.is_contiguous() and v.t.is_contiguous() and q.slot == 0 and k.slot == 0 and v.slot == 0 and o.slot == 0
+    d_q = torch.zeros(q.t.shape, dtype=torch.float32, device=q.t.device)
+    d_k = torch.zeros(k.t.shape, dtype=torch.float32, device=q.t.device)
+    d_v = torch.zeros(v.t.shape, dtype=torch.float32, device=q.t.device)
+    d_table = torch.zeros_like(table)
+    fwd = _attn_args(q, k, v, o, B, nh, table, masked, ones_col, head_dim, False, None, lse)
+    args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale)
+    with _timed("attention_bwd"):
+        L.check(L.lib().grl_attention_bwd(L.stream_ptr(), C.byref(args)), "grl_attention_bwd")
+    return d_q, d_k, d_v, d_table

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 10
+#define GRL_ABI_VERSION 11
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -67,6 +67,9 @@ typedef struct GrlLinearArgs {
                             /* and the kernel stages A (fp32) as [hi(a) | lo(a) | hi(a)], hi = fp16(a),         */
                             /* lo = fp16(a - hi); the caller packs W as [hi(w) | hi(w) | lo(w)]: the product    */
                             /* carries ~22 mantissa bits at 3x the MFMA work (small, error-amplifying models)   */
+    float a_scale;          /* 0 means 1: fp32 A is multiplied by this before its conversion to fp16 and the          */
+    float out_scale;        /* accumulator (before bias / epilogue) by out_scale (0 means 1): the backward pass feeds  */
+                            /* gradients as A, pre-scaled into fp16 range, and un-scales the product                  */
     void* out;              /* [M, ldo]: GRL_DT_F32 or GRL_DT_F16 (attention operands, planes)       */
     int32_t out_dtype;
     int64_t ldo;
@@ -242,6 +245,8 @@ typedef struct GrlConvArgs {
     int32_t CinP, CoutP;    /* CinP % 32 == 0, CoutP % 16 == 0, CoutP <= 192 per call               */
     int32_t x_split;        /* 1 (0 means 1) or 3: split-precision operands as in GrlLinearArgs.a_split: CinP =     */
                             /* 3 * CinSrc, x (fp32, CinSrc wide) is staged as [hi | lo | hi], w packed [hi | hi | lo] */
+    float x_scale;          /* 0 means 1: fp32 x is multiplied by this before its conversion to fp16, the accumulator */
+    float out_scale;        /* (before bias) by out_scale (0 means 1) -- gradient inputs of the backward pass         */
     int32_t act;            /* 0 none, 1 exact GELU, 2 LeakyReLU(slope)                             */
     float slope;
     const float* resid;     /* optional fp32 [B*H*W, ldr] added after the activation                */
@@ -297,6 +302,74 @@ typedef struct GrlLnResArgs {
 } GrlLnResArgs;
 
 int grl_layernorm_res_fwd(void* stream, const GrlLnResArgs* args);
+
+/* ---------------------------------------------------------------------------------------------
+ * Training path (BASELINE config 5; reference: engines/base.py:221-236, autograd through the modules above).
+ *
+ * The data gradients of the linears and convolutions re-use grl_linear_fwd / grl_conv3x3_fwd with transposed / flipped
+ * weights (a_scale / x_scale bring the fp32 gradients into fp16 range).  The entry points below are the remaining
+ * contractions of the backward pass and the optimizer step.
+ * ------------------------------------------------------------------------------------------- */
+
+/* Weight gradient: c[tap][n][k] += out_scale * sum_m (a_scale * a[m][n]) * b[row(m, tap)][k]   (fp32 atomics; zero c first)
+ *   taps = 1: row = m (token-wise linear: dW = dY^T X)
+ *   taps = 9: 3x3 convolution, a / b are [images*H*W, ld] channels-last pixel matrices, tap = (dy+1)*3 + (dx+1),
+ *             row = pixel (y + dy, x + dx) of the same image, zero outside: dW[tap][co][ci]                          */
+typedef struct GrlGemmTnArgs {
+    const float* a;         /* [M, lda] fp32 (output gradient)                                      */
+    int64_t lda;
+    const void* b;          /* [M, ldb] GRL_DT_F32 or GRL_DT_F16 (the layer's input)                */
+    int32_t b_dtype;
+    int64_t ldb;
+    int32_t M, N, K;        /* N, K multiples of 8                                                  */
+    int32_t taps, H, W;     /* 1, or 9 with the image size                                          */
+    int32_t splits;         /* M is cut into this many slabs (one workgroup column each)            */
+    float a_scale, out_scale;
+    float* c;               /* [taps][N][ldc] fp32                                                  */
+    int64_t ldc, c_tap_stride;
+} GrlGemmTnArgs;
+
+int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args);
+
+/* Cosine attention backward (flash-style recompute from q, k, v, the forward's output and its log2-sum-exp2):
+ *   replaces autograd through Attention.attn / AffineTransform  models/common/mixed_attn_block_efficient.py:36-58,77-94
+ * Inputs as grl_attention_fwd (`fwd`: the same argument block, o = the forward OUTPUT (GRL_DT_F32), lse required) plus the
+ * output gradient d_o (fp32, o's grid).  Outputs (fp32, gradients w.r.t. the kernel's own operands -- the normalisation,
+ * the logit scale and the CPB-MLP are differentiated by the caller): d_q, d_k, d_v on the grids of q, k, v (same
+ * ld / hstride / col0 in ELEMENTS as the fp16 operands), d_table [nh, tstride] (accumulated with atomics: zero it first).
+ * g_scale brings d_o into fp16 range for the contractions (results are un-scaled). */
+typedef struct GrlAttnBwdArgs {
+    GrlAttnArgs fwd;
+    const float* d_o;
+    float* d_q;
+    float* d_k;
+    float* d_v;
+    float* d_table;
+    float g_scale;
+} GrlAttnBwdArgs;
+
+int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args);
+
+/* torch.optim.AdamW over a list of fp32 tensors in one launch (config/optimizer/adamw.yaml):
+ *   w *= 1 - lr*wd;  m = b1 m + (1-b1) g;  v = b2 v + (1-b2) g^2;  w -= lr/bc1 * m / (sqrt(v)/sqrt(bc2) + eps)
+ * Host-built work list: chunk c covers elements [chunk_offset[c], +4096) of tensor chunk_tensor[c].  All pointer arrays
+ * live in DEVICE memory. */
+typedef struct GrlAdamWArgs {
+    void* const* params;
+    const void* const* grads;
+    void* const* exp_avg;
+    void* const* exp_avg_sq;
+    const int64_t* numel;
+    const int32_t* weight_decay_flags;   /* optional per tensor: 0 = no decay                        */
+    const int32_t* chunk_tensor;
+    const int64_t* chunk_offset;
+    int32_t num_chunks;
+    float lr, beta1, beta2, eps, weight_decay;
+    float bias_correction1, bias_correction2_sqrt;
+    float grad_scale;                    /* gradients are multiplied by this (1 / loss scale, DDP averaging) */
+} GrlAdamWArgs;
+
+int grl_adamw_step(void* stream, const GrlAdamWArgs* args);
 
 /* Library self-description (used by the loader to refuse a stale build). */
 int grl_abi_version(void);

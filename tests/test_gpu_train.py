@@ -1,0 +1,193 @@
+"""GPU parity of the training path (BASELINE config 5): backward kernels, autograd wiring, optimizer step -- needs the MI355X.
+
+Checkers: torch fp32/fp64 autograd on the CPU for the single ops, oracle/backward_math.py (pinned against autograd through the
+oracle's attention) for the attention backward, and the frozen gradients of one L1 training step of the REAL reference
+(tests/golden_grads/train_base2x2_sr4_64.npz) for the whole network.  Tolerance: gradients are contracted on fp16 operands
+(like the forward): 1e-2 relative (norm-wise) per tensor.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import backward_math as BM
+from oracle import grl_oracle as O
+
+pytestmark = pytest.mark.gpu
+LOG2E = 1.4426950408889634
+
+
+def _rel(a, b):
+    return ((a.double().cpu() - b.double().cpu()).norm() / b.double().cpu().norm().clamp_min(1e-30)).item()
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 180, 540), (513, 64, 192), (700, 360, 180), (300, 90, 90)])
+def test_linear_fn_gradients(M, K, N):
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(41)
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = 0.1 * torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g) * 1e-6          # L1-loss-sized gradients: below the fp16 normal range
+    xr, wr, br = (t.clone().double().requires_grad_(True) for t in (x, w, b))
+    (F.linear(xr, wr, br) * dy.double()).sum().backward()
+    xd, wd, bd = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    y = AG.GradScaleTop.apply(AG.linear(xd, wd, bd))
+    assert _rel(y, F.linear(x.double(), w.double(), b.double())) < 2e-3
+    y.backward(dy.cuda())
+    assert _rel(xd.grad, xr.grad) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 1e-5
+    assert AG.grad_scale() > 1e4                         # the pass was scaled into fp16 range
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 20, 45, 180, 180), (1, 16, 32, 180, 45), (2, 12, 20, 45, 180), (1, 17, 33, 3, 64), (1, 16, 16, 64, 3)])
+def test_conv3x3_fn_gradients(B, H, W, Cin, Cout):
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(42)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+    b = 0.1 * torch.randn(Cout, generator=g)
+    dy = torch.randn(B, Cout, H, W, generator=g) * 1e-5
+    xr, wr, br = (t.clone().double().requires_grad_(True) for t in (x, w, b))
+    (F.conv2d(xr, wr, br, padding=1) * dy.double()).sum().backward()
+    tok = lambda t: t.permute(0, 2, 3, 1).reshape(-1, t.shape[1]).contiguous()
+    xd = tok(x).cuda().requires_grad_(True)
+    wd, bd = w.clone().cuda().requires_grad_(True), b.clone().cuda().requires_grad_(True)
+    y = AG.GradScaleTop.apply(AG.conv3x3(xd, wd, bd, B, H, W))
+    assert _rel(y, tok(F.conv2d(x.double(), w.double(), b.double(), padding=1))) < 2e-3
+    y.backward(tok(dy).cuda())
+    assert _rel(xd.grad, tok(xr.grad)) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 1e-5
+
+
+ATT_CASES = [
+    # name, mode, (H, W), window/stripe, shift, df, nh, d
+    ("win8_shift", "w", (16, 16), (8, 8), (4, 4), 1, 3, 30),
+    ("win32_shift", "w", (64, 64), (32, 32), (16, 16), 1, 3, 30),
+    ("win12_ragged", "w", (24, 36), (12, 12), (6, 6), 1, 3, 30),
+    ("win16_d32", "w", (32, 32), (16, 16), (0, 0), 1, 2, 32),
+    ("a2w_64_df2", "a2w", (64, 64), (64, 64), (32, 32), 2, 3, 30),
+    ("w2a_64_df2", "w2a", (64, 64), (64, 64), (32, 32), 2, 3, 30),
+    ("a2w_48x96_df4", "a2w", (48, 96), (48, 96), (24, 48), 4, 2, 16),
+    ("w2a_8x16_df4", "w2a", (16, 32), (8, 16), (4, 8), 4, 3, 30),
+]
+
+
+@pytest.mark.parametrize("case", ATT_CASES, ids=[c[0] for c in ATT_CASES])
+def test_attention_fn_gradients(case):
+    """AttentionFn (grl_attention_fwd + grl_attention_bwd) inside the same torch glue the model uses (normalise, scale, table)
+    against the closed-form backward of oracle/backward_math.py on the reference's partitioned windows."""
+    from grl_image_restoration_amd import autograd as AG, tables
+    from tests.test_gpu_kernels import _windows
+
+    name, mode, (H, W), win, shift, df, nh, d = case
+    B = 2
+    g = torch.Generator().manual_seed(43)
+    awin, ashift = (win[0] // df, win[1] // df), (shift[0] // df, shift[1] // df)
+    Ha, Wa = H // df, W // df
+    if mode == "w":
+        qg = kg = (H, W, win, shift)
+    elif mode == "a2w":
+        qg, kg = (Ha, Wa, awin, ashift), (H, W, win, shift)
+    else:
+        qg, kg = (H, W, win, shift), (Ha, Wa, awin, ashift)
+    Mq, Mk = B * qg[0] * qg[1], B * kg[0] * kg[1]
+    q = torch.randn(Mq, nh, d, generator=g)
+    k = torch.randn(Mk, nh, d, generator=g)
+    v = torch.randn(Mk, nh, d, generator=g)
+    scale_raw = torch.log(torch.rand(nh, generator=g) * 12 + 4)
+    rows = (qg[2][0] + kg[2][0] - 1) * (qg[2][1] + kg[2][1] - 1)
+    bias = torch.rand(rows, nh, generator=g) * 16
+    dO = torch.randn(Mq, nh, d, generator=g) * 1e-5
+    masked = shift[0] > 0 or shift[1] > 0
+    if mode == "w":
+        index, mask = O.rel_index(win), (O.shift_mask((H, W), win, shift, mode="w") if masked else None)
+    else:
+        index, mask = O.rel_index(win, df, mode == "w2a"), (O.shift_mask((H, W), win, shift, df, mode) if masked else None)
+
+    # reference: partition into windows exactly like the oracle's attention, closed-form backward, scatter back
+    def part(t, gg):
+        x = t.view(B, gg[0], gg[1], nh * t.shape[-1])
+        if gg[3][0] or gg[3][1]:
+            x = torch.roll(x, shifts=(-gg[3][0], -gg[3][1]), dims=(1, 2))
+        return O.partition(x, gg[2]).reshape(-1, gg[2][0] * gg[2][1], nh, t.shape[-1]).permute(0, 2, 1, 3)
+
+    def unpart(t, gg):   # (B_, nh, N, c) -> (tokens, nh, c)
+        c = t.shape[-1]
+        x = O.unpartition(t.permute(0, 2, 1, 3).reshape(-1, gg[2][0], gg[2][1], nh * c), gg[2], (gg[0], gg[1]))
+        if gg[3][0] or gg[3][1]:
+            x = torch.roll(x, shifts=(gg[3][0], gg[3][1]), dims=(1, 2))
+        return x.reshape(-1, nh, c)
+
+    dq_r, dk_r, dv_r, dsc_r, dbias_r = BM.attention_backward(part(q, qg).double(), part(k, kg).double(), part(v, kg).double(),
+                                                             part(dO, qg).double(), scale_raw.double(), bias.double(), index, mask)
+    dq_r, dk_r, dv_r = unpart(dq_r, qg), unpart(dk_r, kg), unpart(dv_r, kg)
+
+    dev = "cuda"
+    qd, kd, vd, sd, bd = (t.clone().to(dev).requires_grad_(True) for t in (q, k, v, scale_raw, bias))
+    P = lambda t: F.pad(t, (0, 32 - t.shape[-1])).permute(1, 0, 2).contiguous()
+    sc = torch.clamp(sd, max=math.log(100.0)).exp() * LOG2E
+    geo = dict(q=(qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]), k=(kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
+               B=B, nh=nh, d=d, masked=masked, floor=tables.lazy_floor(sc.detach() / LOG2E))
+    o = AG.AttentionFn.apply(P(F.normalize(qd, dim=-1) * sc.view(1, nh, 1)), P(F.normalize(kd, dim=-1)), P(vd), tables.kernel_table(bd), geo)
+    out = AG.GradScaleTop.apply(o.permute(1, 0, 2)[..., :d])
+    out.backward(dO.to(dev))
+    errs = dict(dq=_rel(qd.grad, dq_r), dk=_rel(kd.grad, dk_r), dv=_rel(vd.grad, dv_r), dscale=_rel(sd.grad, dsc_r), dbias=_rel(bd.grad, dbias_r))
+    print(name, {k_: f"{v_:.2e}" for k_, v_ in errs.items()})
+    assert max(errs.values()) < 1e-2, errs
+
+
+def test_gemm_tn_matches_torch():
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(44)
+    M, N, K = 5000, 192, 96
+    a, b = torch.randn(M, N, generator=g) * 1e-4, torch.randn(M, K, generator=g)
+    c = ops.gemm_tn(a.cuda(), b.cuda(), N, K, a_scale=4096.0, out_scale=1.0 / 4096.0)[0].cpu()
+    assert _rel(c, a.double().t() @ b.double()) < 2e-3
+    c16 = ops.gemm_tn(a.cuda(), b.cuda().half(), N, K, a_scale=4096.0, out_scale=1.0 / 4096.0)[0].cpu()
+    assert _rel(c16, a.double().t() @ b.double()) < 2e-3
+
+
+def _grad_fixture():
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_grads", "train_base2x2_sr4_64.npz")
+    z = np.load(path, allow_pickle=False)
+    return json.loads(str(z["meta"])), z
+
+
+def test_training_step_gradients_match_reference():
+    """One L1 training step of GRL-Base blocks (x4 SR, 64x64 LQ, eval mode as in the fixture): loss, input gradient, the norm
+    of all 156 parameter gradients and every small gradient tensor against the REAL reference (find_unused_parameters=False
+    holds: every parameter receives a gradient)."""
+    from grl_image_restoration_amd import GRL
+
+    meta, z = _grad_fixture()
+    cfg = meta["cfg"]
+    m = GRL(**cfg).eval()
+    sd = O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, meta["weight_seed"])
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    x = torch.from_numpy(z["input"]).cuda().requires_grad_(True)
+    gt = torch.from_numpy(z["target"]).cuda()
+    loss = (m(x) - gt).abs().mean()
+    loss.backward()
+    assert abs(loss.item() - meta["loss"]) < 2e-4, (loss.item(), meta["loss"])
+    assert _rel(x.grad, torch.from_numpy(z["grad_input"])) < 2e-2
+    names = json.loads(str(z["grad_norm_names"]))
+    grads = {k: p.grad for k, p in m.named_parameters()}
+    assert set(names) == set(grads) and all(g is not None for g in grads.values())
+    worst = ("", 0.0)
+    for k, n in zip(names, z["grad_norms"]):
+        e = abs(grads[k].norm().item() - n) / max(n, 1e-12)
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 1e-2, (k, e)
+    small = [k for k in z.files if k.startswith("grad::")]
+    for k in small:
+        e = _rel(grads[k[6:]], torch.from_numpy(z[k]))
+        worst = max(worst, (k, e), key=lambda t: t[1])
+        assert e < 2e-2, (k, e)
+    print(f"training step: loss {loss.item():.6f} (reference {meta['loss']:.6f}); worst gradient error {worst}")
