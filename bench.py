@@ -20,6 +20,9 @@ The timed region contains no probes.  After it, separate untimed passes collect
                    checkpoint looks like): the fast attention kernels must stay selected (ratio ~ 1)
   tiled          : (N > 1) strong-scaling leg: tiling.forward_tiled of a fixed 8 x N-tile list, sharded over the ranks
                    with its RCCL all-gather
+  training       : BASELINE configs[4] in short: GRL-Base x4 SR training steps on 64x64 LQ patches, batch 8 per GPU, L1 loss,
+                   autograd over the HIP kernels + FusedAdamW (one launch for the 1390 tensors); N > 1: DistributedDataParallel
+                   over RCCL (bucketed gradient all-reduce overlapped with the backward pass)
   cpu_baseline   : the CPU oracle (a torch-fp32 port of the reference forward) on this box's host cores: a
                    128x128 LQ tile of the same network (1/4 of a bench tile), 1 warm-up + median of 2, thread
                    count picked by a sweep on a 64x64 tile.
@@ -133,6 +136,61 @@ def timed_steps(model, x, steps, world):
     return dt, y
 
 
+def training_leg(args, dev, rank, world):
+    """A few optimizer steps of BASELINE configs[4] (reference: engines/base.py:221-236, tools/trainer.py:135-142,
+    config/optimizer/adamw.yaml, config/loss/l1.yaml) on synthetic pairs."""
+    from grl_image_restoration_amd import GRL, FusedAdamW, baseline_config, ddp, ops
+
+    cfg = baseline_config(5)
+    torch.manual_seed(0)
+    model = GRL(**cfg).to(dev).train()
+    net = ddp.wrap(model, device=dev, bucket_mb=32) if world > 1 else model
+    opt = FusedAdamW(model.parameters(), lr=2e-4, weight_decay=1e-4)
+    bsz, side, sc = args.train_batch, 64, cfg["upscale"]
+    g = torch.Generator().manual_seed(100 + rank)
+    lq = torch.rand(bsz, 3, side, side, generator=g).to(dev)
+    gt = torch.rand(bsz, 3, side * sc, side * sc, generator=g).to(dev)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        loss = (net(lq) - gt).abs().mean()
+        loss.backward()
+        opt.step()
+        return loss
+
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.train_steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert math.isfinite(float(loss.detach()))
+    ops.profile_begin()
+    step()
+    prof = ops.profile_end()
+    kern = {k: round(sum(v), 3) for k, v in sorted(prof.items(), key=lambda kv: -sum(kv[1]))}
+    return {
+        "workload": "BASELINE configs[4]: GRL-Base x4 SR training, 64x64 LQ synthetic pairs, L1 loss, FusedAdamW(lr 2e-4, wd 1e-4)",
+        "batch_per_gpu": bsz, "steps": args.train_steps, "ms_per_step": round(dt / args.train_steps * 1e3, 2),
+        "samples_per_s": round(world * bsz * args.train_steps / dt, 2),
+        "value": round(world * bsz * side * side * args.train_steps / dt / 1e6, 4), "unit": "LQ megapixels/s (training)",
+        "parallelism": f"DDP x{world} over RCCL, 32 MB gradient buckets" if world > 1 else "single GPU",
+        "hip_kernel_ms_per_step": kern, "final_loss": round(float(loss.detach()), 5),
+    }
+
+
 def run(args, rank, world, local_rank):
     if world > 1:
         torch.cuda.set_device(local_rank)
@@ -209,6 +267,13 @@ def run(args, rank, world, local_rank):
                  "value": round(n_t * side * side * 3 / dt_s / 1e6, 4), "unit": "LQ megapixels/s", "scaling": "strong",
                  "collective": f"all_gather_into_tensor of {n_t // world} x (3, {side * scale}, {side * scale}) fp32 tiles per rank (RCCL)"}
 
+    precision_mode = model.precision
+    training = None
+    if not args.no_train and args.config == 3:
+        del model, x, y
+        torch.cuda.empty_cache()
+        training = training_leg(args, dev, rank, world)
+
     if rank == 0:
         mp = world * args.tiles * side * side * args.steps / dt / 1e6
         att = prof.get("attention", [])
@@ -225,7 +290,7 @@ def run(args, rank, world, local_rank):
             "tiles_per_gpu_per_step": args.tiles,
             "hr_megapixels_per_s": round(mp * scale * scale, 2),
             "parallelism": f"tile-sharded x{world}, no data-path collective",
-            "precision_mode": model.precision,
+            "precision_mode": precision_mode,
         }
         if gflop_tile:
             conf.update(gflop_per_tile=gflop_tile, model_tflops=round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12, 2))
@@ -265,6 +330,8 @@ def run(args, rank, world, local_rank):
             line["trained_scales"] = trained
         if tiled:
             line["tiled"] = tiled
+        if training:
+            line["training"] = training
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
@@ -290,6 +357,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trained-scales", action="store_true")
     ap.add_argument("--no-tiled", action="store_true")
+    ap.add_argument("--no-train", action="store_true")
+    ap.add_argument("--train-steps", type=int, default=3)
+    ap.add_argument("--train-batch", type=int, default=8, help="64x64 LQ patches per GPU per training step")
     args = ap.parse_args()
 
     env_world = os.environ.get("WORLD_SIZE")

@@ -2,7 +2,7 @@
 //
 // Replaces autograd through Attention.attn + AffineTransform (models/common/mixed_attn_block_efficient.py:36-58,77-94)
 // inside WindowAttention / AnchorStripeAttention (:128-165, :215-270) in the reference's training step
-// (engines/base.py:221-236).  Closed form (oracle/backward_math.py, pinned against autograd), in the kernel's own operands
+// (engines/base.py:221-236).  Closed form (the tests check it against autograd), in the kernel's own operands
 //   S_ij = q~_i . k^_j + table[idx(i,j)] (+ mask)        (log2 domain; q~ carries scale*log2e)
 //   P_ij = exp2(S_ij - lse_i)                             (lse from the forward kernel)
 //   D_i  = sum_c dO_ic O_ic          dP_ij = dO_i . v_j          dS_ij = ln2 * P_ij (dP_ij - D_i)

@@ -464,10 +464,10 @@ class GRL(nn.Module):
                 cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO, split=sp), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
                 cab2_w=ops.pack_conv_weight(c2.weight.to(dev), CmI, CP, split=sp), cab2_b=ops.pack_conv_bias(c2.bias.to(dev), CP),
                 cab_mid=CmI,
-                se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).contiguous().to(dev),
-                se1_b=se[1].bias.detach().float().to(dev),
-                se3_w=se[3].weight.detach().float().reshape(C, -1).contiguous().to(dev),
-                se3_b=se[3].bias.detach().float().to(dev),
+                se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).to(dev).clone(),   # copies: a plan never aliases
+                se1_b=se[1].bias.detach().float().to(dev).clone(),                                        # the live parameters
+                se3_w=se[3].weight.detach().float().reshape(C, -1).to(dev).clone(),
+                se3_b=se[3].bias.detach().float().to(dev).clone(),
             )
         return pk
 

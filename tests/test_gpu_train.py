@@ -191,3 +191,67 @@ def test_training_step_gradients_match_reference():
         worst = max(worst, (k, e), key=lambda t: t[1])
         assert e < 2e-2, (k, e)
     print(f"training step: loss {loss.item():.6f} (reference {meta['loss']:.6f}); worst gradient error {worst}")
+
+
+def test_fused_adamw_matches_torch():
+    from grl_image_restoration_amd import FusedAdamW
+
+    g = torch.Generator().manual_seed(45)
+    shapes = [(180, 180), (540,), (1,), (64, 180, 3, 3), (3, 1, 1), (5000,), (4096,), (4097,)]
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    pa = [t.clone().cuda().requires_grad_(True) for t in p0]
+    pb = [t.clone().cuda().requires_grad_(True) for t in p0]
+    kw = dict(lr=2e-4, weight_decay=1e-4)                      # config/optimizer/adamw.yaml
+    oa, ob = FusedAdamW(pa, **kw), torch.optim.AdamW(pb, **kw)
+    for step in range(4):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (10.0 ** -step)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() <= 2e-6 * max(1.0, b.abs().max().item())
+    sa, sb = oa.state[pa[0]], ob.state[pb[0]]
+    assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-4, atol=1e-8) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-4, atol=1e-10)
+    assert pa[0]._version > 0                                  # the raw-pointer update is visible to autograd / plan stamps
+
+
+def test_train_mode_steps_reduce_the_loss_and_inference_sees_the_update():
+    """model.train(): stochastic depth is honoured (mixed_attn_block_efficient.py:500, grl.py:299-300), a few FusedAdamW steps on
+    one batch reduce the L1 loss, and the inference path afterwards runs on the UPDATED weights (plan version stamp) and agrees
+    with the differentiable path."""
+    from grl_image_restoration_amd import GRL, FusedAdamW, make_config
+
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[2, 2], num_heads_window=[3, 3], num_heads_stripe=[3, 3])
+    torch.manual_seed(0)
+    m = GRL(**cfg)
+    sd = O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda().train()
+    assert m._dpr[0] == 0.0 and abs(m._dpr[-1] - 0.1) < 1e-7
+    lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=4, seed=11)
+    lq, gt = lq.cuda(), gt.cuda()
+    with torch.no_grad():
+        before = m(lq).clone()                                   # inference path, initial weights
+    torch.manual_seed(1)
+    y1 = m(lq)
+    torch.manual_seed(2)
+    y2 = m(lq)
+    assert not torch.equal(y1, y2)                               # different stochastic-depth draws
+    opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
+    losses = []
+    for it in range(6):
+        opt.zero_grad(set_to_none=True)
+        loss = (m(lq) - gt).abs().mean()
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+        opt.step()
+        losses.append(loss.item())
+    print("train losses:", [f"{v:.5f}" for v in losses])
+    assert losses[-1] < losses[0]
+    m.eval()
+    with torch.no_grad():
+        after = m(lq)
+    assert (after - before).abs().max().item() > 1e-4             # the fast path picked the new weights up
+    diff = m(lq)                                                  # grad-enabled eval = differentiable path, no drop path
+    assert (after - diff.detach()).abs().max().item() < 1e-3

@@ -113,7 +113,9 @@ def test_ctypes_layout_matches_the_c_header(tmp_path):
     import subprocess
 
     structs = {"GrlLinearArgs": _lib.GrlLinearArgs, "GrlTokenGrid": _lib.GrlTokenGrid, "GrlAttnArgs": _lib.GrlAttnArgs,
-               "GrlConvArgs": _lib.GrlConvArgs, "GrlMlpArgs": _lib.GrlMlpArgs, "GrlQkvArgs": _lib.GrlQkvArgs, "GrlTailArgs": _lib.GrlTailArgs}
+               "GrlConvArgs": _lib.GrlConvArgs, "GrlMlpArgs": _lib.GrlMlpArgs, "GrlQkvArgs": _lib.GrlQkvArgs, "GrlTailArgs": _lib.GrlTailArgs,
+               "GrlLnResArgs": _lib.GrlLnResArgs, "GrlGemmTnArgs": _lib.GrlGemmTnArgs, "GrlAttnBwdArgs": _lib.GrlAttnBwdArgs,
+               "GrlAdamWArgs": _lib.GrlAdamWArgs}
     lines = ['#include <stdio.h>', '#include <stddef.h>', '#include "grl_hip.h"', 'int main(void) {']
     for name, st in structs.items():
         lines.append(f'printf("{name} %zu\\n", sizeof({name}));')
