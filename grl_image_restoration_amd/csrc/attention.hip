@@ -368,6 +368,7 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
         }
     }
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+    const bool band16 = (p.k.shx & 15) == 0;   // key-column region bands are aligned to 16 (k.ww % 32 == 0 on this path)
 
     // ---- this wave's unit: query rows QTN*pr .. QTN*pr+QTN-1, segment sg ----
     int unit = qs * upw + wave;
@@ -543,13 +544,25 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
             S[0] = mfma32_f16(kf[1], qf[0][1], S[0]);
             S[1] = mfma32_f16(kf[1], qf[1][1], S[1]);
             if (border) {
+                if (band16) {
+                    // region labels change only at multiples of 16 key columns (shift and window width are multiples of 16):
+                    // keys 0..15 of the tile (accumulator registers 0..7) share one label, keys 16..31 (registers 8..15) another
+                    const int id_lo = ids[0] & 255, id_hi = ids[2] & 255;
 #pragma unroll
-                for (int t = 0; t < 2; ++t)
+                    for (int t = 0; t < 2; ++t) {
+                        const float m_lo = id_lo != idq[t] ? MASK_L2 : 0.f, m_hi = id_hi != idq[t] ? MASK_L2 : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
-                        S[t][r] += idk != idq[t] ? MASK_L2 : 0.f;
+                        for (int r = 0; r < 8; ++r) { S[t][r] += m_lo; S[t][8 + r] += m_hi; }
                     }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 2; ++t)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int idk = (ids[r >> 2] >> (8 * (r & 3))) & 255;
+                            S[t][r] += idk != idq[t] ? MASK_L2 : 0.f;
+                        }
+                }
             }
         };
         auto pair = [&](f16x8 (&kf)[2], f16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
