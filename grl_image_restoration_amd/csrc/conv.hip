@@ -87,7 +87,11 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
         for (int s = tid; s < HALO_H * HALO_W * SEG_ROW; s += CWAVES * 64) {
             const int pix = s / SEG_ROW, cc = s % SEG_ROW;
             const int vch = kc * KC + cc * 8;             // first virtual channel of this 16-B segment
-            const int part = vch / csrc, ch0 = vch - part * csrc;
+            int part = 0, ch0 = vch;
+            if (p.x_split == 3) {                         // (uniform; keeps the integer division out of the common path)
+                part = vch / csrc;
+                ch0 = vch - part * csrc;
+            }
             const int hy = pix / HALO_W, hx = pix % HALO_W;
             const int gy = y0 + hy - 1, gx = x0 + hx - 1;
             gemm_x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -100,9 +104,10 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
                     const float4 a0 = q[0], a1 = q[1];
                     const float e[8] = {a0.x * xsc, a0.y * xsc, a0.z * xsc, a0.w * xsc, a1.x * xsc, a1.y * xsc, a1.z * xsc, a1.w * xsc};
 #pragma unroll
-                    for (int i = 0; i < 8; ++i) {
-                        const f16 h = to_f16(e[i]);
-                        v[i] = part == 1 ? (f16)(e[i] - (float)h) : h;
+                    for (int i = 0; i < 8; ++i) v[i] = to_f16(e[i]);
+                    if (p.x_split == 3 && part == 1) {
+#pragma unroll
+                        for (int i = 0; i < 8; ++i) v[i] = (f16)(e[i] - (float)v[i]);
                     }
                 }
             }
