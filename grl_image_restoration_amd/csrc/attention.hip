@@ -52,14 +52,25 @@ __device__ __forceinline__ void store_o(const GrlAttnArgs& p, const f32x16& O, f
         for (int g = 0; g < 4; ++g)
             *(float4*)(dst + 8 * g) = float4{O[4 * g + 0] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
     } else {
-        f16* dst = (f16*)p.o.ptr + qrow * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
+        // fp16: a lane holds 4 x 4 consecutive head dims (8 B pieces), its partner 32 lanes away the interleaved ones.  The pair
+        // swaps two pieces each so that every lane owns 2 x 8 consecutive dims and issues two 16-B stores instead of four 8-B
+        // ones (the epilogue is store-issue bound: a token's 64-B slot is written by 2 lanes x 2 instructions instead of 2 x 4)
+        uint2 pk[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
-            uint2 pk;
-            pk.x = pack_f16(O[4 * g + 0] * inv, O[4 * g + 1] * inv);
-            pk.y = pack_f16(O[4 * g + 2] * inv, O[4 * g + 3] * inv);
-            *(uint2*)(dst + 8 * g) = pk;
+            pk[g].x = pack_f16(O[4 * g + 0] * inv, O[4 * g + 1] * inv);
+            pk[g].y = pack_f16(O[4 * g + 2] * inv, O[4 * g + 3] * inv);
         }
+        const uint2 sa = half ? pk[0] : pk[1], sb = half ? pk[2] : pk[3];
+        uint2 ra, rb;
+        ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
+        rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
+        f16* dst = (f16*)p.o.ptr + qrow * p.o.ld + p.o.col0 + head * p.o.hstride + 8 * half;
+        // half 0: dims 0-7 = own g0 | partner g0, dims 16-23 = own g2 | partner g2;  half 1: dims 8-15 = partner g1 | own g1, 24-31 likewise
+        const uint4 lo = half ? uint4{ra.x, ra.y, pk[1].x, pk[1].y} : uint4{pk[0].x, pk[0].y, ra.x, ra.y};
+        const uint4 hi = half ? uint4{rb.x, rb.y, pk[3].x, pk[3].y} : uint4{pk[2].x, pk[2].y, rb.x, rb.y};
+        *(uint4*)(dst) = lo;
+        *(uint4*)(dst + 16) = hi;
     }
 }
 
@@ -716,6 +727,7 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
         (p.v.col0 % 8) || (p.o.col0 % 4) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 4))
         return GRL_ERR_BAD_ARG;
     if (p.lse != nullptr && p.lse_stride <= 0) return GRL_ERR_BAD_ARG;
+    if (p.out_dtype == GRL_DT_F16 && ((p.o.ld % 8) || (p.o.col0 % 8) || (p.o.hstride % 8))) return GRL_ERR_BAD_ARG;   // 16-B stores
     hipStream_t st = (hipStream_t)stream;
     // fast path: 32-aligned geometry with the ones column and the lazy running offset (needs the spare head-dim slot 31:
     // K carries 1.0 there, `k_one31`)
