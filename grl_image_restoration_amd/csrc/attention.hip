@@ -17,13 +17,13 @@
 //   With `ones_col`, the softmax denominator is row `ones_col` of O^T.
 //
 // The softmax offset.  P is an fp16 MFMA operand and sub-normal halves are lost to the matrix core, so the weights of a
-// row must sit high in the fp16 range: largest weight of a row between 2^6 and 2^14 leaves >= 20 binades (14 nats) below it.
+// row must sit high in the fp16 range: largest weight of a row between 2^4 and 2^14 leaves >= 18 binades (12 nats) below it.
 // The logit scale is clamped at 100 (efficient.py:39), i.e. logits span +-144 in the log2 domain, and q / k are different
 // projections, so no a-priori bound of the row maximum is tight enough: the offset must follow the data.
 //   lazy   (fast kernel): a running per-query offset m, integer valued, kept in the spare head-dim slot 31 of the Q
 //           fragment (K carries 1.0 there), i.e. it costs no instruction in the loop: S^T = K.Q + bias - m comes out of the
 //           matrix core.  A tile whose largest packed weight reaches 2^14 (packed 16-bit max over the tile + one compare)
-//           takes a rare wave-uniform slow path that raises m so that the tile maximum lands at 2^6, rescales O and redoes
+//           takes a rare wave-uniform slow path that raises m so that the tile maximum lands at 2^4, rescales O and redoes
 //           the tile -- flash-attention's running maximum, evaluated only when needed;
 //   online (generic kernel): ordinary running maximum per tile, weights = exp2(S - max + 14).
 //
@@ -40,7 +40,8 @@ constexpr int QT = 2;            // query tiles per wave
 constexpr int KC = 256;          // keys per LDS chunk
 constexpr int VROW = KC * 2 + 8; // V^T row stride in bytes (pad: conflict-free ds_read_b64)
 constexpr float P_TOP = 14.0f;           // log2 of the largest fp16 weight the kernels produce (fp16 max is 2^16)
-constexpr float LAZY_REST = 6.0f;        // lazy offset: after a rescale the tile maximum sits in (2^5, 2^6]
+constexpr float LAZY_REST = 4.0f;        // lazy offset: after a rescale the tile maximum sits in (2^3, 2^4]
+                                         // (measured: 6 -> 4 costs nothing in parity and saves 9 % at logit scale 100; 2 loses parity margin)
 constexpr unsigned short LAZY_TRIP = 0x7400;   // fp16 bit pattern of 2^14: a packed weight >= this moves the offset
 constexpr unsigned short F16_INF = 0x7C00;
 

@@ -41,12 +41,17 @@ def extract_state_dict(obj: Dict) -> Dict[str, torch.Tensor]:
 def load_checkpoint(model, path_or_obj, strict: bool = True):
     """Load a reference checkpoint into ``model`` (a ``grl_image_restoration_amd.GRL``).  Mirrors tools/trainer.py:93-115:
     geometry buffers (``table_*/index_*/mask_*``, ``relative_*``, ``attn_mask``) are dropped, the Lightning module prefix
-    ``model.`` is removed, the remaining keys must match the module's parameters exactly (``strict``)."""
+    ``model.`` is removed, and -- as trainer.py:106-108 does -- the checkpoint is merged INTO the module's current state before
+    the strict load: a partial checkpoint keeps the current values of the keys it lacks, an unknown key still fails.
+    (The other direction: ``GRL.state_dict()`` has no ``table_/index_/mask_`` buffers, so loading it into the reference module
+    needs ``strict=False`` or the reference's own buffers merged in the same way.)"""
     obj = torch.load(path_or_obj, map_location="cpu") if isinstance(path_or_obj, (str, os.PathLike)) else path_or_obj
     sd = extract_state_dict(obj)
     sd = model.convert_checkpoint(dict(sd))           # needs the un-stripped "model.table_*" names (grl.py:556-569)
     sd = {(k[len("model."):] if k.startswith("model.") else k): v for k, v in sd.items()}
-    return model.load_state_dict(sd, strict=strict)
+    cur = dict(model.state_dict())
+    cur.update(sd)
+    return model.load_state_dict(cur, strict=strict)
 
 
 # ---- metric (restated here: the product does not depend on the test infrastructure) -------------------------------

@@ -640,10 +640,13 @@ class GRL(nn.Module):
         n = self.stream_groups(B)
         if n > 1:
             return self._features_streams(t, plan, B, H, W, n)
-        for si, st in enumerate(plan["stages"]):
+        check = os.environ.get("GRL_CHECK_RANGE", "0") == "1"   # debug: largest residual-stream magnitude per block (fp16 operand
+        for si, st in enumerate(plan["stages"]):                # staging saturates at 65504; this reports how close a checkpoint gets)
             r = t
             for bi, pk in enumerate(st["blocks"]):
                 r = self._block(r, pk, plan["sched"][si][bi], B, H, W)
+                if check:
+                    print(f"GRL_CHECK_RANGE layers.{si}.blocks.{bi}: max|x| = {r.abs().max().item():.4g}  (fp16 operand limit 65504)")
             # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
             t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t, x_split=plan["split"])
         return ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
@@ -653,6 +656,8 @@ class GRL(nn.Module):
         """Number of tile groups / HIP streams a batch of B tiles is processed in (GRL_SPLIT_STREAMS, default 2;
         measured on MI355X: 2 groups +6 % tiles/s over one stream, 4 groups are host-launch bound)."""
         n = int(os.environ.get("GRL_SPLIT_STREAMS", "2"))
+        if os.environ.get("GRL_CHECK_RANGE", "0") == "1":
+            return 1
         return n if n > 1 and B >= n and B % n == 0 else 1
 
     def _features_streams(self, t, plan, B, H, W, n):

@@ -49,10 +49,17 @@ def test_load_checkpoint_formats(fmt, tmp_path):
     assert not res.missing_keys and not res.unexpected_keys
     for k, v in dst.state_dict().items():
         assert torch.equal(v, sd[k]), k
+    part = dict(sd)
+    gone = next(iter(part))
+    part.pop(gone)
+    m2 = GRL(**cfg)
+    keep = m2.state_dict()[gone].clone()
+    EV.load_checkpoint(m2, part)                     # merged into the current state like tools/trainer.py:106-108
+    assert torch.equal(m2.state_dict()[gone], keep)
     bad = dict(sd)
-    bad.pop(next(iter(bad)))
+    bad["not.a.parameter"] = torch.zeros(1)
     with pytest.raises(RuntimeError):
-        EV.load_checkpoint(GRL(**cfg), bad)          # strict, like the reference
+        EV.load_checkpoint(GRL(**cfg), bad)          # strict for unknown keys, like the reference
 
 
 @pytest.mark.gpu
