@@ -320,3 +320,43 @@ def test_ddp_two_replicas_on_the_gpu():
     worst = max(_rel(g0[k], p.grad) for k, p in m.named_parameters())
     print(f"DDP (2 replicas) vs single process, worst relative gradient difference: {worst:.2e}")
     assert worst < 5e-3       # fp32 atomics in the weight-gradient / table reductions and per-pass gradient scales differ
+
+
+@pytest.mark.parametrize("model,geom,up,hw,task", [
+    ("tiny", "yaml", 2, (32, 32), "sr"),            # stripe_groups geometry, head_dim 16, pixelshuffledirect tail, no CAB
+    ("small", "dn_df4", 1, (64, 128), "dn"),        # head_dim 32 (generic attention kernels), window 16, stripes 64x128 / anchors 16x32
+    ("base", "deblur", 1, (48, 96), "deblur"),      # window 12 (ragged key tiles), stripes 48x96 / anchors 12x24, CAB, no upsampler
+])
+def test_training_gradients_other_geometries_vs_oracle_autograd(model, geom, up, hw, task):
+    """Whole-network gradients on the geometries the reference ships besides the SR checkpoint one, against torch autograd through
+    the CPU oracle (itself pinned to the reference's gradients, tests/test_oracle_pinned.py) on two blocks per stage."""
+    from grl_image_restoration_amd import GRL, make_config
+
+    over = dict(depths=[2, 2], num_heads_window=[2, 2] if model != "base" else [3, 3], num_heads_stripe=[2, 2] if model != "base" else [3, 3])
+    cfg = make_config(model, geom, upscale=up, img_size=hw[0], **over)
+    m = GRL(**cfg).eval()
+    sd = O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 3)
+    m.load_state_dict(sd, strict=True)
+    m = m.cuda()
+    lq, gt = O.synthetic_pair(task, hw, up, batch=2, seed=31)
+    lq, gt = lq[..., : hw[0], : hw[1]].contiguous(), gt[..., : hw[0] * up, : hw[1] * up].contiguous()
+    # oracle autograd
+    sdr = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    xr = lq.clone().requires_grad_(True)
+    lo = (O.grl_forward(xr, cfg, sdr) - gt).abs().mean()
+    lo.backward()
+    # HIP path
+    x = lq.cuda().requires_grad_(True)
+    loss = (m(x) - gt.cuda()).abs().mean()
+    loss.backward()
+    assert abs(loss.item() - lo.item()) < 5e-4, (loss.item(), lo.item())
+    errs = {}
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        errs[k] = _rel(p.grad, sdr[k].grad)
+    ex = _rel(x.grad, xr.grad)
+    srt = sorted(errs.items(), key=lambda t: -t[1])
+    med = srt[len(srt) // 2][1]
+    print(f"{model}/{geom}: loss {loss.item():.6f} vs {lo.item():.6f}; d/dx {ex:.2e}; median {med:.2e}; worst {[(k, round(e, 4)) for k, e in srt[:4]]}")
+    # fp16 operands forward and backward: 1e-2 typical; the smallest gradients (CPB-MLP biases of late blocks) up to a few percent
+    assert ex < 5e-2 and med < 1e-2 and srt[0][1] < 6e-2, srt[:4]
