@@ -79,6 +79,9 @@ __device__ __forceinline__ void store_cols(float* base, const GrlTokenGrid& g, i
 // ------------------------------------------------------------------------------------------------
 // dq + dtable
 // ------------------------------------------------------------------------------------------------
+// GHIST: the bias-table gradient goes straight to global memory with atomics (tables whose two LDS copies would not fit:
+// 64x128 stripes with /2 anchors = 73 KB per copy); otherwise an LDS histogram flushed once per workgroup.
+template <bool GHIST>
 __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     const GrlAttnArgs& p = a.fwd;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -97,15 +100,18 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     const int tpad = (p.trows + 3) & ~3;
 
     float* tab = (float*)smem;                         // tpad
-    float* dtab = tab + tpad;                          // tpad (histogram)
-    char* Ks = (char*)(dtab + tpad);                   // KC x 64 B   (rows = keys)
+    float* dtab = tab + tpad;                          // tpad (histogram; absent with GHIST)
+    char* Ks = (char*)(dtab + (GHIST ? 0 : tpad));     // KC x 64 B   (rows = keys)
     char* Vs = Ks + KC * 64;                           // KC x 64 B
     char* Kt = Vs + KC * 64;                           // 32 x TROW   (rows = head dim)
     int* koff = (int*)(Kt + 32 * TROW);                // KC
     unsigned char* kreg = (unsigned char*)(koff + KC); // KC
 
     load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
-    for (int i = tid; i < tpad; i += nthreads) dtab[i] = 0.f;
+    if constexpr (!GHIST)
+        for (int i = tid; i < tpad; i += nthreads) dtab[i] = 0.f;
+    float* gtab = a.d_table + (int64_t)head * p.tstride;
+    const float inv_g = 1.0f / a.g_scale;
 
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
 
@@ -205,7 +211,10 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
                     else if (border && idk != idq[t]) s += MASK_L2;
                     const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
                     dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
-                    if (qvalid[t] && idk != 255) atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
+                    if (qvalid[t] && idk != 255) {
+                        if constexpr (GHIST) unsafeAtomicAdd(gtab + U[t] + kofs[r], dS[r] * inv_g);
+                        else atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
+                    }
                 }
                 f16x8 dsp[2];
                 pack_acc(dS, dsp);
@@ -219,11 +228,12 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < QT; ++t)
         if (qvalid[t]) store_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
-    __syncthreads();
-    float* gt = a.d_table + (int64_t)head * p.tstride;
-    for (int i = tid; i < p.trows; i += nthreads) {
-        const float v = dtab[i];
-        if (v != 0.f) unsafeAtomicAdd(gt + i, v * inv);
+    if constexpr (!GHIST) {
+        __syncthreads();
+        for (int i = tid; i < p.trows; i += nthreads) {
+            const float v = dtab[i];
+            if (v != 0.f) unsafeAtomicAdd(gtab + i, v * inv);
+        }
     }
 }
 
@@ -399,11 +409,14 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
         const int blk = waves * QT * 32;
         const int64_t grid = (int64_t)((Nq + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
-        const size_t lds = 2 * tpad + 2 * (size_t)KC * 64 + 32 * (size_t)TROW + KC * 4 + KC;
+        const size_t rest = 2 * (size_t)KC * 64 + 32 * (size_t)TROW + KC * 4 + KC;
+        const bool ghist = 2 * tpad + rest > 160 * 1024;
+        const size_t lds = (ghist ? 1 : 2) * tpad + rest;
         if (grid > 0x7fffffff || lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
-        hipError_t e = hipFuncSetAttribute((const void*)attn_dq_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        auto kfn = ghist ? attn_dq_kernel<true> : attn_dq_kernel<false>;
+        hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(attn_dq_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a);
+        hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(waves * 64), lds, st, a);
         GRL_CHECK_LAUNCH();
     }
     {

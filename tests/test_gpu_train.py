@@ -74,6 +74,10 @@ ATT_CASES = [
     ("w2a_64_df2", "w2a", (64, 64), (64, 64), (32, 32), 2, 3, 30),
     ("a2w_48x96_df4", "a2w", (48, 96), (48, 96), (24, 48), 4, 2, 16),
     ("w2a_8x16_df4", "w2a", (16, 32), (8, 16), (4, 8), 4, 3, 30),
+    # 64x128 stripes with /2 anchors (denoising Base): the bias table (95 x 191 rows) no longer fits LDS twice -> the dq kernel
+    # accumulates its table gradient in global memory
+    ("w2a_64x128_df2_bigtable", "w2a", (64, 128), (64, 128), (32, 64), 2, 1, 30, 1),
+    ("a2w_64x128_df2_bigtable", "a2w", (64, 128), (64, 128), (32, 64), 2, 1, 30, 1),
 ]
 
 
@@ -84,8 +88,8 @@ def test_attention_fn_gradients(case):
     from grl_image_restoration_amd import autograd as AG, tables
     from tests.test_gpu_kernels import _windows
 
-    name, mode, (H, W), win, shift, df, nh, d = case
-    B = 2
+    name, mode, (H, W), win, shift, df, nh, d = case[:8]
+    B = case[8] if len(case) > 8 else 2
     g = torch.Generator().manual_seed(43)
     awin, ashift = (win[0] // df, win[1] // df), (shift[0] // df, shift[1] // df)
     Ha, Wa = H // df, W // df
