@@ -3,16 +3,18 @@
 The reference trains by plain autograd through its PyTorch modules (engines/base.py:221-236).  Here every contraction of
 the forward AND the backward pass runs in libgrl_hip.so:
 
-  LinearFn     y = x W^T + b      fwd grl_linear_fwd | dx = grl_linear_fwd on (dy, W) | dW = grl_gemm_tn(dy, x)
-  Conv3x3Fn    3x3 conv (pad 1)   fwd grl_conv3x3_fwd | dx = grl_conv3x3_fwd on (dy, flipped W^T) | dW = grl_gemm_tn (9 taps)
-  AttentionFn  cosine attention   fwd grl_attention_fwd (+ log-sum-exp) | grl_attention_bwd (dq, dk, dv, dtable)
+  torch.ops.grl.linear     y = x W^T + b      fwd grl_linear_fwd | dx = grl_linear_fwd on (dy, W) | dW = grl_gemm_tn(dy, x)
+  torch.ops.grl.conv3x3    3x3 conv (pad 1)   fwd grl_conv3x3_fwd | dx = grl_conv3x3_fwd on (dy, flipped W^T) | dW = grl_gemm_tn (9 taps)
+  torch.ops.grl.attention  cosine attention   fwd grl_attention_fwd (+ log-sum-exp) | grl_attention_bwd (dq, dk, dv, dtable)
+
+(torch.library custom ops with registered autograd and fake kernels)
 
 and the element-wise glue between them (LayerNorm, GELU, L2 normalisation, logit scale, CPB-MLP, squeeze-excite, residuals,
 pixel shuffle) is ordinary differentiable torch code on the GPU (model.py: ``GRL._forward_train``).
 
 Gradient range: the kernels contract fp16 operands.  An L1 loss over a 256x256 output produces gradients of ~1e-6, below the
 fp16 normal range, so the backward contractions multiply their gradient operand by a power of two on its way to fp16 and
-divide the product by it again (``a_scale`` / ``out_scale`` / ``g_scale`` of the C ABI): every Function receives and returns
+divide the product by it again (``a_scale`` / ``out_scale`` / ``g_scale`` of the C ABI): every op receives and returns
 true-valued fp32 gradients.  The factor is chosen once per backward pass from the largest gradient entering the network
 (``GradScaleTop``: one host read per step).
 """
@@ -62,124 +64,173 @@ def _padded(x: torch.Tensor, width: int) -> torch.Tensor:
     return x if x.shape[1] == width and x.is_contiguous() else F.pad(x, (0, width - x.shape[1])).contiguous()
 
 
-class LinearFn(torch.autograd.Function):
-    """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in the kernel)."""
+# ---- the contractions as torch.library custom ops (torch.ops.grl.*) with registered autograd ----------------------------
+# forward = one or two C-ABI launches; backward = the C-ABI launches listed in the module docstring.  Registered ops (rather than
+# bare autograd.Function) are visible to torch.compile / export, carry fake (meta) kernels and are what DDP / Lightning see.
 
-    @staticmethod
-    def forward(ctx, x, w, b):
-        M, K = x.shape
-        N = w.shape[0]
-        Kp, Np = pad_width(K), pad_width(N)
-        xp = _padded(x.detach().float(), Kp)
-        wp = torch.zeros(Np, Kp, dtype=ops.GEMM_DTYPE, device=x.device)
-        wp[:N, :K] = w.detach()
-        bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
-        if b is not None:
-            bp[:N] = b.detach()
-        y = ops.linear(xp, wp, bp, out_dtype=torch.float32)
-        ctx.save_for_backward(xp, wp)
-        ctx.dims = (M, K, N, Kp, Np, b is not None)
-        return y[:, :N]
-
-    @staticmethod
-    def backward(ctx, dy):
-        xp, wp = ctx.saved_tensors
-        M, K, N, Kp, Np, has_b = ctx.dims
-        s = grad_scale()
-        dyp = _padded(dy.float(), Np)
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            wt = wp.t().contiguous()                                   # [Kp, Np]: rows = input channels
-            dx = ops.linear(dyp, wt, torch.zeros(Kp, dtype=torch.float32, device=dy.device), out_dtype=torch.float32,
-                            a_scale=s, out_scale=1.0 / s)[:, :K]
-        if ctx.needs_input_grad[1]:
-            dw = ops.gemm_tn(dyp, xp, Np, Kp, a_scale=s, out_scale=1.0 / s)[0, :N, :K]
-        if has_b and ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
-        return dx, dw, db
+def _linear_operands(x, w, b):
+    M, K = x.shape
+    N = w.shape[0]
+    Kp, Np = pad_width(K), pad_width(N)
+    xp = _padded(x.detach().float(), Kp)
+    wp = torch.zeros(Np, Kp, dtype=ops.GEMM_DTYPE, device=x.device)
+    wp[:N, :K] = w.detach()
+    bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+    if b is not None:
+        bp[:N] = b.detach()
+    return xp, wp, bp, (M, K, N, Kp, Np)
 
 
-class Conv3x3Fn(torch.autograd.Function):
-    """3x3 convolution, stride 1, zero pad 1, on channels-last token matrices x[B*H*W, Cin] -> [B*H*W, Cout]."""
+@torch.library.custom_op("grl::linear", mutates_args=())
+def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
+    """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in grl_linear_fwd)."""
+    xp, wp, bp, (M, K, N, Kp, Np) = _linear_operands(x, w, b)
+    return ops.linear(xp, wp, bp, out_dtype=torch.float32)[:, :N].contiguous()
 
-    @staticmethod
-    def forward(ctx, x, w, b, B, H, W):
-        Cout, Cin = w.shape[:2]
-        CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
+
+@linear_op.register_fake
+def _(x, w, b):
+    return x.new_empty(x.shape[0], w.shape[0], dtype=torch.float32)
+
+
+def _linear_setup(ctx, inputs, output):
+    x, w, b = inputs
+    ctx.save_for_backward(x, w)
+    ctx.has_b = b is not None
+
+
+def _linear_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    xp, wp, _, (M, K, N, Kp, Np) = _linear_operands(x, w, None)
+    s = grad_scale()
+    dyp = _padded(dy.float(), Np)
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        wt = wp.t().contiguous()                                   # [Kp, Np]: rows = input channels
+        dx = ops.linear(dyp, wt, torch.zeros(Kp, dtype=torch.float32, device=dy.device), out_dtype=torch.float32,
+                        a_scale=s, out_scale=1.0 / s)[:, :K]
+    if ctx.needs_input_grad[1]:
+        dw = ops.gemm_tn(dyp, xp, Np, Kp, a_scale=s, out_scale=1.0 / s)[0, :N, :K]
+    if ctx.has_b and ctx.needs_input_grad[2]:
+        db = dy.float().sum(0)
+    return dx, dw, db
+
+
+linear_op.register_autograd(_linear_backward, setup_context=_linear_setup)
+
+
+@torch.library.custom_op("grl::conv3x3", mutates_args=())
+def conv3x3_op(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
+    """3x3 convolution, stride 1, zero pad 1, on channels-last token matrices x[B*H*W, Cin] -> [B*H*W, Cout] (grl_conv3x3_fwd)."""
+    Cout, Cin = w.shape[:2]
+    CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
+    xp = _padded(x.detach().float(), CinP)
+    y = ops.conv3x3(xp, ops.pack_conv_weight(w.detach(), CinP, CoutP), ops.pack_conv_bias(b.detach(), CoutP), B, H, W)
+    return y[:, :Cout].contiguous()
+
+
+@conv3x3_op.register_fake
+def _(x, w, b, B, H, W):
+    return x.new_empty(x.shape[0], w.shape[0], dtype=torch.float32)
+
+
+def _conv_setup(ctx, inputs, output):
+    x, w, b, B, H, W = inputs
+    ctx.save_for_backward(x, w)
+    ctx.bhw = (B, H, W)
+
+
+def _conv_backward(ctx, dy):
+    x, w = ctx.saved_tensors
+    B, H, W = ctx.bhw
+    Cout, Cin = w.shape[:2]
+    CinP = (Cin + 31) // 32 * 32
+    s = grad_scale()
+    dx = dw = db = None
+    if ctx.needs_input_grad[0]:
+        # data gradient = the same convolution with the taps flipped and the channel roles swapped
+        gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
+        wt = ops.pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous(), gin, gout)
+        dyp = _padded(dy.float(), gin)
+        dx = ops.conv3x3(dyp, wt, torch.zeros(gout, dtype=torch.float32, device=dy.device), B, H, W, x_scale=s, out_scale=1.0 / s)[:, :Cin]
+    if ctx.needs_input_grad[1]:
+        n8 = (Cout + 7) // 8 * 8
+        dyp = _padded(dy.float(), n8)
         xp = _padded(x.detach().float(), CinP)
-        wpk = ops.pack_conv_weight(w.detach(), CinP, CoutP)
-        bpk = ops.pack_conv_bias(b.detach(), CoutP)
-        y = ops.conv3x3(xp, wpk, bpk, B, H, W)
-        ctx.save_for_backward(xp, w.detach())
-        ctx.dims = (B, H, W, Cin, Cout, CinP, CoutP)
-        return y[:, :Cout]
+        c = ops.gemm_tn(dyp, xp, n8, CinP, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s)      # [9, n8, CinP]
+        dw = c[:, :Cout, :Cin].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
+    if ctx.needs_input_grad[2]:
+        db = dy.float().sum(0)
+    return dx, dw, db, None, None, None
+
+
+conv3x3_op.register_autograd(_conv_backward, setup_context=_conv_setup)
+
+
+def _attn_operands(q, k, v, d):
+    q16 = q.detach().to(ops.PLANE_DTYPE)
+    k16 = k.detach().to(ops.PLANE_DTYPE)
+    v16 = v.detach().to(ops.PLANE_DTYPE)
+    if d <= 30:
+        k16[..., 31] = 1.0          # partner of the kernel's running softmax offset (q slot 31)
+    if d < 32:
+        v16[..., d] = 1.0           # ones column: the softmax denominator falls out of the PV product
+    return q16, k16, v16
+
+
+@torch.library.custom_op("grl::attention", mutates_args=())
+def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, floor: torch.Tensor, qgeo: Sequence[int],
+                 kgeo: Sequence[int], B: int, nh: int, d: int, masked: bool) -> tuple[torch.Tensor, torch.Tensor]:
+    """softmax(q k^T + bias (+ mask)) v over every window (grl_attention_fwd); operands are fp32 head planes [nh, tokens, 32]
+    (fp16 in the kernel): q = normalised * scale * log2e, k normalised, v raw; ``table`` from tables.kernel_table; ``floor`` from
+    tables.lazy_floor; qgeo / kgeo = (Himg, Wimg, wh, ww, shy, shx).  Returns (fp32 planes [nh, q_tokens, 32], log2-sum-exp2)."""
+    q16, k16, v16 = _attn_operands(q, k, v, d)
+    o = torch.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
+    lse = torch.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
+    TG = ops.TokenGrid
+    ops.attention(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), B=B, nh=nh, table=table.detach().contiguous(),
+                  masked=masked, ones_col=d if d < 32 else -1, head_dim=d, k_one31=d <= 30, lazy_floor=floor if d <= 30 else None, lse=lse)
+    return o, lse
+
+
+@attention_op.register_fake
+def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked):
+    return q.new_empty(nh, q.shape[1], 32, dtype=torch.float32), q.new_empty(nh, q.shape[1], dtype=torch.float32)
+
+
+def _attn_setup(ctx, inputs, output):
+    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked = inputs
+    o, lse = output
+    ctx.save_for_backward(q, k, v, table, o, lse)
+    ctx.geo = (tuple(qgeo), tuple(kgeo), B, nh, d, masked)
+
+
+def _attn_backward(ctx, d_o, d_lse):
+    q, k, v, table, o, lse = ctx.saved_tensors
+    qgeo, kgeo, B, nh, d, masked = ctx.geo
+    q16, k16, v16 = _attn_operands(q, k, v, d)
+    TG = ops.TokenGrid
+    dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o.float().contiguous(),
+                                         lse, B=B, nh=nh, table=table.detach().contiguous(), masked=masked, ones_col=d if d < 32 else -1,
+                                         head_dim=d, g_scale=grad_scale())
+    return dq, dk, dv, dtab, None, None, None, None, None, None, None
+
+
+attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
+
+
+class AttentionFn:
+    """Call-compatible front of torch.ops.grl.attention: ``AttentionFn.apply(q, k, v, table, geo)`` with
+    geo = dict(q=(Himg, Wimg, wh, ww, shy, shx), k=(...), B, nh, d, masked, floor)."""
 
     @staticmethod
-    def backward(ctx, dy):
-        xp, w = ctx.saved_tensors
-        B, H, W, Cin, Cout, CinP, CoutP = ctx.dims
-        s = grad_scale()
-        dx = dw = db = None
-        if ctx.needs_input_grad[0]:
-            # data gradient = the same convolution with the taps flipped and the channel roles swapped
-            gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
-            wt = ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous(), gin, gout)
-            dyp = _padded(dy.float(), gin)
-            dx = ops.conv3x3(dyp, wt, torch.zeros(gout, dtype=torch.float32, device=dy.device), B, H, W, x_scale=s, out_scale=1.0 / s)[:, :Cin]
-        if ctx.needs_input_grad[1]:
-            n8 = (Cout + 7) // 8 * 8
-            dyp = _padded(dy.float(), n8)
-            c = ops.gemm_tn(dyp, xp, n8, CinP, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s)      # [9, n8, CinP]
-            dw = c[:, :Cout, :Cin].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
-        if ctx.needs_input_grad[2]:
-            db = dy.float().sum(0)
-        return dx, dw, db, None, None, None
-
-
-class AttentionFn(torch.autograd.Function):
-    """softmax(q k^T + bias (+ mask)) v over every window; operands are head planes [nh, tokens, 32] (fp32 here, fp16 in the
-    kernels): q = normalised * scale * log2e, k = normalised (slot 31 := 1.0 by this function), v raw (slot ``d`` := 1.0 by this
-    function); ``table`` from tables.kernel_table.  Returns fp32 planes [nh, q_tokens, 32]."""
-
-    @staticmethod
-    def forward(ctx, q, k, v, table, geo):
-        # geo: dict(q=(Himg, Wimg, wh, ww, shy, shx), k=(...), B, nh, d, masked, floor)
-        nh, d = geo["nh"], geo["d"]
-        q16 = q.detach().to(ops.PLANE_DTYPE)
-        k16 = k.detach().to(ops.PLANE_DTYPE)
-        v16 = v.detach().to(ops.PLANE_DTYPE)
-        ones = d if d < 32 else -1
-        one31 = d <= 30
-        if one31:
-            k16[..., 31] = 1.0
-        if ones >= 0:
-            v16[..., ones] = 1.0
-        o = torch.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
-        lse = torch.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
-        TG = ops.TokenGrid
-        tab = table.detach().contiguous()
-        ops.attention(TG(q16, 0, *geo["q"]), TG(k16, 0, *geo["k"]), TG(v16, 0, *geo["k"]), TG(o, 0, *geo["q"]), B=geo["B"], nh=nh,
-                      table=tab, masked=geo["masked"], ones_col=ones, head_dim=d, k_one31=one31,
-                      lazy_floor=geo["floor"] if one31 else None, lse=lse)
-        ctx.save_for_backward(q16, k16, v16, o, lse, tab)
-        ctx.geo = geo
-        return o
-
-    @staticmethod
-    def backward(ctx, d_o):
-        q16, k16, v16, o, lse, tab = ctx.saved_tensors
-        geo = ctx.geo
-        nh, d = geo["nh"], geo["d"]
-        TG = ops.TokenGrid
-        dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *geo["q"]), TG(k16, 0, *geo["k"]), TG(v16, 0, *geo["k"]), TG(o, 0, *geo["q"]),
-                                             d_o.float().contiguous(), lse, B=geo["B"], nh=nh, table=tab, masked=geo["masked"],
-                                             ones_col=d if d < 32 else -1, head_dim=d, g_scale=grad_scale())
-        return dq, dk, dv, dtab, None
+    def apply(q, k, v, table, geo):
+        return attention_op(q, k, v, table, geo["floor"], list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]))[0]
 
 
 def linear(x, w, b=None):
-    return LinearFn.apply(x, w, b)
+    return linear_op(x, w, b)
 
 
 def conv3x3(x, w, b, B, H, W):
-    return Conv3x3Fn.apply(x, w, b, B, H, W)
+    return conv3x3_op(x, w, b, B, H, W)

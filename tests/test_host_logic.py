@@ -201,3 +201,19 @@ def test_product_never_touches_the_oracle_or_the_reference():
     for f in ("bench.py", "__graft_entry__.py"):
         txt = open(os.path.join(ROOT, f)).read()
         assert "/root/reference" not in txt and "refshim" not in txt
+
+
+def test_training_contractions_are_registered_torch_ops():
+    """torch.ops.grl.{linear, conv3x3, attention}: registered custom ops (autograd + fake kernels), so shape inference works
+    without a device and without touching the extension."""
+    import grl_image_restoration_amd.autograd  # noqa: F401  (registers the ops)
+
+    x = torch.empty(100, 180, device="meta")
+    y = torch.ops.grl.linear(x, torch.empty(540, 180, device="meta"), torch.empty(540, device="meta"))
+    assert y.shape == (100, 540) and y.dtype == torch.float32
+    c = torch.ops.grl.conv3x3(torch.empty(2 * 8 * 8, 180, device="meta"), torch.empty(45, 180, 3, 3, device="meta"), torch.empty(45, device="meta"), 2, 8, 8)
+    assert c.shape == (128, 45)
+    q = torch.empty(3, 256, 32, device="meta")
+    o, lse = torch.ops.grl.attention(q, q, q, torch.empty(3, 228, device="meta"), torch.empty(3, device="meta"), [16, 16, 8, 8, 4, 4],
+                                     [16, 16, 8, 8, 4, 4], 1, 3, 30, True)
+    assert o.shape == (3, 256, 32) and lse.shape == (3, 256)
