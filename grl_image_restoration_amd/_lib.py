@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 11
+ABI_VERSION = 12
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -82,6 +82,7 @@ class GrlLinearArgs(_Strict):
         ("out_dtype", C.c_int32),
         ("ldo", C.c_int64),
         ("out_plane_stride", C.c_int64),
+        ("out_lo", C.c_void_p),
     ]
 
 
@@ -182,6 +183,10 @@ class GrlAttnArgs(_Strict):
         ("lazy_floor", C.c_void_p),
         ("lse", C.c_void_p),
         ("lse_stride", C.c_int64),
+        ("q_lo", C.c_void_p),
+        ("k_lo", C.c_void_p),
+        ("v_lo", C.c_void_p),
+        ("o_lo", C.c_void_p),
     ]
 
 

@@ -45,6 +45,27 @@ constexpr float LAZY_REST = 4.0f;        // lazy offset: after a rescale the til
 constexpr unsigned short LAZY_TRIP = 0x7400;   // fp16 bit pattern of 2^14: a packed weight >= this moves the offset
 constexpr unsigned short F16_INF = 0x7C00;
 
+// 16 x fp16 of one (query, head) slot half -> global as two 16-B stores.  A lane holds 4 x 4 consecutive head dims (8-B
+// pieces), its partner 32 lanes away the interleaved ones: the pair swaps two pieces each so that every lane owns 2 x 8
+// consecutive dims (the epilogue is store-issue bound: a token's 64-B slot is written by 2 lanes x 2 instructions, not 2 x 4).
+__device__ __forceinline__ void store_f16_slot(f16* slot, const float (&v)[16], int half) {
+    uint2 pk[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pk[g].x = pack_f16(v[4 * g + 0], v[4 * g + 1]);
+        pk[g].y = pack_f16(v[4 * g + 2], v[4 * g + 3]);
+    }
+    const uint2 sa = half ? pk[0] : pk[1], sb = half ? pk[2] : pk[3];
+    uint2 ra, rb;
+    ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
+    rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
+    // half 0: dims 0-7 = own g0 | partner g0, dims 16-23 = own g2 | partner g2;  half 1: dims 8-15 = partner g1 | own g1, 24-31 likewise
+    const uint4 lo = half ? uint4{ra.x, ra.y, pk[1].x, pk[1].y} : uint4{pk[0].x, pk[0].y, ra.x, ra.y};
+    const uint4 hi = half ? uint4{rb.x, rb.y, pk[3].x, pk[3].y} : uint4{pk[2].x, pk[2].y, rb.x, rb.y};
+    *(uint4*)(slot + 8 * half) = lo;
+    *(uint4*)(slot + 8 * half + 16) = hi;
+}
+
 // normalised O^T fragment of one query tile -> global (lane holds head dims 8*g + 4*half + [0..3] of query l31)
 __device__ __forceinline__ void store_o(const GrlAttnArgs& p, const f32x16& O, float inv, int64_t qrow, int head, int half) {
     if (p.out_dtype == GRL_DT_F32) {
@@ -53,25 +74,16 @@ __device__ __forceinline__ void store_o(const GrlAttnArgs& p, const f32x16& O, f
         for (int g = 0; g < 4; ++g)
             *(float4*)(dst + 8 * g) = float4{O[4 * g + 0] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
     } else {
-        // fp16: a lane holds 4 x 4 consecutive head dims (8 B pieces), its partner 32 lanes away the interleaved ones.  The pair
-        // swaps two pieces each so that every lane owns 2 x 8 consecutive dims and issues two 16-B stores instead of four 8-B
-        // ones (the epilogue is store-issue bound: a token's 64-B slot is written by 2 lanes x 2 instructions instead of 2 x 4)
-        uint2 pk[4];
+        const int64_t off = qrow * p.o.ld + p.o.col0 + head * p.o.hstride;
+        float v[16];
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            pk[g].x = pack_f16(O[4 * g + 0] * inv, O[4 * g + 1] * inv);
-            pk[g].y = pack_f16(O[4 * g + 2] * inv, O[4 * g + 3] * inv);
+        for (int r = 0; r < 16; ++r) v[r] = O[r] * inv;
+        store_f16_slot((f16*)p.o.ptr + off, v, half);
+        if (p.o_lo != nullptr) {   // rounding residual: the low half of a split-precision operand (precision "high")
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] -= (float)to_f16(v[r]);
+            store_f16_slot((f16*)p.o_lo + off, v, half);
         }
-        const uint2 sa = half ? pk[0] : pk[1], sb = half ? pk[2] : pk[3];
-        uint2 ra, rb;
-        ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
-        rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
-        f16* dst = (f16*)p.o.ptr + qrow * p.o.ld + p.o.col0 + head * p.o.hstride + 8 * half;
-        // half 0: dims 0-7 = own g0 | partner g0, dims 16-23 = own g2 | partner g2;  half 1: dims 8-15 = partner g1 | own g1, 24-31 likewise
-        const uint4 lo = half ? uint4{ra.x, ra.y, pk[1].x, pk[1].y} : uint4{pk[0].x, pk[0].y, ra.x, ra.y};
-        const uint4 hi = half ? uint4{rb.x, rb.y, pk[3].x, pk[3].y} : uint4{pk[2].x, pk[2].y, rb.x, rb.y};
-        *(uint4*)(dst) = lo;
-        *(uint4*)(dst + 16) = hi;
     }
 }
 
@@ -89,7 +101,9 @@ __device__ __forceinline__ float ones_row(const f32x16& O, int oc, int half) {
 // ------------------------------------------------------------------------------------------------
 // Generic kernel: any window shape (12x12 windows, 8-anchor stripes, ragged key counts, head_dim 32), online softmax.
 // ------------------------------------------------------------------------------------------------
-template <bool ONES, bool KW4>
+// SPLIT: split-precision operands (precision "high"): S = q_hi k_hi + q_lo k_hi + q_hi k_lo, O = P v_hi + P v_lo with the fp16
+// residual planes q_lo / k_lo / v_lo (3 + 2 MFMA terms instead of 1 + 1: ~22-bit operands; P stays fp16).
+template <bool ONES, bool KW4, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -111,6 +125,8 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     char* Vt = Ks + KC * 64;                                     // 32 x VROW
     int* koff = (int*)(Vt + 32 * VROW);                          // KC
     unsigned char* kreg = (unsigned char*)(koff + KC);           // KC
+    char* Ks2 = (char*)(kreg + KC);                              // SPLIT: residual planes, same layouts
+    char* Vt2 = Ks2 + KC * 64;
 
     load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
 
@@ -122,7 +138,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     int U[QT], idq[QT];
     int64_t qrow[QT];
     bool qvalid[QT];
-    f16x8 qf[QT][2];
+    f16x8 qf[QT][2], ql[QT][2];
     f32x16 O[QT];
     float mrun[QT], lrun[QT];
 #pragma unroll
@@ -136,6 +152,14 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         const f16* src = (const f16*)p.q.ptr + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
         qf[t][0] = *(const f16x8*)(src);
         qf[t][1] = *(const f16x8*)(src + 16);
+        if constexpr (SPLIT) {
+            ql[t][0] = ql[t][1] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
+            if (p.q_lo != nullptr) {
+                const f16* sl = (const f16*)p.q_lo + qrow[t] * p.q.ld + p.q.col0 + head * p.q.hstride + 8 * half;
+                ql[t][0] = *(const f16x8*)(sl);
+                ql[t][1] = *(const f16x8*)(sl + 16);
+            }
+        }
 #pragma unroll
         for (int r = 0; r < 16; ++r) O[t][r] = 0.f;
         mrun[t] = NEG_BIG;
@@ -163,6 +187,14 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
 #pragma unroll
             for (int e = 0; e < 8; ++e) *(f16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
+            if constexpr (SPLIT) {
+                f16x8 k2 = {0, 0, 0, 0, 0, 0, 0, 0}, v2 = k2;
+                if (valid && p.k_lo != nullptr) k2 = *(const f16x8*)((const f16*)p.k_lo + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
+                if (valid && p.v_lo != nullptr) v2 = *(const f16x8*)((const f16*)p.v_lo + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
+                *(f16x8*)(Ks2 + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = k2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) *(f16*)(Vt2 + (seg * 8 + e) * VROW + kk * 2) = v2[e];
+            }
             if (seg == 0) {
                 const int nn = valid ? n : 0;
                 const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
@@ -207,6 +239,20 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             for (int t = 0; t < QT; ++t) {
                 S[t] = mfma32_f16(kf[0], qf[t][0], S[t]);
                 S[t] = mfma32_f16(kf[1], qf[t][1], S[t]);
+            }
+            if constexpr (SPLIT) {
+                f16x8 k2[2];
+                const int kk = kb + l31;
+                const int sw = (kk >> 2) & 3;
+                k2[0] = *(const f16x8*)(Ks2 + kk * 64 + (((0 + half) ^ sw) << 4));
+                k2[1] = *(const f16x8*)(Ks2 + kk * 64 + (((2 + half) ^ sw) << 4));
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    S[t] = mfma32_f16(kf[0], ql[t][0], S[t]);
+                    S[t] = mfma32_f16(kf[1], ql[t][1], S[t]);
+                    S[t] = mfma32_f16(k2[0], qf[t][0], S[t]);
+                    S[t] = mfma32_f16(k2[1], qf[t][1], S[t]);
+                }
             }
             if (need_mask) {
 #pragma unroll
@@ -263,6 +309,21 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                 O[t] = mfma32_f16(vf[0], pb[t][0], O[t]);
                 O[t] = mfma32_f16(vf[1], pb[t][1], O[t]);
             }
+            if constexpr (SPLIT) {
+                f16x8 v2[2];
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const char* vp = Vt2 + l31 * VROW + (kb + 16 * s2 + 4 * half) * 2;
+                    const f16x4 lo = *(const f16x4*)(vp);
+                    const f16x4 hi = *(const f16x4*)(vp + 16);
+                    v2[s2] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    O[t] = mfma32_f16(v2[0], pb[t][0], O[t]);
+                    O[t] = mfma32_f16(v2[1], pb[t][1], O[t]);
+                }
+            }
         }
     }
 
@@ -279,12 +340,12 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     }
 }
 
-template <bool ONES>
+template <bool ONES, bool SPLIT>
 int launch_kw(const GrlAttnArgs& p, int grid, int block, size_t lds, hipStream_t st) {
     const bool kw4 = (p.k.ww % 4) == 0;
 #define GRL_ATTN_GO(KW4V)                                                                                   \
     {                                                                                                       \
-        auto kfn = attn_kernel<ONES, KW4V>;                                                                 \
+        auto kfn = attn_kernel<ONES, KW4V, SPLIT>;                                                          \
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize,    \
                                            (int)lds);                                                       \
         if (e != hipSuccess) return (int)e;                                                                 \
@@ -732,7 +793,9 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     hipStream_t st = (hipStream_t)stream;
     // fast path: 32-aligned geometry with the ones column and the lazy running offset (needs the spare head-dim slot 31:
     // K carries 1.0 there, `k_one31`)
-    const bool lazy_ok = p.k_one31 && p.head_dim <= 30 && p.ones_col != 31 && p.lazy_floor != nullptr;
+    const bool split = p.q_lo != nullptr || p.k_lo != nullptr || p.v_lo != nullptr;
+    if (p.o_lo != nullptr && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
+    const bool lazy_ok = !split && p.k_one31 && p.head_dim <= 30 && p.ones_col != 31 && p.lazy_floor != nullptr;
     if (lazy_ok && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
         (p.k.wh % 8) == 0 && fast_lds_bytes(p, 1) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
         return launch_fast(p, st);
@@ -741,7 +804,10 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     const int nqs = (Nq + qblk - 1) / qblk;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
-    const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC * 4 + KC;
+    const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC * 4 + KC +
+                       (split ? (size_t)KC * 64 + 32 * (size_t)VROW : 0);
     if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
-    return p.ones_col >= 0 ? launch_kw<true>(p, (int)grid, waves * 64, lds, st) : launch_kw<false>(p, (int)grid, waves * 64, lds, st);
+    if (split)
+        return p.ones_col >= 0 ? launch_kw<true, true>(p, (int)grid, waves * 64, lds, st) : launch_kw<false, true>(p, (int)grid, waves * 64, lds, st);
+    return p.ones_col >= 0 ? launch_kw<true, false>(p, (int)grid, waves * 64, lds, st) : launch_kw<false, false>(p, (int)grid, waves * 64, lds, st);
 }

@@ -210,26 +210,37 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
         // instructions of 32-B pieces (8-B-per-lane stores were the bottleneck of these epilogues).
         // All lanes take part in the exchange; only the store is predicated.
         const bool odd = g4 & 1;
+        // pass 1 (out_lo given): the rounding residual v - fp16(v) of every value, same layout: the low half of a split-precision
+        // operand for a consumer that contracts hi + lo (the attention kernel in precision "high")
+        for (int pass = 0; pass < (p.out_lo != nullptr ? 2 : 1); ++pass) {
+            f16* obase = (f16*)(pass ? p.out_lo : p.out);
 #pragma unroll
-        for (int c = 0; c < NCH; ++c)
+            for (int c = 0; c < NCH; ++c)
 #pragma unroll
-            for (int nt = 0; nt < NT; nt += 2) {
-                uint2 lo, hi;  // this lane's 4 channels of tile nt / tile nt+1
-                lo.x = pack_f16(acc[c][mt][nt][0], acc[c][mt][nt][1]);
-                lo.y = pack_f16(acc[c][mt][nt][2], acc[c][mt][nt][3]);
-                hi.x = pack_f16(acc[c][mt][nt + 1][0], acc[c][mt][nt + 1][1]);
-                hi.y = pack_f16(acc[c][mt][nt + 1][2], acc[c][mt][nt + 1][3]);
-                const uint2 send = odd ? lo : hi;       // even lanes keep tile nt, odd lanes keep tile nt+1
-                uint2 recv;
-                recv.x = __shfl_xor(send.x, 16, 64);
-                recv.y = __shfl_xor(send.y, 16, 64);
-                const uint4 v = odd ? uint4{recv.x, recv.y, hi.x, hi.y} : uint4{lo.x, lo.y, recv.x, recv.y};
-                // even lane g4: channels 4*g4 .. 4*g4+7 of tile nt; odd lane: channels 4*(g4-1) .. of tile nt+1
-                const int col = n0 + 16 * (c * NT + nt + (odd ? 1 : 0)) + 4 * (g4 & ~1);
-                const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
-                                                           : (int64_t)m * p.ldo + col;
-                if (valid) *(uint4*)((f16*)p.out + off) = v;
-            }
+                for (int nt = 0; nt < NT; nt += 2) {
+                    float v[8] = {acc[c][mt][nt][0], acc[c][mt][nt][1], acc[c][mt][nt][2], acc[c][mt][nt][3],
+                                  acc[c][mt][nt + 1][0], acc[c][mt][nt + 1][1], acc[c][mt][nt + 1][2], acc[c][mt][nt + 1][3]};
+                    if (pass) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) v[e] -= (float)to_f16(v[e]);
+                    }
+                    uint2 lo, hi;  // this lane's 4 channels of tile nt / tile nt+1
+                    lo.x = pack_f16(v[0], v[1]);
+                    lo.y = pack_f16(v[2], v[3]);
+                    hi.x = pack_f16(v[4], v[5]);
+                    hi.y = pack_f16(v[6], v[7]);
+                    const uint2 send = odd ? lo : hi;       // even lanes keep tile nt, odd lanes keep tile nt+1
+                    uint2 recv;
+                    recv.x = __shfl_xor(send.x, 16, 64);
+                    recv.y = __shfl_xor(send.y, 16, 64);
+                    const uint4 w4 = odd ? uint4{recv.x, recv.y, hi.x, hi.y} : uint4{lo.x, lo.y, recv.x, recv.y};
+                    // even lane g4: channels 4*g4 .. 4*g4+7 of tile nt; odd lane: channels 4*(g4-1) .. of tile nt+1
+                    const int col = n0 + 16 * (c * NT + nt + (odd ? 1 : 0)) + 4 * (g4 & ~1);
+                    const int64_t off = p.out_plane_stride > 0 ? (int64_t)(col >> 5) * p.out_plane_stride + (int64_t)m * 32 + (col & 31)
+                                                               : (int64_t)m * p.ldo + col;
+                    if (valid) *(uint4*)(obase + off) = w4;
+                }
+        }
         return;
     }
     if (!valid) return;
@@ -430,6 +441,8 @@ int launch_split(const GrlLinearArgs& p0, hipStream_t st) {
         const size_t esz = p0.out_dtype == GRL_DT_F32 ? 4 : 2;
         if (p0.out_plane_stride > 0) p.out = (char*)p0.out + (size_t)(c0 / 32) * p0.out_plane_stride * esz;
         else p.out = (char*)p0.out + (size_t)c0 * esz;
+        if (p0.out_lo != nullptr)
+            p.out_lo = (char*)p0.out_lo + (p0.out_plane_stride > 0 ? (size_t)(c0 / 32) * p0.out_plane_stride : (size_t)c0) * esz;
         const int rc = launch_k<KSTEPS>(p, st);
         if (rc) return rc;
     }
@@ -448,6 +461,7 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     hipStream_t st = (hipStream_t)stream;
     if (p.a_split == 3 && ((p.Kpad / 32) % 3 != 0 || p.a_dtype != GRL_DT_F32)) return GRL_ERR_BAD_ARG;
     if (p.a_split != 0 && p.a_split != 1 && p.a_split != 3) return GRL_ERR_BAD_ARG;
+    if (p.out_lo != nullptr && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
     switch (p.Kpad / 32) {
         case 2: return launch_split<2>(p, st);
         case 3: return launch_split<3>(p, st);

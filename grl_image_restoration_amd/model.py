@@ -548,14 +548,18 @@ class GRL(nn.Module):
         gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])
         return raw, gate
 
-    def _attention(self, qkv, anc, att, pk, geo: BlockGeo, B, H, W, lse=None):
+    def _attention(self, qkv, anc, att, pk, geo: BlockGeo, B, H, W, lse=None, qkv_lo=None, anc_lo=None):
         """The three attention launches of a block on head planes: window (efficient.py:128-165), anchors -> stripe tokens
-        and stripe tokens -> anchors (:215-270).  ``att``: [M, (nh_w+nh_s)*32] output (fp16 or fp32)."""
+        and stripe tokens -> anchors (:215-270).  ``att``: [M, (nh_w+nh_s)*32] output (fp16 or fp32).  ``qkv_lo`` / ``anc_lo``:
+        rounding-residual twins of the planes (precision 'high': split-precision attention operands)."""
         C = self.embed_dim
         nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
         d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
         Ha, Wa = H // df, W // df
         y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=ops.PLANE_DTYPE, device=att.device)
+        split = qkv_lo is not None
+        y_lo = torch.empty_like(y) if split else None
+
         ws, sh = geo.window, geo.window_shift
         TG = ops.TokenGrid
         ls = lse if lse is not None else (None, None, None)
@@ -564,6 +568,7 @@ class GRL(nn.Module):
             TG(qkv, 2 * nh_w, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
             B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0,
             ones_col=d_w if d_w < 32 else -1, head_dim=d_w, k_one31=pk["one_w"], lazy_floor=pk["floor_w"], lse=ls[0],
+            q_lo=qkv_lo, k_lo=qkv_lo, v_lo=qkv_lo,
         )
         s0 = 3 * nh_w
         st, ss = geo.stripe, geo.stripe_shift_size
@@ -575,10 +580,11 @@ class GRL(nn.Module):
         g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         oc = d_s if d_s < 32 else -1
         ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
-                      ones_col=oc, head_dim=d_s, k_one31=pk["one_s"], lazy_floor=pk["floor_a2w"], lse=ls[1])
+                      ones_col=oc, head_dim=d_s, k_one31=pk["one_s"], lazy_floor=pk["floor_a2w"], lse=ls[1],
+                      q_lo=anc_lo, k_lo=qkv_lo, v_lo=qkv_lo, o_lo=y_lo)
         ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s, table=pk["tab_w2a"],
                       masked=geo.stripe_shift, ones_col=oc, head_dim=d_s, k_one31=pk["one_s"],
-                      lazy_floor=pk["floor_w2a"], lse=ls[2])
+                      lazy_floor=pk["floor_w2a"], lse=ls[2], q_lo=qkv_lo, k_lo=anc_lo, v_lo=y_lo)
         return y
 
     def _block(self, r, pk, geo: BlockGeo, B, H, W):
@@ -615,16 +621,21 @@ class GRL(nn.Module):
 
     def _block_high(self, r, pk, geo: BlockGeo, B, H, W):
         """precision='high': every linear / conv contraction on split operands (activation hi+lo staged in-kernel from fp32,
-        weights packed hi|hi|lo), fp32 intermediates, the row norms as separate launches.  Attention as in the fast path
-        (fp16 operands) with an fp32 output."""
+        weights packed hi|hi|lo), fp32 intermediates, the row norms as separate launches; attention on hi + lo operand planes
+        (3 QK^T terms, 2 PV terms in the generic kernel) with an fp32 output."""
         C, CP = self.embed_dim, r.shape[1]
         M = B * H * W
         f32 = torch.float32
-        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3)
+        G = pk["qkv_w"].shape[0] // 32
+        Ma = M // (geo.df * geo.df)
+        qkv_lo = torch.empty(G, M, 32, dtype=ops.PLANE_DTYPE, device=r.device)
+        anc_lo = torch.empty(geo.nh_s, Ma, 32, dtype=ops.PLANE_DTYPE, device=r.device)
+        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3, out_lo=qkv_lo)
         anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(geo.df, H, W), planes=True,
-                         a_split=3)
+                         a_split=3, out_lo=anc_lo)
         att = torch.empty(M, (geo.nh_w + geo.nh_s) * 32, dtype=f32, device=r.device)
-        self._attention(qkv, anc, att, pk, geo, B, H, W)
+        # attention on split operands too: q, k, v (and the anchor-side values) as fp16 hi + lo planes -> generic kernel
+        self._attention(qkv, anc, att, pk, geo, B, H, W, qkv_lo=qkv_lo, anc_lo=anc_lo)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         p1 = ops.linear(att, pk["proj_w"], pk["proj_b"], out_dtype=f32, a_split=3)
         r1 = ops.layernorm_res(p1, r, pk["n1_g"], pk["n1_b"], C, res_scale=self.res_scale, add2=cab, add2_scale=gate,

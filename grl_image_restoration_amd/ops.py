@@ -5,6 +5,7 @@ the HIP kernels.  Inputs must be CUDA (ROCm) tensors -- there is no CPU path.
 """
 import ctypes as C
 import os
+import dataclasses
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
@@ -104,6 +105,7 @@ def linear(
     a_split: int = 1,
     a_scale: float = 1.0,
     out_scale: float = 1.0,
+    out_lo: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
@@ -146,8 +148,10 @@ def linear(
         add2=_ptr(add2), add2_dtype=_KIND[add2.dtype] if add2 is not None else 0,
         ldadd2=add2.stride(0) if add2 is not None else 0,
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split, a_scale=a_scale, out_scale=out_scale,
-        out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
+        out_lo=_ptr(out_lo), out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
     )
+    if out_lo is not None:   # rounding residuals of the fp16 outputs, same layout (split-precision attention operands)
+        assert out_lo.dtype == torch.float16 and out_lo.shape == out.shape and out_lo.stride() == out.stride() and out.dtype == torch.float16
     if epi == L.EPI_GROUPNORM:
         assert gscale is not None and gscale.dtype == torch.float32 and gscale.numel() == Npad // 32
     if epi == L.EPI_LN_RES:
@@ -324,8 +328,12 @@ class TokenGrid:
 
 def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int, nh: int, table: torch.Tensor,
               masked: bool, ones_col: int, head_dim: int, k_one31: bool = False,
-              lazy_floor: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None):
+              lazy_floor: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
+              q_lo: Optional[torch.Tensor] = None, k_lo: Optional[torch.Tensor] = None, v_lo: Optional[torch.Tensor] = None,
+              o_lo: Optional[torch.Tensor] = None):
     """softmax(q k^T + bias(+mask)) v over every window of every image; see grl_attention_fwd.
+    ``q_lo / k_lo / v_lo``: fp16 rounding residuals of q / k / v (same tensors' layout; ``TokenGrid.t`` twins) for the
+    split-precision mode, ``o_lo``: residual output twin of ``o.t``.
     ``table``: (nh, rows padded to 4) from tables.kernel_table (reversed rows); ``k_one31`` / ``lazy_floor``: the
     softmax-offset contract of include/grl_hip.h; ``lse`` (nh, tokens) fp32 optional output."""
     _dev_check(q.t, k.t, v.t, o.t, table, lazy_floor, lse)
@@ -337,10 +345,17 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
         assert lazy_floor.dtype == torch.float32 and lazy_floor.is_contiguous() and lazy_floor.numel() == nh
     if lse is not None:
         assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape[0] == nh and lse.shape[1] >= q.tokens
+    def twin(g: TokenGrid, t: Optional[torch.Tensor]):
+        if t is None:
+            return C.c_void_p(0)
+        assert t.dtype == torch.float16 and t.shape == g.t.shape and t.stride() == g.t.stride()
+        return C.c_void_p(dataclasses.replace(g, t=t).c().ptr)
+
     args = L.GrlAttnArgs(q=q.c(), k=k.c(), v=v.c(), o=o.c(), B=B, nh=nh, nwy=nwy, nwx=nwx, table=_ptr(table),
                          trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), ones_col=ones_col,
                          head_dim=head_dim, out_dtype=_KIND[o.t.dtype], k_one31=int(k_one31), lazy_floor=_ptr(lazy_floor),
-                         lse=_ptr(lse), lse_stride=lse.stride(0) if lse is not None else 0)
+                         lse=_ptr(lse), lse_stride=lse.stride(0) if lse is not None else 0,
+                         q_lo=twin(q, q_lo), k_lo=twin(k, k_lo), v_lo=twin(v, v_lo), o_lo=twin(o, o_lo))
     with _timed("attention"):
         L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
     return o.t

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 11
+#define GRL_ABI_VERSION 12
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -75,6 +75,8 @@ typedef struct GrlLinearArgs {
     int64_t ldo;
     int64_t out_plane_stride; /* >0: write 32-column groups as planes: element (m, c) goes to          */
                               /* out[(c/32)*out_plane_stride + m*32 + c%32]  (ldo ignored)             */
+    void* out_lo;             /* optional, GRL_DT_F16 outputs: the rounding residual v - fp16(v) of every output value, */
+                              /* same layout as out (the low half of a split-precision attention operand)               */
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
@@ -222,6 +224,10 @@ typedef struct GrlAttnArgs {
     const float* lazy_floor; /* [nh] see above (may be NULL: generic kernel)                        */
     float* lse;              /* optional [nh][lse_stride] fp32: log2-sum-exp2 of the kernel-domain  */
     int64_t lse_stride;      /* logits per query token row (what the backward kernel re-normalises with) */
+    const void* q_lo;        /* optional split-precision operands (precision "high"): fp16 residuals q - fp16(q), ... on   */
+    const void* k_lo;        /* the grids of q, k, v (same ld / hstride / col0).  With any of them the generic kernel forms */
+    const void* v_lo;        /* S = q_hi k_hi + q_lo k_hi + q_hi k_lo and O = P v_hi + P v_lo (~22-bit operands)            */
+    void* o_lo;              /* optional, GRL_DT_F16 output: residual o - fp16(o) on o's grid (the next attention's v_lo)    */
 } GrlAttnArgs;
 
 int grl_attention_fwd(void* stream, const GrlAttnArgs* args);

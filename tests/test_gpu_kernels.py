@@ -559,3 +559,87 @@ def test_fp16_staging_saturates():
     w = torch.eye(64).to(torch.float16)
     out = ops.linear(a.to(d), w.to(d), torch.zeros(64, device=d), out_dtype=torch.float32).cpu()
     assert torch.isfinite(out).all() and out[0, 0] == 65504.0 and out[1, 1] == -65504.0
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("win32_shift", "win12_ragged", "a2w_64_df4_tiny", "w2a_8x16_df4", "a2w_64_noshift")],
+                         ids=lambda c: c[0])
+def test_attention_split_precision_operands(case):
+    """precision='high': q, k, v as fp16 hi + lo planes (3 QK^T terms, 2 PV terms) at logit scales up to the clamp, against fp64 on
+    the UNROUNDED operands: the logit error of fp16 operands (scale * 2^-12) disappears; what remains is the fp16 rounding of the
+    softmax weights.  Also the residual output plane (o_lo): o_hi + o_lo reproduces the fp32 result."""
+    from grl_image_restoration_amd import ops, tables
+
+    name, mode, (H, W), win, shift, df, nh, d = case
+    B = 2
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) % 1000 + 7)
+    awin, ashift = (win[0] // df, win[1] // df), (shift[0] // df, shift[1] // df)
+    Ha, Wa = H // df, W // df
+    scale = torch.rand(nh, generator=g) * 60 + 40
+    if mode == "w":
+        qg = kg = (H, W, win, shift)
+    elif mode == "a2w":
+        qg, kg = (Ha, Wa, awin, ashift), (H, W, win, shift)
+    else:
+        qg, kg = (H, W, win, shift), (Ha, Wa, awin, ashift)
+    rnd = lambda Hh, Ww: torch.randn(B * Hh * Ww, nh, d, generator=g)
+    q = F.normalize(rnd(qg[0], qg[1]), dim=-1) * (scale * LOG2E).view(1, nh, 1)
+    k = F.normalize(rnd(kg[0], kg[1]), dim=-1)
+    v = rnd(kg[0], kg[1])
+    rows = (qg[2][0] + kg[2][0] - 1) * (qg[2][1] + kg[2][1] - 1)
+    bias = torch.rand(rows, nh, generator=g) * 16
+    tab_k = tables.kernel_table(bias)
+    tab = torch.flip(tab_k[:, : tab_k.shape[1] - (-rows) % 4], dims=(1,))
+    masked = shift[0] > 0 or shift[1] > 0
+    if mode == "w":
+        index, mask = O.rel_index(win), (O.shift_mask((H, W), win, shift, mode="w") if masked else None)
+    else:
+        index, mask = O.rel_index(win, df, mode == "w2a"), (O.shift_mask((H, W), win, shift, df, mode) if masked else None)
+
+    def pad32(t, ones=False):
+        p = torch.zeros(*t.shape[:-1], 32)
+        p[..., :d] = t
+        if ones and d < 32:
+            p[..., d] = 1.0
+        return p.reshape(t.shape[0], -1)
+
+    q32, k32, v32 = pad32(q), pad32(k), pad32(v, True)
+    qw = _windows(q32, B, qg[0], qg[1], qg[2], qg[3], nh)
+    kw = _windows(k32, B, kg[0], kg[1], kg[2], kg[3], nh)
+    vw = _windows(v32, B, kg[0], kg[1], kg[2], kg[3], nh)
+    s = qw[..., :d].double() @ kw[..., :d].double().transpose(-1, -2) + tab.double()[:, index.reshape(-1)].view(nh, *index.shape).unsqueeze(0)
+    if mask is not None:
+        nW = mask.shape[0]
+        s = (s.view(B, nW, nh, *index.shape) + (mask.double() * LOG2E).unsqueeze(1).unsqueeze(0)).view(-1, nh, *index.shape)
+    p = torch.exp2(s - s.max(dim=-1, keepdim=True).values)
+    ref = (p @ vw.double()) / p.sum(-1, keepdim=True)
+    ref = ref.permute(0, 2, 1, 3).reshape(-1, qg[2][0], qg[2][1], nh * 32)
+    ref = O.unpartition(ref, qg[2], (qg[0], qg[1]))
+    if qg[3][0] or qg[3][1]:
+        ref = torch.roll(ref, shifts=(qg[3][0], qg[3][1]), dims=(1, 2))
+    ref = ref.reshape(B * qg[0] * qg[1], nh, 32)[..., :d]
+
+    dev = _dev()
+    planes = lambda t: t.view(t.shape[0], nh, 32).permute(1, 0, 2).contiguous()
+
+    def hl(t):
+        hi = t.to(torch.float16)
+        return planes(hi).to(dev), planes((t - hi.float()).to(torch.float16)).to(dev)
+
+    (qh, ql), (kh, kl), (vh, vl) = hl(q32), hl(k32), hl(v32)
+    TG = ops.TokenGrid
+    gq = lambda t: TG(t, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1])
+    gk = lambda t: TG(t, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1])
+    out = torch.zeros(nh, B * qg[0] * qg[1], 32, dtype=torch.float32, device=dev)
+    kw_ = dict(B=B, nh=nh, table=tab_k.to(dev), masked=masked, ones_col=d if d < 32 else -1, head_dim=d)
+    ops.attention(gq(qh), gk(kh), gk(vh), gq(out), q_lo=ql, k_lo=kl, v_lo=vl, **kw_)
+    plain = torch.zeros_like(out)
+    ops.attention(gq(qh), gk(kh), gk(vh), gq(plain), **kw_)
+    o16, o16lo = torch.zeros(nh, out.shape[1], 32, dtype=torch.float16, device=dev), torch.zeros(nh, out.shape[1], 32, dtype=torch.float16, device=dev)
+    ops.attention(gq(qh), gk(kh), gk(vh), gq(o16), q_lo=ql, k_lo=kl, v_lo=vl, o_lo=o16lo, **kw_)
+    torch.cuda.synchronize()
+    got = out.permute(1, 0, 2).cpu()[..., :d].double()
+    e_split = (got - ref).abs().max().item()
+    e_plain = (plain.permute(1, 0, 2).cpu()[..., :d].double() - ref).abs().max().item()
+    print(f"{name}: split operands {e_split:.2e}, fp16 operands {e_plain:.2e} (ref max {ref.abs().max().item():.2f})")
+    assert e_split < 5e-4 * max(1.0, ref.abs().max().item()) and e_split < 0.5 * e_plain
+    assert (o16.float() + o16lo.float() - out).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())

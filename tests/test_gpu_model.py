@@ -30,8 +30,7 @@ def _golden_model(meta):
     return _product(meta["cfg"], meta["weight_seed"], **meta.get("sd_kwargs", {}))[0]
 
 
-# tiny_sr2_ckpt_64_hiscale: see test_tiny_at_the_clamp_known_gap
-@pytest.mark.parametrize("name", [n for n in golden_names() if n not in ("base_sr4_ckpt_256", "tiny_sr2_ckpt_64_hiscale")])
+@pytest.mark.parametrize("name", [n for n in golden_names() if n != "base_sr4_ckpt_256"])
 def test_hip_forward_matches_reference_golden(name):
     meta, z = load_golden(name)
     m = _golden_model(meta)
@@ -42,20 +41,6 @@ def test_hip_forward_matches_reference_golden(name):
     rms = (y - z["output"]).pow(2).mean().sqrt().item()
     print(f"{name} [{m.precision}]: max|hip - reference| = {err:.3e}  rms = {rms:.3e}")
     assert err < TOL_MAXABS, err
-
-
-def test_tiny_at_the_clamp_known_gap():
-    """KNOWN GAP (precision): GRL-Tiny (64 channels, head_dim 16) with seeded-random weights and logit scales at
-    the clamp amplifies the fp16 rounding of the attention operands themselves (q, k: 3.6e-3, v: 1.3e-3 by CPU emulation,
-    tools/precision_sites.py) beyond the 1e-3 bar; the split-operand mode covers the linear / conv contractions only.
-    Asserted: finite, and within the emulated fp16-attention floor."""
-    meta, z = load_golden("tiny_sr2_ckpt_64_hiscale")
-    m = _golden_model(meta)
-    with torch.no_grad():
-        y = m(z["input"].to("cuda:0")).float().cpu()
-    err = (y - z["output"]).abs().max().item()
-    print(f"tiny_sr2_ckpt_64_hiscale [{m.precision}]: max|hip - reference| = {err:.3e}")
-    assert torch.isfinite(y).all() and err < 8e-3
 
 
 def test_hip_forward_at_the_bench_shape():
