@@ -13,7 +13,10 @@
 // mask / index tensors):
 //   dq_kernel  : workgroup = (window, head, 256 queries); S^T = K.Q orientation (lane = query) exactly as the forward, keys
 //                stream through LDS; 6 MFMAs per (32 keys x 32 queries) tile; dtable as an LDS histogram (ds_add_f32)
-//                flushed with global atomics.
+//                flushed with global atomics.  When both windows are whole multiples of 32 wide a (32 x 32) tile is one key-row
+//                segment against one query-row segment, its table entries depend on (key - query) only, and the tile is
+//                summed along its diagonals in registers first (rotating the wave one lane per key row, see diag_ring):
+//                one conflict-free ds_add per tile instead of 16 two-way-conflicting ones.
 //   dkv_kernel : workgroup = (window, head, 256 keys); S = Q.K^T orientation (lane = key), queries stream through LDS;
 //                8 MFMAs per tile.
 // dO is multiplied by g_scale on its way to fp16 (gradients of an L1 loss are ~1e-6: below the fp16 normal range); all
@@ -76,6 +79,47 @@ __device__ __forceinline__ void store_cols(float* base, const GrlTokenGrid& g, i
         *(float4*)(dst + 8 * q) = float4{a[4 * q + 0] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale};
 }
 
+// wave_rol:1 -- lane i takes the value of lane (i + 1) mod 64
+__device__ __forceinline__ float wave_rol1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xf, 0xf, true));
+}
+
+// Diagonal sums of a (32 keys x 32 queries) dS tile whose table entry is  ebase + key - query.
+// The accumulator holds key row 8g + 4*half + m in register 4g + m, query = lane & 31.  v_permlane32_swap against zero
+// (vdst lanes 32-63 <-> src lanes 0-31) splits a register into its two key rows, each in lanes 0-31 over zeros.  Then Horner from key row 31 down to 0 on one
+// 64-lane ring: rotate the running sums one lane towards lane 0 (the entry of a value does not change, it now sits with
+// the query one to the left; what leaves lane 0 re-enters at lane 63, and after 31 steps the spill has reached lane 33)
+// and add the next row.  Lane p ends with the whole diagonal  key - query = -p  (p < 32)  or  64 - p  (p > 32): one
+// conflict-free ds_add per tile instead of 16 two-way conflicting ones.
+template <bool GHIST>
+__device__ __forceinline__ void diag_ring(const f32x16& dS, int lane, float* dtab, float* gtab, int ebase, float inv_g) {
+    float z = 0.f;
+#pragma unroll
+    for (int g = 3; g >= 0; --g) {
+        // (inline asm: this toolchain's __builtin_amdgcn_permlane32_swap returns its first result twice; the s_nops are the
+        // VALU-write -> swap and swap -> DPP-read wait states the compiler would otherwise place)
+        float row_lo[4] = {dS[4 * g], dS[4 * g + 1], dS[4 * g + 2], dS[4 * g + 3]};   // -> key rows 8g + m     in lanes 0-31
+        float row_hi[4] = {0.f, 0.f, 0.f, 0.f};                                        // -> key rows 8g + 4 + m in lanes 0-31
+        asm("s_nop 1\n\t"
+            "v_permlane32_swap_b32 %0, %4\n\t"
+            "v_permlane32_swap_b32 %1, %5\n\t"
+            "v_permlane32_swap_b32 %2, %6\n\t"
+            "v_permlane32_swap_b32 %3, %7\n\t"
+            "s_nop 1"
+            : "+v"(row_lo[0]), "+v"(row_lo[1]), "+v"(row_lo[2]), "+v"(row_lo[3]),
+              "+v"(row_hi[0]), "+v"(row_hi[1]), "+v"(row_hi[2]), "+v"(row_hi[3]));
+#pragma unroll
+        for (int m = 3; m >= 0; --m) z = wave_rol1(z) + row_hi[m];
+#pragma unroll
+        for (int m = 3; m >= 0; --m) z = wave_rol1(z) + row_lo[m];
+    }
+    const int e = ebase - (lane < 32 ? lane : lane - 64);
+    if (lane != 32) {
+        if constexpr (GHIST) unsafeAtomicAdd(gtab + e, z * inv_g);
+        else atomicAdd(&dtab[e], z);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // dq + dtable
 // ------------------------------------------------------------------------------------------------
@@ -114,6 +158,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     const float inv_g = 1.0f / a.g_scale;
 
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+    // every (32 x 32) tile is a key-row segment against a query-row segment: table entry = U(query 0) + koff(key 0) + key - query
+    const bool toeplitz = (p.q.ww & 31) == 0 && (p.k.ww & 31) == 0;
 
     int U[QT], idq[QT];
     int64_t qrow[QT];
@@ -211,7 +257,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
                     else if (border && idk != idq[t]) s += MASK_L2;
                     const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
                     dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
-                    if (qvalid[t] && idk != 255) {
+                    if (!toeplitz && qvalid[t] && idk != 255) {
                         if constexpr (GHIST) unsafeAtomicAdd(gtab + U[t] + kofs[r], dS[r] * inv_g);
                         else atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
                     }
@@ -220,6 +266,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
                 pack_acc(dS, dsp);
                 dQ[t] = mfma32_f16(ktf[0], dsp[0], dQ[t]);
                 dQ[t] = mfma32_f16(ktf[1], dsp[1], dQ[t]);
+                if (toeplitz)   // masked pairs carry dS = 0 exactly; there are no pad rows in this geometry
+                    diag_ring<GHIST>(dS, lane, dtab, gtab, __builtin_amdgcn_readfirstlane(U[t]) + koff[kb], inv_g);
             }
         }
     }
