@@ -66,7 +66,7 @@ struct TailP {
 // residual + CAB, mixed_attn_block_efficient.py:379,543-548) through the same weight ring -- Cpad/32 extra chunk
 // iterations -- and feeds r1 to the MLP from registers: the intermediate residual stream never goes to HBM.
 template <int KSTEPS, int WV, bool PROJ>
-__global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
+__global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
     using S = MlpShape<KSTEPS>;
     constexpr int CP = S::CP, NT2 = S::NT2;
     constexpr int THREADS = WV * 64;
@@ -87,15 +87,18 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
     const char* pblob = (const char*)p.pblob;
     auto fetch = [&](int k, int buf_off) {   // chunk k of the per-tile sequence [NP projection chunks | nchunks MLP chunks]
         const bool isp = PROJ && k < NP;
-        const char* src = (isp ? pblob + (size_t)k * (PPIECES * 1024) : blob + (size_t)(k - NP) * S::BUFP) + lane * 16;
+        // wave-uniform image base in SGPRs + a 32-bit lane offset (saddr form): no per-piece 64-bit VGPR addresses to keep
+        const uint64_t srcv = (uint64_t)(isp ? pblob + (size_t)k * (PPIECES * 1024) : blob + (size_t)(k - NP) * S::BUFP);
+        const uint64_t src = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)(srcv >> 32)) << 32) |
+                             (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((uint32_t)srcv);   // (the builtin returns int)
         const int pieces = isp ? PPIECES : S::PIECES;
 #pragma unroll
         for (int q0 = 0; q0 < S::PIECES; q0 += WV) {
             const int q = q0 + wave_u;
             if (q < pieces) {
-                const uint32_t m0v = lds0 + buf_off + q * 1024;
-                const char* g = src + q * 1024;
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + buf_off + q * 1024);
+                const uint32_t voff = (uint32_t)(q * 1024 + lane * 16);
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" ::"s"(m0v), "v"(voff), "s"(src) : "m0", "memory");
             }
         }
     };
@@ -104,9 +107,19 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
     if ((int)blockIdx.x >= ntiles) return;
     // fc2 bias and the norm affine live in LDS behind the ring (read once per tile by every lane)
     float* vec = (float*)(smem + 2 * S::BUFP);
-    for (int i = tid; i < 3 * CP; i += THREADS) vec[i] = i < CP ? p.b2[i] : (i < 2 * CP ? p.ln_g[i - CP] : p.ln_b[i - 2 * CP]);
+    // Pad channels (>= n_real) of every vector are stored as 0: with the zero pad rows of the packed weights the pad
+    // accumulators are then exactly 0, the norm statistics need no per-channel masks (only a correction term), and the pad
+    // outputs come out as the pad channels of x (0 in a padded token matrix) without compare/select in the epilogues.
+    for (int i = tid; i < 3 * CP; i += THREADS) {
+        const float v = i < CP ? p.b2[i] : (i < 2 * CP ? p.ln_g[i - CP] : p.ln_b[i - 2 * CP]);
+        vec[i] = (i % CP) < p.n_real ? v : 0.f;
+    }
     if constexpr (PROJ)   // [3CP..6CP): projection bias, norm1 weight / bias; [6CP..8CP): SE gate rows of the tile's <= 2 images
-        for (int i = tid; i < 3 * CP; i += THREADS) vec[3 * CP + i] = i < CP ? p.pb[i] : (i < 2 * CP ? p.n1_g[i - CP] : p.n1_b[i - 2 * CP]);
+        for (int i = tid; i < 3 * CP; i += THREADS) {
+            const float v = i < CP ? p.pb[i] : (i < 2 * CP ? p.n1_g[i - CP] : p.n1_b[i - 2 * CP]);
+            vec[3 * CP + i] = (i % CP) < p.n_real ? v : 0.f;
+        }
+    const float npad = (float)(CP - p.n_real);
     constexpr int VECF = PROJ ? 8 * CP : 3 * CP;
 
     // Token tile staging: the fp32 rows of the NEXT tile are DMA'd into LDS (rows padded by 16 B) in 1-KiB pieces
@@ -147,7 +160,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
             for (int i = tid; i < 2 * CP; i += THREADS) {   // gate rows of the (at most two) images this tile touches
                 const int im = img0 + i / CP;
                 const int last = (p.M - 1) / p.rows_per_image;
-                vec[6 * CP + i] = p.gate[(int64_t)(im < last ? im : last) * CP + (i % CP)];
+                vec[6 * CP + i] = (i % CP) < p.n_real ? p.gate[(int64_t)(im < last ? im : last) * CP + (i % CP)] : 0.f;
             }
             gemm_x8 a0[KSTEPS];
             gemm_x4 cb[NT2];
@@ -155,9 +168,6 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
                 const gemm_t* arow = p.att + mc0 * p.ldatt + 8 * g4;
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) a0[s] = *(const gemm_x8*)(arow + 32 * s);
-                const gemm_t* crow = p.cab + mc0 * p.ldcab + 4 * g4;
-#pragma unroll
-                for (int nt = 0; nt < NT2; ++nt) cb[nt] = *(const gemm_x4*)(crow + 16 * nt);
             }
             f32x4 pacc[NT2];
 #pragma unroll
@@ -166,22 +176,31 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
                 __builtin_amdgcn_s_barrier();
                 char* cur = smem + (it & 1) * S::BUFP;
                 fetch(j + 1, ((it + 1) & 1) * S::BUFP);   // j + 1 == NP is MLP chunk 0
-                gemm_x8 wa[KSTEPS], wb[KSTEPS];
+                if (j == (NP > 1 ? NP - 2 : 0)) {          // CAB rows: needed after the last projection step, two steps of cover
+                    const gemm_t* crow = p.cab + mc0 * p.ldcab + 4 * g4;
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    wa[s] = *(const gemm_x8*)(cur + r16 * S::W1ROW + (32 * s + 8 * g4) * 2);
-                    wb[s] = *(const gemm_x8*)(cur + (16 + r16) * S::W1ROW + (32 * s + 8 * g4) * 2);
+                    for (int nt = 0; nt < NT2; ++nt) cb[nt] = *(const gemm_x4*)(crow + 16 * nt);
                 }
-                __builtin_amdgcn_sched_barrier(0);
                 f32x4 h0 = f32x4{0, 0, 0, 0}, h1 = f32x4{0, 0, 0, 0};
+                constexpr int KB = KSTEPS > 4 ? KSTEPS / 2 : KSTEPS;   // k-steps per read batch (register budget)
 #pragma unroll
-                for (int s = 0; s < KSTEPS; ++s) {
-                    h0 = mfma16_gemm(wa[s], a0[s], h0);
-                    h1 = mfma16_gemm(wb[s], a0[s], h1);
+                for (int s0 = 0; s0 < KSTEPS; s0 += KB) {
+                    gemm_x8 wa[KB], wb[KB];
+#pragma unroll
+                    for (int s = 0; s < KB; ++s) {
+                        wa[s] = *(const gemm_x8*)(cur + r16 * S::W1ROW + (32 * (s0 + s) + 8 * g4) * 2);
+                        wb[s] = *(const gemm_x8*)(cur + (16 + r16) * S::W1ROW + (32 * (s0 + s) + 8 * g4) * 2);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int s = 0; s < KB; ++s) {
+                        h0 = mfma16_gemm(wa[s], a0[s0 + s], h0);
+                        h1 = mfma16_gemm(wb[s], a0[s0 + s], h1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
                 }
                 pacc[2 * j] = h0;
                 pacc[2 * j + 1] = h1;
-                __builtin_amdgcn_sched_barrier(0);
             }
             // the token tile landed before the first of the barriers above (issued a whole tile earlier)
             float s1 = 0.f;
@@ -189,8 +208,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
             for (int nt = 0; nt < NT2; ++nt) {
                 const float4 b4 = *(const float4*)(vec + 3 * CP + 16 * nt + 4 * g4);
                 pacc[nt][0] += b4.x; pacc[nt][1] += b4.y; pacc[nt][2] += b4.z; pacc[nt][3] += b4.w;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) s1 += (16 * nt + 4 * g4 + e) < p.n_real ? pacc[nt][e] : 0.f;
+                s1 += (pacc[nt][0] + pacc[nt][1]) + (pacc[nt][2] + pacc[nt][3]);   // pad channels are exactly 0
             }
             s1 += __shfl_xor(s1, 16, 64);
             s1 += __shfl_xor(s1, 32, 64);
@@ -201,10 +219,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = pacc[nt][e] - mean;
-                    s2 += (16 * nt + 4 * g4 + e) < p.n_real ? d * d : 0.f;
+                    s2 = fmaf(d, d, s2);
                 }
             s2 += __shfl_xor(s2, 16, 64);
             s2 += __shfl_xor(s2, 32, 64);
+            s2 = fmaxf(s2 - npad * mean * mean, 0.f);   // the pad channels contributed (0 - mean)^2 each
             const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
             const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
             const float* grow = vec + 6 * CP + ((int)(mc0 / p.rows_per_image) - img0) * CP;
@@ -220,11 +239,8 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
                 o4.y = res.y + p.res_scale * ((pacc[nt][1] - mean) * rstd * g.y + bb.y) + (float)cb[nt][1] * gt.y;
                 o4.z = res.z + p.res_scale * ((pacc[nt][2] - mean) * rstd * g.z + bb.z) + (float)cb[nt][2] * gt.z;
                 o4.w = res.w + p.res_scale * ((pacc[nt][3] - mean) * rstd * g.w + bb.w) + (float)cb[nt][3] * gt.w;
-                if (col + 0 >= p.n_real) o4.x = 0.f;   // keep pad channels 0
-                if (col + 1 >= p.n_real) o4.y = 0.f;
-                if (col + 2 >= p.n_real) o4.z = 0.f;
-                if (col + 3 >= p.n_real) o4.w = 0.f;
                 xs[nt >> 1][nt & 1] = o4;
+                if ((nt & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // bounds the live range of the four vector reads per n-tile
             }
         } else {
             // the tile's rows have landed (own pieces: vmcnt, everybody's: barrier).  Lane = token r16; its 8 k-slots of
@@ -253,14 +269,14 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
         const int next_tile = tile + (int)gridDim.x;   // may lie past the end: rows are clamped, the data is never read
 
 #pragma unroll 1
-        for (int c = 0; c < ((dbg & 16) ? 1 : nchunks); ++c, ++it) {
+        for (int c = 0; c < nchunks; ++c, ++it) {
             // Every wave waits for its own DMA pieces (chunk `it` and the token pieces of the previous iteration) before
             // the barrier publishes them; after the barrier nobody reads ring buffer (it+1)&1 any more -- and, at c == 0,
             // everybody has copied its token rows into registers -- so the next DMAs may land.
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: my LDS reads of the token tile / last chunk are done
-            if (!(dbg & 2)) __builtin_amdgcn_s_barrier();
+            __builtin_amdgcn_s_barrier();
             char* cur = smem + (it & 1) * S::BUFP;
-            if (!(dbg & 1)) fetch(c + 1 < nchunks ? NP + c + 1 : 0, ((it + 1) & 1) * S::BUFP);
+            fetch(c + 1 < nchunks ? NP + c + 1 : 0, ((it + 1) & 1) * S::BUFP);
             for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) fetch_x(next_tile, q);
 
             // ---- h = GELU(W1_c . x + b1_c): two n-tiles of 16 hidden channels ----
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            constexpr int QB = 4, NB = NT2 / QB;   // fc2 n-tiles per read batch; batch k+1 is in flight while k multiplies
+            constexpr int QB = 4, NB = NT2 / QB;   // fc2 n-tiles per read batch; batch k+1 is in flight while k multiplies (deeper prefetch measured slower: the kernel is LDS-bandwidth bound)
             gemm_x8 w2[2][QB];
 #pragma unroll
             for (int j = 0; j < QB; ++j) w2[0][j] = *(const gemm_x8*)(cur + S::W1B + (16 * j + r16) * S::W2ROW + 16 * g4);
@@ -318,8 +334,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
         for (int nt = 0; nt < NT2; ++nt) {
             const float4 b4 = *(const float4*)(vec + 16 * nt + 4 * g4);
             acc[nt][0] += b4.x; acc[nt][1] += b4.y; acc[nt][2] += b4.z; acc[nt][3] += b4.w;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) s1 += (16 * nt + 4 * g4 + e) < p.n_real ? acc[nt][e] : 0.f;
+            s1 += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);   // pad channels are exactly 0
         }
         s1 += __shfl_xor(s1, 16, 64);
         s1 += __shfl_xor(s1, 32, 64);
@@ -330,17 +345,18 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = acc[nt][e] - mean;
-                s2 += (16 * nt + 4 * g4 + e) < p.n_real ? d * d : 0.f;
+                s2 = fmaf(d, d, s2);
             }
         s2 += __shfl_xor(s2, 16, 64);
         s2 += __shfl_xor(s2, 32, 64);
+        s2 = fmaxf(s2 - npad * mean * mean, 0.f);
         const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
         const int64_t mc = valid ? m : (int64_t)p.M - 1;
         float* orow = p.out + mc * p.ldo;
 #pragma unroll
         for (int nt = 0; nt < NT2; ++nt) {
             const int col = 16 * nt + 4 * g4;
-            const float4 res = (dbg & 8) ? float4{0, 0, 0, 0} : xs[nt >> 1][nt & 1];
+            const float4 res = xs[nt >> 1][nt & 1];
             const float4 g = *(const float4*)(vec + CP + col);
             const float4 bb = *(const float4*)(vec + 2 * CP + col);
             float4 o4;
@@ -348,10 +364,6 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p, int dbg) {
             o4.y = res.y + p.res_scale * ((acc[nt][1] - mean) * rstd * g.y + bb.y);
             o4.z = res.z + p.res_scale * ((acc[nt][2] - mean) * rstd * g.z + bb.z);
             o4.w = res.w + p.res_scale * ((acc[nt][3] - mean) * rstd * g.w + bb.w);
-            if (col + 0 >= p.n_real) o4.x = 0.f;   // keep pad channels 0
-            if (col + 1 >= p.n_real) o4.y = 0.f;
-            if (col + 2 >= p.n_real) o4.z = 0.f;
-            if (col + 3 >= p.n_real) o4.w = 0.f;
             if (valid) *(float4*)(orow + col) = o4;
         }
     }
@@ -368,8 +380,7 @@ int launch_mlp(const TailP& p, hipStream_t st) {
     auto kfn = mlp_kernel<KSTEPS, WV, PROJ>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
-    static const int dbg = getenv("GRL_MLP_DEBUG") ? atoi(getenv("GRL_MLP_DEBUG")) : 0;  // timing ablations only
-    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WV * 64), lds, st, p, dbg);
+    hipLaunchKernelGGL(kfn, dim3(grid), dim3(WV * 64), lds, st, p);
     GRL_CHECK_LAUNCH();
     return 0;
 }

@@ -97,7 +97,7 @@ int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
  *   the next.  grl_mlp_blob_bytes gives the total size; ops.pack_mlp builds it; the blob must be 16-B aligned.
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlMlpArgs {
-    const float* x;         /* [M, ldx] fp32 input, also the residual                               */
+    const float* x;         /* [M, ldx] fp32 input, also the residual; pad channels (>= n_real) must be 0 */
     int64_t ldx;
     const void* blob;       /* weight chunk stream, see above                                       */
     int32_t M, Cpad, Hpad;  /* Cpad in {64, 128, 192}; Hpad % 32 == 0                               */
@@ -107,7 +107,7 @@ typedef struct GrlMlpArgs {
     int32_t n_real;
     float ln_eps;
     float res_scale;
-    float* out;             /* [M, ldo] fp32, pad channels written as 0; must not alias x           */
+    float* out;             /* [M, ldo] fp32, pad channels = those of x (0); must not alias x       */
     int64_t ldo;
 } GrlMlpArgs;
 
