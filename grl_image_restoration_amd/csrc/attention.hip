@@ -30,6 +30,7 @@
 // Work decomposition: one workgroup = (window, head, block of up to 256 queries); each wave owns 2 query tiles (64
 // queries) whose Q fragments and O^T accumulators stay in registers; K and V chunks of 256 keys are staged in LDS.
 #include "common.h"
+#include <type_traits>
 #include "grl_hip_internal.h"
 #include "attn_common.h"
 #include <stdlib.h>
@@ -611,12 +612,14 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) dst[r] = tp[(r & 3) + 8 * (r >> 2)];
         };
-        auto logits = [&](const f16x8 (&kf)[2], const f32x16& C0, const f32x16& C1, const uint32_t (&ids)[4], f32x16 (&S)[2]) {
+        // BORDER is a compile-time tag: with a run-time `if (border)` around the mask the two versions of S meet in 32 register
+        // copies (+ the MFMA drain in front of them) on the common unmasked path
+        auto logits = [&](auto border_tag, const f16x8 (&kf)[2], const f32x16& C0, const f32x16& C1, const uint32_t (&ids)[4], f32x16 (&S)[2]) {
             S[0] = mfma32_f16(kf[0], qf[0][0], C0);
             S[1] = mfma32_f16(kf[0], qf[1][0], C1);
             S[0] = mfma32_f16(kf[1], qf[0][1], S[0]);
             S[1] = mfma32_f16(kf[1], qf[1][1], S[1]);
-            if (border) {
+            if constexpr (decltype(border_tag)::value) {
                 if (band16) {
                     // region labels change only at multiples of 16 key columns (shift and window width are multiples of 16):
                     // keys 0..15 of the tile (accumulator registers 0..7) share one label, keys 16..31 (registers 8..15) another
@@ -638,9 +641,9 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
                 }
             }
         };
-        auto pair = [&](f16x8 (&kf)[2], f16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
+        auto pair = [&](auto border_tag, f16x8 (&kf)[2], f16x8 (&vf)[2], const f32x16& C0, const f32x16& C1, uint32_t (&ids)[4]) {
             f32x16 S[2];
-            logits(kf, C0, C1, ids, S);
+            logits(border_tag, kf, C0, C1, ids, S);
             // weights as packed fp16 pairs (word i of a tile = accumulator registers 2i, 2i+1: the PV B-operand order)
             typedef __attribute__((__vector_size__(2 * sizeof(unsigned short)))) unsigned short u16x2;
             typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t u32x4;
@@ -663,9 +666,11 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
             unsigned short top[2];
 #pragma unroll
             for (int t = 0; t < 2; ++t) {
-                u16x2 m2 = __builtin_bit_cast(u16x2, pw[t][0]);
+                u16x2 m4[4];   // tree, not a chain: seven dependent v_pk_max_u16 cost a stall each
 #pragma unroll
-                for (int i = 1; i < 8; ++i) m2 = __builtin_elementwise_max(m2, __builtin_bit_cast(u16x2, pw[t][i]));
+                for (int i = 0; i < 4; ++i)
+                    m4[i] = __builtin_elementwise_max(__builtin_bit_cast(u16x2, pw[t][2 * i]), __builtin_bit_cast(u16x2, pw[t][2 * i + 1]));
+                const u16x2 m2 = __builtin_elementwise_max(__builtin_elementwise_max(m4[0], m4[1]), __builtin_elementwise_max(m4[2], m4[3]));
                 top[t] = m2[0] > m2[1] ? m2[0] : m2[1];
             }
             bool post = false;   // wave-uniform: raise the offsets after this tile's PV product
@@ -673,7 +678,7 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
                 if (__builtin_amdgcn_ballot_w64(top[0] >= F16_INF || top[1] >= F16_INF) != 0ull) {
                     // a weight overflowed fp16: raise the offsets of the queries concerned so that their tile maximum lands at
                     // 2^REST, rescale their accumulators, redo the tile's weights
-                    logits(kf, C0, C1, ids, S);
+                    logits(border_tag, kf, C0, C1, ids, S);
                     float delta[2];
 #pragma unroll
                     for (int t = 0; t < 2; ++t) {
@@ -720,18 +725,22 @@ __global__ __launch_bounds__(FW * 64, 2) void attn_fast_kernel(GrlAttnArgs p) {
                 }
             }
         };
+        auto rows = [&](auto border_tag) {
 #pragma unroll 1
-        for (int kt = 0; kt < FROWS; kt += 2) {
-            f16x8 kf[2], vf[2];
-            uint32_t ids[4] = {0, 0, 0, 0};
-            frags(kt, kf, vf, ids);
-            if (hk0 + kt == 0) gather(1, 0, HB);      // strip start: tile 1 has no predecessor fragment
-            gather(0, hk0 + kt, HA);
-            pair(kf, vf, HA, HB, ids);
-            frags(kt + 1, kf, vf, ids);
-            gather(0, hk0 + kt + 1, HB);              // HB (tile 1 @ row kt) is consumed
-            pair(kf, vf, HB, HA, ids);                // tile 1 @ row kt+1 == tile 0 @ row kt
-        }
+            for (int kt = 0; kt < FROWS; kt += 2) {
+                f16x8 kf[2], vf[2];
+                uint32_t ids[4] = {0, 0, 0, 0};
+                frags(kt, kf, vf, ids);
+                if (hk0 + kt == 0) gather(1, 0, HB);      // strip start: tile 1 has no predecessor fragment
+                gather(0, hk0 + kt, HA);
+                pair(border_tag, kf, vf, HA, HB, ids);
+                frags(kt + 1, kf, vf, ids);
+                gather(0, hk0 + kt + 1, HB);              // HB (tile 1 @ row kt) is consumed
+                pair(border_tag, kf, vf, HB, HA, ids);    // tile 1 @ row kt+1 == tile 0 @ row kt
+            }
+        };
+        if (border) rows(std::true_type{});
+        else rows(std::false_type{});
     }
     if (!active) return;
 
