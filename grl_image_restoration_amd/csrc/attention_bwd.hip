@@ -366,8 +366,8 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(GrlAttnBwdArgs a) {
                     if (seg * 8 + e < p.head_dim) dpart += op[e] * gp[e];
             }
             // D_i: the four segment owners of a query are four consecutive lanes
-            dpart += __shfl_xor(dpart, 1, 64);
-            dpart += __shfl_xor(dpart, 2, 64);
+            dpart += dpp_move<DPP_QUAD_XOR1>(dpart);
+            dpart += dpp_move<DPP_QUAD_XOR2>(dpart);
             *(f16x8*)(Qs + qq * 64 + ((seg ^ ((qq >> 2) & 3)) << 4)) = qv;
             *(f16x8*)(Gs + qq * 64 + ((seg ^ ((qq >> 2) & 3)) << 4)) = gv;
 #pragma unroll

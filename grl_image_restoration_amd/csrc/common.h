@@ -80,12 +80,22 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_x);
 }
 
-// sum over the 16 lanes that share (lane >> 4)
+// Cross-lane moves inside a 16-lane row as DPP modifiers (VALU only; __shfl_xor goes through ds_bpermute, i.e. the LDS pipe)
+template <int CTRL>
+__device__ __forceinline__ float dpp_move(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+constexpr int DPP_QUAD_XOR1 = 0xB1;   // quad_perm:[1,0,3,2]
+constexpr int DPP_QUAD_XOR2 = 0x4E;   // quad_perm:[2,3,0,1]
+constexpr int DPP_ROW_ROR4 = 0x124;   // row_ror:4
+constexpr int DPP_ROW_ROR8 = 0x128;   // row_ror:8
+
+// sum over the 16 lanes that share (lane >> 4); every lane of the row gets the total
 __device__ __forceinline__ float row16_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    v += __shfl_xor(v, 8, 64);
+    v += dpp_move<DPP_QUAD_XOR1>(v);
+    v += dpp_move<DPP_QUAD_XOR2>(v);   // quad totals
+    v += dpp_move<DPP_ROW_ROR4>(v);    // + the next quad
+    v += dpp_move<DPP_ROW_ROR8>(v);    // + the other pair of quads
     return v;
 }
 

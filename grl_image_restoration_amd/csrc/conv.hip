@@ -303,11 +303,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                float s = psum[nt][e];
-                s += __shfl_xor(s, 1, 64);
-                s += __shfl_xor(s, 2, 64);
-                s += __shfl_xor(s, 4, 64);
-                s += __shfl_xor(s, 8, 64);
+                const float s = row16_sum(psum[nt][e]);
                 if (r16 == 0) red[wave * (NT * 16) + 16 * nt + 4 * g4 + e] = s;
             }
         __syncthreads();
