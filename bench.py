@@ -181,13 +181,23 @@ def training_leg(args, dev, rank, world):
     step()
     prof = ops.profile_end()
     kern = {k: round(sum(v), 3) for k, v in sorted(prof.items(), key=lambda kv: -sum(kv[1]))}
+    # dominant kernel pair of the step: attention backward (attn_dq_kernel + attn_dkv_kernel, one "attention_bwd" probe each).
+    # Algorithmic work = 5 contractions (S recomputed, dP, dV, dK, dQ) against the forward's 2 (QK^T, PV).
+    bwd = prof.get("attention_bwd", [])
+    bwd_ms = sum(bwd) / max(len(bwd), 1)
+    fl_bwd = 2.5 * attention_flops_per_launch(cfg, bsz, (side, side))
+    ach = fl_bwd / (bwd_ms * 1e-3) / 1e12 if bwd_ms > 0 else 0.0
+    roof = {"kernel": "attn_dq_kernel + attn_dkv_kernel (attention backward, recompute-S)", "bound": "mfma", "achieved": round(ach, 2),
+            "peak": PEAK_F16_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / PEAK_F16_TFLOPS, 4), "traffic": None,
+            "launches_timed": len(bwd), "mean_launch_ms": round(bwd_ms, 4), "flops_per_launch": fl_bwd,
+            "share_of_hip_kernel_time": round(sum(bwd) / max(sum(sum(v) for v in prof.values()), 1e-9), 3)}
     return {
         "workload": "BASELINE configs[4]: GRL-Base x4 SR training, 64x64 LQ synthetic pairs, L1 loss, FusedAdamW(lr 2e-4, wd 1e-4)",
         "batch_per_gpu": bsz, "steps": args.train_steps, "ms_per_step": round(dt / args.train_steps * 1e3, 2),
         "samples_per_s": round(world * bsz * args.train_steps / dt, 2),
         "value": round(world * bsz * side * side * args.train_steps / dt / 1e6, 4), "unit": "LQ megapixels/s (training)",
         "parallelism": f"DDP x{world} over RCCL, 32 MB gradient buckets" if world > 1 else "single GPU",
-        "hip_kernel_ms_per_step": kern, "final_loss": round(float(loss.detach()), 5),
+        "hip_kernel_ms_per_step": kern, "roofline": roof, "final_loss": round(float(loss.detach()), 5),
     }
 
 

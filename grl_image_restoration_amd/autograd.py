@@ -19,6 +19,7 @@ true-valued fp32 gradients.  The factor is chosen once per backward pass from th
 (``GradScaleTop``: one host read per step).
 """
 import math
+import weakref
 from typing import Optional, Sequence
 
 import torch
@@ -60,8 +61,72 @@ class GradScaleTop(torch.autograd.Function):
         return dy
 
 
-def _padded(x: torch.Tensor, width: int) -> torch.Tensor:
-    return x if x.shape[1] == width and x.is_contiguous() else F.pad(x, (0, width - x.shape[1])).contiguous()
+_PAD_BLOCKS: dict = {}     # (rows, width, ones, device) -> constant fp32 block appended to a token matrix
+_ZERO_VECS: dict = {}      # (n, device) -> fp32 zeros (bias operand of the data-gradient launches)
+_WEIGHTS: dict = {}        # data_ptr of a weight -> (version, shape, Np, Kp, padded fp16 copy): rebuilt when the optimizer bumps the version
+
+
+def _padded(x: torch.Tensor, width: int, ones: bool = False) -> torch.Tensor:
+    """x [M, K] -> contiguous [M, width] with zero pad columns in ONE launch (a cat with a cached constant block; F.pad is a
+    fill plus a copy).  ``ones``: the first pad column holds 1.0 -- against zero weight columns it is inert in the forward and
+    in the data gradient, and in the weight-gradient contraction dy^T [x | 1 | 0] it yields the bias gradient for free."""
+    M, K = x.shape
+    if K == width:
+        return x.contiguous()
+    key = (M, width - K, ones, x.device)
+    blk = _PAD_BLOCKS.get(key)
+    if blk is None:
+        blk = torch.zeros(M, width - K, dtype=torch.float32, device=x.device)
+        if ones:
+            blk[:, 0] = 1.0
+        _PAD_BLOCKS[key] = blk
+    return torch.cat([x, blk], 1)
+
+
+def _zeros(n: int, device) -> torch.Tensor:
+    z = _ZERO_VECS.get((n, device))
+    if z is None:
+        z = _ZERO_VECS[(n, device)] = torch.zeros(n, dtype=torch.float32, device=device)
+    return z
+
+
+_REGISTERED = weakref.WeakKeyDictionary()   # module -> storage addresses of its parameters (long-lived: safe cache keys)
+
+
+def register_parameters(module: torch.nn.Module) -> None:
+    """Allow the padded fp16 copies of this module's weights to be kept between the forward and the backward of a step (and
+    across steps until the optimizer changes them).  Only registered parameters are cached: a temporary tensor's address can be
+    reused by another tensor with the same shape and version, a parameter's cannot while its module lives (the registration
+    goes away with the module)."""
+    ptrs = frozenset(p.data_ptr() for p in module.parameters())
+    for ptr in ptrs:                       # a previous owner of the same addresses (a deleted model) may have left copies behind
+        _WEIGHTS.pop(ptr, None)
+    _REGISTERED[module] = ptrs
+
+
+def _is_registered(ptr: int) -> bool:
+    return any(ptr in s for s in _REGISTERED.values())
+
+
+def _padded_weight(w: torch.Tensor, Np: int, Kp: int, transposed: bool = False) -> torch.Tensor:
+    """fp16 [Np, Kp] zero-padded copy of a weight (``transposed``: its [Kp, Np] transpose, the operand of the data-gradient
+    launch); for registered parameters kept per parameter and refreshed when the version counter moves (an optimizer step),
+    so the backward of a step finds the copy its forward made."""
+    key = w.data_ptr()
+    sig = (tuple(w.shape), Np, Kp, w.device)
+    keep = _is_registered(key)
+    ent = _WEIGHTS.get(key) if keep else None
+    if ent is None or ent[0] != w._version or ent[1] != sig:
+        buf = ent[2] if ent is not None and ent[1] == sig else torch.zeros(Np, Kp, dtype=ops.GEMM_DTYPE, device=w.device)
+        buf[: w.shape[0], : w.shape[1]].copy_(w.detach())
+        ent = [w._version, sig, buf, None]
+        if keep:
+            _WEIGHTS[key] = ent
+    if not transposed:
+        return ent[2]
+    if ent[3] is None:
+        ent[3] = ent[2].t().contiguous()
+    return ent[3]
 
 
 # ---- the contractions as torch.library custom ops (torch.ops.grl.*) with registered autograd ----------------------------
@@ -72,12 +137,11 @@ def _linear_operands(x, w, b):
     M, K = x.shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
-    xp = _padded(x.detach().float(), Kp)
-    wp = torch.zeros(Np, Kp, dtype=ops.GEMM_DTYPE, device=x.device)
-    wp[:N, :K] = w.detach()
-    bp = torch.zeros(Np, dtype=torch.float32, device=x.device)
+    xp = _padded(x.detach().float(), Kp, ones=True)
+    wp = _padded_weight(w, Np, Kp)
+    bp = _zeros(Np, x.device)
     if b is not None:
-        bp[:N] = b.detach()
+        bp = torch.cat([b.detach().float(), _zeros(Np - N, x.device)]) if Np > N else b.detach().float()
     return xp, wp, bp, (M, K, N, Kp, Np)
 
 
@@ -106,12 +170,16 @@ def _linear_backward(ctx, dy):
     dyp = _padded(dy.float(), Np)
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
-        wt = wp.t().contiguous()                                   # [Kp, Np]: rows = input channels
-        dx = ops.linear(dyp, wt, torch.zeros(Kp, dtype=torch.float32, device=dy.device), out_dtype=torch.float32,
-                        a_scale=s, out_scale=1.0 / s)[:, :K]
-    if ctx.needs_input_grad[1]:
-        dw = ops.gemm_tn(dyp, xp, Np, Kp, a_scale=s, out_scale=1.0 / s)[0, :N, :K]
-    if ctx.has_b and ctx.needs_input_grad[2]:
+        wt = _padded_weight(w, Np, Kp, transposed=True)            # [Kp, Np]: rows = input channels
+        dx = ops.linear(dyp, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s)[:, :K]
+    want_b = ctx.has_b and ctx.needs_input_grad[2]
+    if ctx.needs_input_grad[1] or (want_b and Kp > K):
+        full = ops.gemm_tn(dyp, xp, Np, Kp, a_scale=s, out_scale=1.0 / s)[0]
+        if ctx.needs_input_grad[1]:
+            dw = full[:N, :K]
+        if want_b and Kp > K:
+            db = full[:N, K]                                       # the ones column of xp: sum over the rows of dy
+    if want_b and db is None:
         db = dy.float().sum(0)
     return dx, dw, db
 
@@ -124,7 +192,7 @@ def conv3x3_op(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, B: int, H: int
     """3x3 convolution, stride 1, zero pad 1, on channels-last token matrices x[B*H*W, Cin] -> [B*H*W, Cout] (grl_conv3x3_fwd)."""
     Cout, Cin = w.shape[:2]
     CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
-    xp = _padded(x.detach().float(), CinP)
+    xp = _padded(x.detach().float(), CinP, ones=True)   # (the ones column meets zero weight columns; see _padded)
     y = ops.conv3x3(xp, ops.pack_conv_weight(w.detach(), CinP, CoutP), ops.pack_conv_bias(b.detach(), CoutP), B, H, W)
     return y[:, :Cout].contiguous()
 
@@ -152,14 +220,18 @@ def _conv_backward(ctx, dy):
         gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
         wt = ops.pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous(), gin, gout)
         dyp = _padded(dy.float(), gin)
-        dx = ops.conv3x3(dyp, wt, torch.zeros(gout, dtype=torch.float32, device=dy.device), B, H, W, x_scale=s, out_scale=1.0 / s)[:, :Cin]
-    if ctx.needs_input_grad[1]:
+        dx = ops.conv3x3(dyp, wt, _zeros(gout, dy.device), B, H, W, x_scale=s, out_scale=1.0 / s)[:, :Cin]
+    want_b = ctx.needs_input_grad[2]
+    if ctx.needs_input_grad[1] or (want_b and CinP > Cin):
         n8 = (Cout + 7) // 8 * 8
         dyp = _padded(dy.float(), n8)
-        xp = _padded(x.detach().float(), CinP)
+        xp = _padded(x.detach().float(), CinP, ones=True)
         c = ops.gemm_tn(dyp, xp, n8, CinP, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s)      # [9, n8, CinP]
-        dw = c[:, :Cout, :Cin].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
-    if ctx.needs_input_grad[2]:
+        if ctx.needs_input_grad[1]:
+            dw = c[:, :Cout, :Cin].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
+        if want_b and CinP > Cin:
+            db = c[4, :Cout, Cin]          # centre tap against the ones column of xp: sum of dy over all pixels
+    if want_b and db is None:
         db = dy.float().sum(0)
     return dx, dw, db, None, None, None
 

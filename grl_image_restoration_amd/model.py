@@ -780,6 +780,10 @@ class GRL(nn.Module):
     def _forward_train(self, x):
         """GRL.forward (grl.py:506-551) as a differentiable graph over the HIP kernels (autograd.py)."""
         H0, W0 = x.shape[2:]
+        first = self.conv_first.weight
+        if getattr(self, "_ag_registered", None) != (first.data_ptr(), first.device):   # (re)register after .to() / load
+            AG.register_parameters(self)
+            self._ag_registered = (first.data_ptr(), first.device)
         x = self.check_image_size(x.float())
         mean = self._mean.to(x.device, x.dtype)
         x = (x - mean) * self.img_range

@@ -524,9 +524,10 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     _dev_check(q.t, k.t, v.t, o.t, d_o, lse, table)
     assert o.t.dtype == torch.float32 and d_o.dtype == torch.float32 and d_o.shape == o.t.shape and d_o.is_contiguous() and o.t.is_contiguous()
     assert q.t.is_contiguous() and k.t.is_contiguous() and v.t.is_contiguous() and q.slot == 0 and k.slot == 0 and v.slot == 0 and o.slot == 0
-    d_q = torch.zeros(q.t.shape, dtype=torch.float32, device=q.t.device)
-    d_k = torch.zeros(k.t.shape, dtype=torch.float32, device=q.t.device)
-    d_v = torch.zeros(v.t.shape, dtype=torch.float32, device=q.t.device)
+    # every token of q / k / v belongs to exactly one window of the launch: the kernels write all 32 columns of every row
+    d_q = torch.empty(q.t.shape, dtype=torch.float32, device=q.t.device)
+    d_k = torch.empty(k.t.shape, dtype=torch.float32, device=q.t.device)
+    d_v = torch.empty(v.t.shape, dtype=torch.float32, device=q.t.device)
     d_table = torch.zeros_like(table)
     fwd = _attn_args(q, k, v, o, B, nh, table, masked, ones_col, head_dim, False, None, lse)
     args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale)

@@ -40,7 +40,8 @@ def test_linear_fn_gradients(M, K, N):
     y = AG.GradScaleTop.apply(AG.linear(xd, wd, bd))
     assert _rel(y, F.linear(x.double(), w.double(), b.double())) < 2e-3
     y.backward(dy.cuda())
-    assert _rel(xd.grad, xr.grad) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 1e-5
+    # the bias gradient rides the weight-gradient contraction (ones column of the padded input): fp16-rounded dy, fp32 sums
+    assert _rel(xd.grad, xr.grad) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 2e-3
     assert AG.grad_scale() > 1e4                         # the pass was scaled into fp16 range
 
 
@@ -61,7 +62,7 @@ def test_conv3x3_fn_gradients(B, H, W, Cin, Cout):
     y = AG.GradScaleTop.apply(AG.conv3x3(xd, wd, bd, B, H, W))
     assert _rel(y, tok(F.conv2d(x.double(), w.double(), b.double(), padding=1))) < 2e-3
     y.backward(tok(dy).cuda())
-    assert _rel(xd.grad, tok(xr.grad)) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 1e-5
+    assert _rel(xd.grad, tok(xr.grad)) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 2e-3
 
 
 ATT_CASES = [
