@@ -368,15 +368,17 @@ int launch_shape(const GrlLinearArgs& p, hipStream_t st) {
 
 template <int KSTEPS, int NT, int NCH, int EPI, bool ADD2 = false>
 int launch_one(const GrlLinearArgs& p, hipStream_t st) {
-    static const int shape = getenv("GRL_LINEAR_SHAPE") ? atoi(getenv("GRL_LINEAR_SHAPE")) : -1;
-    if (shape == 0) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 2, 8>(p, st);
-    if (shape == 1) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
-    if (shape == 2) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
-    // split-precision layers: the operand slab alone is 4 * KSTEPS VGPRs -> 8 waves (256 VGPRs each)
-    if constexpr (KSTEPS >= 18) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 8>(p, st);
-    // default: LayerNorm epilogues need ~150 VGPRs -> 12 waves (3 per SIMD); the others fit 16 waves
-    if constexpr (EPI == GRL_EPI_LN_RES) return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
-    return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
+    // exactly one workgroup shape per instantiation (if / else chain: every extra shape is another ~110 kernels to compile):
+    if constexpr (KSTEPS >= 18) {
+        // split-precision layers: the operand slab alone is 4 * KSTEPS VGPRs -> 8 waves (256 VGPRs each)
+        return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 8>(p, st);
+    } else if constexpr (EPI == GRL_EPI_LN_RES || KSTEPS >= 12) {
+        // LayerNorm epilogues need ~150 VGPRs, K = 384 slabs 48 + the fragment reads in flight -> 12 waves (3 per SIMD,
+        // 168 VGPRs; at 16 waves these spill 70-300 registers)
+        return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 12>(p, st);
+    } else {
+        return launch_shape<KSTEPS, NT, NCH, EPI, ADD2, 1, 16>(p, st);
+    }
 }
 
 // chunk = NT n-tiles (NT*16 output channels) swept per pass over the A slab; LayerNorm needs the whole
