@@ -22,6 +22,7 @@
 // dO is multiplied by g_scale on its way to fp16 (gradients of an L1 loss are ~1e-6: below the fp16 normal range); all
 // outputs are un-scaled on store.
 #include "common.h"
+#include <type_traits>
 #include "grl_hip_internal.h"
 #include "attn_common.h"
 
@@ -160,6 +161,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
     // every (32 x 32) tile is a key-row segment against a query-row segment: table entry = U(query 0) + koff(key 0) + key - query
     const bool toeplitz = (p.q.ww & 31) == 0 && (p.k.ww & 31) == 0;
+    const bool band16 = (p.k.shx & 15) == 0;
 
     int U[QT], idq[QT];
     int64_t qrow[QT];
@@ -236,39 +238,69 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
             frag_rows(Ks, kb, l31, half, kf);
             frag_rows(Vs, kb, l31, half, vf);
             frag_cols(Kt, kb, l31, half, ktf);
-            int kofs[16];
+            // PLAIN (compile-time tag): Toeplitz geometry and no shift mask -- every key of the tile is valid and unmasked, and the
+            // bias of (query lane, key row i) is tab[U + koff(key 0) + i]: ascending LDS reads at constant offsets instead of
+            // 16 key-offset + 16 region-id look-ups per tile.  (A run-time `if` inside the element loop would merge the two
+            // versions of dS in 16 register copies per tile.)
+            // MODE 2: the same geometry with a shift mask whose key-column bands are 16 wide (shift % 16 == 0): keys 0..15 of the
+            // tile (accumulator registers 0..7) share one region label, keys 16..31 another -- two look-ups and two selects.
+            auto tile = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                constexpr bool PLAIN = MODE != 0;
+                int kofs[16];
+                if constexpr (!PLAIN) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) kofs[r] = koff[kb + mfma32_row(r, half)];
-#pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                f32x16 S, dP;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { S[r] = tab[U[t] + kofs[r]]; dP[r] = 0.f; }
-                S = mfma32_f16(kf[0], qf[t][0], S);
-                S = mfma32_f16(kf[1], qf[t][1], S);
-                dP = mfma32_f16(vf[0], dof[t][0], dP);
-                dP = mfma32_f16(vf[1], dof[t][1], dP);
-                f32x16 dS;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int idk = kreg[kb + mfma32_row(r, half)];
-                    float s = S[r];
-                    if (idk == 255) s = NEG_BIG;
-                    else if (border && idk != idq[t]) s += MASK_L2;
-                    const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
-                    dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
-                    if (!toeplitz && qvalid[t] && idk != 255) {
-                        if constexpr (GHIST) unsafeAtomicAdd(gtab + U[t] + kofs[r], dS[r] * inv_g);
-                        else atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
-                    }
+                    for (int r = 0; r < 16; ++r) kofs[r] = koff[kb + mfma32_row(r, half)];
                 }
-                f16x8 dsp[2];
-                pack_acc(dS, dsp);
-                dQ[t] = mfma32_f16(ktf[0], dsp[0], dQ[t]);
-                dQ[t] = mfma32_f16(ktf[1], dsp[1], dQ[t]);
-                if (toeplitz)   // masked pairs carry dS = 0 exactly; there are no pad rows in this geometry
-                    diag_ring<GHIST>(dS, lane, dtab, gtab, __builtin_amdgcn_readfirstlane(U[t]) + koff[kb], inv_g);
-            }
+                const int kbase = koff[kb];
+                int id_lo = 0, id_hi = 0;
+                if constexpr (MODE == 2) { id_lo = kreg[kb]; id_hi = kreg[kb + 16]; }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    f32x16 S, dP;
+                    if constexpr (PLAIN) {
+                        const float* tp = tab + (U[t] + kbase + 4 * half);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { S[r] = tp[(r & 3) + 8 * (r >> 2)]; dP[r] = 0.f; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { S[r] = tab[U[t] + kofs[r]]; dP[r] = 0.f; }
+                    }
+                    S = mfma32_f16(kf[0], qf[t][0], S);
+                    S = mfma32_f16(kf[1], qf[t][1], S);
+                    dP = mfma32_f16(vf[0], dof[t][0], dP);
+                    dP = mfma32_f16(vf[1], dof[t][1], dP);
+                    f32x16 dS;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float s = S[r];
+                        if constexpr (!PLAIN) {
+                            const int idk = kreg[kb + mfma32_row(r, half)];
+                            if (idk == 255) s = NEG_BIG;
+                            else if (border && idk != idq[t]) s += MASK_L2;
+                            const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
+                            dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
+                            if (!toeplitz && qvalid[t] && idk != 255) {
+                                if constexpr (GHIST) unsafeAtomicAdd(gtab + U[t] + kofs[r], dS[r] * inv_g);
+                                else atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
+                            }
+                        } else {
+                            if constexpr (MODE == 2) s += (r < 8 ? id_lo : id_hi) != idq[t] ? MASK_L2 : 0.f;
+                            const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
+                            dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
+                        }
+                    }
+                    f16x8 dsp[2];
+                    pack_acc(dS, dsp);
+                    dQ[t] = mfma32_f16(ktf[0], dsp[0], dQ[t]);
+                    dQ[t] = mfma32_f16(ktf[1], dsp[1], dQ[t]);
+                    if (toeplitz)   // masked pairs carry dS = 0 exactly; there are no pad rows in this geometry
+                        diag_ring<GHIST>(dS, lane, dtab, gtab, __builtin_amdgcn_readfirstlane(U[t]) + kbase, inv_g);
+                }
+            };
+            if (toeplitz && !border) tile(std::integral_constant<int, 1>{});
+            else if (toeplitz && band16) tile(std::integral_constant<int, 2>{});
+            else tile(std::integral_constant<int, 0>{});
         }
     }
 
@@ -318,6 +350,11 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(GrlAttnBwdArgs a) {
     load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
 
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
+
+    // Toeplitz geometry (both windows whole multiples of 32 wide: no pad rows, a tile is one row segment) and no shift mask
+    const bool toeplitz = (p.q.ww & 31) == 0 && (p.k.ww & 31) == 0;
+    const bool plain = toeplitz && !border;
+    const bool band16 = (p.q.shx & 15) == 0;
 
     int Uk[QT], idk[QT];
     int64_t krow[QT];
@@ -393,39 +430,74 @@ __global__ __launch_bounds__(256) void attn_dkv_kernel(GrlAttnBwdArgs a) {
             frag_rows(Gs, qb, l31, half, gfr);
             frag_cols(Qt, qb, l31, half, qtf);     // A operand: rows = head dim, k-slots = queries
             frag_cols(Gt, qb, l31, half, gtf);
-            int qofs[16], qids[16];
+            // per-query scalars of the tile's 16 rows of this lane: rows 8g + 4*half + [0..3] are four consecutive queries
             float ql[16], qd[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int qq = qb + mfma32_row(r, half);
-                qofs[r] = qoff[qq]; qids[r] = qreg[qq]; ql[r] = qlse[qq]; qd[r] = qD[qq];
+            for (int g = 0; g < 4; ++g) {
+                const float4 l4 = *(const float4*)(qlse + qb + 8 * g + 4 * half);
+                const float4 d4 = *(const float4*)(qD + qb + 8 * g + 4 * half);
+                ql[4 * g] = l4.x; ql[4 * g + 1] = l4.y; ql[4 * g + 2] = l4.z; ql[4 * g + 3] = l4.w;
+                qd[4 * g] = d4.x; qd[4 * g + 1] = d4.y; qd[4 * g + 2] = d4.z; qd[4 * g + 3] = d4.w;
             }
+            // PLAIN: see attn_dq_kernel -- the bias of (key lane, query row i) is tab[Uk - qoff(query 0) - i]
+            // MODE 2: shift mask with 16-wide query-column bands (queries 0..15 of the tile share a label, 16..31 another)
+            auto tile = [&](auto mode_tag) {
+                constexpr int MODE = decltype(mode_tag)::value;
+                constexpr bool PLAIN = MODE != 0;
+                int qofs[16], qids[16];
+                if constexpr (!PLAIN) {
 #pragma unroll
-            for (int t = 0; t < QT; ++t) {
-                f32x16 S, dP;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { S[r] = tab[Uk[t] - qofs[r]]; dP[r] = 0.f; }
-                S = mfma32_f16(qfr[0], kfb[t][0], S);
-                S = mfma32_f16(qfr[1], kfb[t][1], S);
-                dP = mfma32_f16(gfr[0], vfb[t][0], dP);
-                dP = mfma32_f16(gfr[1], vfb[t][1], dP);
-                f32x16 P, dS;
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    float s = S[r];
-                    if (border && qids[r] != idk[t]) s += MASK_L2;
-                    const float pr = kvalid[t] ? __builtin_amdgcn_exp2f(s - ql[r]) : 0.f;
-                    P[r] = pr;
-                    dS[r] = LN2_F * pr * (dP[r] - qd[r]);
+                    for (int r = 0; r < 16; ++r) {
+                        const int qq = qb + mfma32_row(r, half);
+                        qofs[r] = qoff[qq]; qids[r] = qreg[qq];
+                    }
                 }
-                f16x8 pp[2], dsp[2];
-                pack_acc(P, pp);
-                pack_acc(dS, dsp);
-                dV[t] = mfma32_f16(gtf[0], pp[0], dV[t]);
-                dV[t] = mfma32_f16(gtf[1], pp[1], dV[t]);
-                dK[t] = mfma32_f16(qtf[0], dsp[0], dK[t]);
-                dK[t] = mfma32_f16(qtf[1], dsp[1], dK[t]);
-            }
+                const int qbase = qoff[qb];
+                int id_lo = 0, id_hi = 0;
+                if constexpr (MODE == 2) { id_lo = qreg[qb]; id_hi = qreg[qb + 16]; }
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    f32x16 S, dP;
+                    if constexpr (PLAIN) {
+                        const float* tp = tab + (Uk[t] - qbase - 4 * half);
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { S[r] = tp[-((r & 3) + 8 * (r >> 2))]; dP[r] = 0.f; }
+                    } else {
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) { S[r] = tab[Uk[t] - qofs[r]]; dP[r] = 0.f; }
+                    }
+                    S = mfma32_f16(qfr[0], kfb[t][0], S);
+                    S = mfma32_f16(qfr[1], kfb[t][1], S);
+                    dP = mfma32_f16(gfr[0], vfb[t][0], dP);
+                    dP = mfma32_f16(gfr[1], vfb[t][1], dP);
+                    f32x16 P, dS;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        float s = S[r];
+                        if constexpr (!PLAIN) {
+                            if (border && qids[r] != idk[t]) s += MASK_L2;
+                            const float pr = kvalid[t] ? __builtin_amdgcn_exp2f(s - ql[r]) : 0.f;
+                            P[r] = pr;
+                            dS[r] = LN2_F * pr * (dP[r] - qd[r]);
+                        } else {
+                            if constexpr (MODE == 2) s += (r < 8 ? id_lo : id_hi) != idk[t] ? MASK_L2 : 0.f;
+                            const float pr = __builtin_amdgcn_exp2f(s - ql[r]);
+                            P[r] = pr;
+                            dS[r] = LN2_F * pr * (dP[r] - qd[r]);
+                        }
+                    }
+                    f16x8 pp[2], dsp[2];
+                    pack_acc(P, pp);
+                    pack_acc(dS, dsp);
+                    dV[t] = mfma32_f16(gtf[0], pp[0], dV[t]);
+                    dV[t] = mfma32_f16(gtf[1], pp[1], dV[t]);
+                    dK[t] = mfma32_f16(qtf[0], dsp[0], dK[t]);
+                    dK[t] = mfma32_f16(qtf[1], dsp[1], dK[t]);
+                }
+            };
+            if (plain) tile(std::integral_constant<int, 1>{});
+            else if (toeplitz && band16) tile(std::integral_constant<int, 2>{});
+            else tile(std::integral_constant<int, 0>{});
         }
     }
     const float inv = 1.0f / a.g_scale;
