@@ -29,7 +29,7 @@
 namespace {
 
 constexpr int QT = 2;            // tiles (32 queries resp. keys) per wave
-constexpr int KC = 256;          // streamed rows per LDS chunk
+constexpr int KC = 128;          // streamed rows per LDS chunk
 constexpr int TROW = KC * 2 + 8; // transposed staging: row stride in bytes
 constexpr float LN2_F = 0.69314718055994531f;
 
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // dk + dv
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void attn_dkv_kernel(GrlAttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a) {
     const GrlAttnArgs& p = a.fwd;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
