@@ -27,12 +27,10 @@ constexpr int TH = 8, TW = 32;       // output tile (pixels); wave w owns tile r
 constexpr int CWAVES = 8;
 constexpr int HALO_W = TW + 2, HALO_H = TH + 2;
 
-// ALLTAPS: the weight slices of all 9 taps of the current channel chunk are resident in LDS (9*NT*16 rows),
-// so a chunk costs two barriers instead of ten.  Measured on MI355X (CAB convs): 25-35 % SLOWER than the
-// per-tap double buffer because the larger LDS footprint leaves one workgroup per CU; kept as an opt-in
-// (GRL_CONV_ALLTAPS=1) experiment.
-template <int KC, int NT, bool ALLTAPS>
-__global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int dbg) {
+// (Keeping the weight slices of all 9 taps of a channel chunk resident -- two barriers per chunk instead of ten -- was
+// measured 25-35 % SLOWER on the CAB convs: the larger LDS footprint leaves one workgroup per CU.  Not kept.)
+template <int KC, int NT>
+__global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int ROWB = KC * 2 + 16;                 // padded row (bytes) for pixels and weight rows
     constexpr int KS = KC / 32;                       // MFMA k-steps per chunk
@@ -133,56 +131,23 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p, int
         }
     };
 
-    if constexpr (ALLTAPS) {
-        constexpr int ASEGS = 9 * WSEGS;
-        constexpr int GRP = 4;
-        for (int kc = 0; kc < nkc; ++kc) {
-            __syncthreads();  // previous chunk's readers are done
-            stage_input(kc);
-            for (int i0 = tid; i0 < ASEGS; i0 += GRP * CWAVES * 64) {
-                gemm_x8 wv[GRP];
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    const int i = i0 + j * CWAVES * 64;
-                    if (i < ASEGS) {
-                        const int tap = i / WSEGS, r = i % WSEGS;
-                        wv[j] = *(const gemm_x8*)((const gemm_t*)p.w + (int64_t)tap * p.w_tap_stride + (int64_t)(r / SEG_ROW) * p.CinP +
-                                                  kc * KC + (r % SEG_ROW) * 8);
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < GRP; ++j) {
-                    const int i = i0 + j * CWAVES * 64;
-                    if (i < ASEGS) {
-                        const int tap = i / WSEGS, r = i % WSEGS;
-                        *(gemm_x8*)(wt_s + tap * WT_BYTES + (r / SEG_ROW) * ROWB + (r % SEG_ROW) * 16) = wv[j];
-                    }
-                }
-            }
-            __syncthreads();
-#pragma unroll
-            for (int tap = 0; tap < 9; ++tap) mfma_tap(tap, wt_s + tap * WT_BYTES);
-        }
-    } else {
-        for (int kc = 0; kc < nkc; ++kc) {
-            load_w(0, kc);
-            __syncthreads();  // previous chunk's readers are done with in_s / wt_s
-            if (!(dbg & 8)) stage_input(kc);
-            store_w(0);
-            __syncthreads();
-            for (int tap = 0; tap < 9; ++tap) {
-                if (tap < 8 && !(dbg & 2)) load_w(tap + 1, kc);  // in flight during the MFMAs below
-                if (!(dbg & 1)) mfma_tap(tap, wt_s + (tap & 1) * WT_BYTES);
-                if (tap < 8) {
-                    if (!(dbg & 2)) store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
-                    __syncthreads();
-                }
+    for (int kc = 0; kc < nkc; ++kc) {
+        load_w(0, kc);
+        __syncthreads();  // previous chunk's readers are done with in_s / wt_s
+        stage_input(kc);
+        store_w(0);
+        __syncthreads();
+        for (int tap = 0; tap < 9; ++tap) {
+            if (tap < 8) load_w(tap + 1, kc);  // in flight during the MFMAs below
+            mfma_tap(tap, wt_s + (tap & 1) * WT_BYTES);
+            if (tap < 8) {
+                store_w((tap + 1) & 1);  // the other buffer: its last readers finished before the previous barrier
+                __syncthreads();
             }
         }
     }
 
     // ---- epilogue: lane owns channels 16*nt + 4*g4 + [0..3] of pixel (y0+wave, x0+16*mt+r16) ----
-    if (dbg & 4) { if (acc[0][0][0] == 12345.678f) ((float*)p.out)[0] = 1.f; return; }
     const int gy = y0 + wave;
     float psum[NT][4];
 #pragma unroll
@@ -322,23 +287,13 @@ int launch_conv(const GrlConvArgs& p, hipStream_t st) {
     const dim3 grid((p.W + TW - 1) / TW, (p.H + TH - 1) / TH, p.B);
     const size_t rowb = KC * 2 + 16;
     const size_t lds_in = (size_t)HALO_H * HALO_W * rowb;
-    const size_t lds_all = lds_in + 9 * (size_t)NT * 16 * rowb;
-    hipError_t e;
-    if (lds_all <= 160 * 1024 && getenv("GRL_CONV_ALLTAPS")) {  // measured slower (1 workgroup/CU): opt-in only
-        auto kfn = conv3x3_kernel<KC, NT, true>;
-        e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_all);
-        if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds_all, st, p, 0);
-    } else {
-        size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
-        const size_t tile_b = (size_t)TH * TW * (NT * 32 + 32 + 16);   // LDS-staged 16-bit output tile (epilogue), incl. zero segments
-        if (lds < tile_b) lds = tile_b;
-        auto kfn = conv3x3_kernel<KC, NT, false>;
-        e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        static const int dbg = getenv("GRL_CONV_DEBUG") ? atoi(getenv("GRL_CONV_DEBUG")) : 0;  // timing ablations only
-        hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p, dbg);
-    }
+    size_t lds = lds_in + 2 * (size_t)NT * 16 * rowb;
+    const size_t tile_b = (size_t)TH * TW * (NT * 32 + 32 + 16);   // LDS-staged 16-bit output tile (epilogue), incl. zero segments
+    if (lds < tile_b) lds = tile_b;
+    auto kfn = conv3x3_kernel<KC, NT>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(kfn, grid, dim3(CWAVES * 64), lds, st, p);
     GRL_CHECK_LAUNCH();
     return 0;
 }

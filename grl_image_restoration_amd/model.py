@@ -713,10 +713,14 @@ class GRL(nn.Module):
     @staticmethod
     def _to_planes(t, extra: int = 32):
         """[tokens, nh, d] -> fp32 head planes [nh, tokens, 32] (zero padded)."""
-        return F.pad(t, (0, extra - t.shape[-1])).permute(1, 0, 2).contiguous()
+        return F.pad(t.permute(1, 0, 2), (0, extra - t.shape[-1]))     # pads the permuted view: fill + one strided copy
 
     def _attn_table(self, m: _Affine, win, df, dev):
-        coords = tables.coords_table(win, df, device=dev)
+        key = (tuple(win), df, str(dev))
+        cache = self.__dict__.setdefault("_coords_cache", {})      # constant per geometry: a dozen tiny launches per call otherwise
+        coords = cache.get(key)
+        if coords is None:
+            coords = cache[key] = tables.coords_table(win, df, device=dev)
         h = F.relu(F.linear(coords, m.cpb_mlp[0].weight, m.cpb_mlp[0].bias))
         return tables.kernel_table(16.0 * torch.sigmoid(F.linear(h, m.cpb_mlp[2].weight)))     # differentiable w.r.t. the CPB-MLP
 
@@ -741,8 +745,8 @@ class GRL(nn.Module):
         qs, ks, vs = qkv[:, 3 * C // 2 :].reshape(M, 3, nh_s, d_s).unbind(1)
         P = self._to_planes
 
-        def floor(m):
-            return tables.lazy_floor(tables.clamped_scale(m.logit_scale).to(dev))
+        def floor(sc):   # tables.lazy_floor from the already scaled value: sc = clamped scale * log2e
+            return -1.0 - torch.ceil(sc.detach())
 
         ws, sh = geo.window, geo.window_shift
         st, ss = geo.stripe, geo.stripe_shift_size
@@ -752,19 +756,25 @@ class GRL(nn.Module):
         g_anc = (Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         # window attention (efficient.py:128-165)
         tw = a.window_attn.attn_transform
-        ow = AG.AttentionFn.apply(P(F.normalize(qw, dim=-1) * self._scale(tw).view(1, nh_w, 1)), P(F.normalize(kw, dim=-1)), P(vw),
+        sw = self._scale(tw)
+        ow = AG.AttentionFn.apply(P(F.normalize(qw, dim=-1) * sw.view(1, nh_w, 1)), P(F.normalize(kw, dim=-1)), P(vw),
                                   self._attn_table(tw, geo.window, 1, dev),
-                                  dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh_w, d=d_w, masked=sh > 0, floor=floor(tw)))
+                                  dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh_w, d=d_w, masked=sh > 0, floor=floor(sw)))
         # anchored stripe attention (efficient.py:215-270): anchors -> stripe tokens, then stripe tokens -> anchors
         t1, t2 = a.stripe_attn.attn_transform1, a.stripe_attn.attn_transform2
         an = F.normalize(anc, dim=-1)
-        y = AG.AttentionFn.apply(P(an * self._scale(t1).view(1, nh_s, 1)), P(F.normalize(ks, dim=-1)), P(vs),
+        s1, s2 = self._scale(t1), self._scale(t2)
+        y = AG.AttentionFn.apply(P(an * s1.view(1, nh_s, 1)), P(F.normalize(ks, dim=-1)), P(vs),
                                  self._attn_table(t1, geo.stripe, df, dev),
-                                 dict(q=g_anc, k=g_tok_s, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(t1)))
-        yv = y * (torch.arange(32, device=dev) < d_s).to(y.dtype)      # real head dims only (the kernel's ones column is not a value)
-        os_ = AG.AttentionFn.apply(P(F.normalize(qs, dim=-1) * self._scale(t2).view(1, nh_s, 1)), P(an), yv,
+                                 dict(q=g_anc, k=g_tok_s, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s1)))
+        cache = self.__dict__.setdefault("_coords_cache", {})
+        dmask = cache.get(("dmask", d_s, str(dev)))
+        if dmask is None:
+            dmask = cache[("dmask", d_s, str(dev))] = (torch.arange(32, device=dev) < d_s).float()
+        yv = y * dmask                                                  # real head dims only (the kernel's ones column is not a value)
+        os_ = AG.AttentionFn.apply(P(F.normalize(qs, dim=-1) * s2.view(1, nh_s, 1)), P(an), yv,
                                    self._attn_table(t2, geo.stripe, df, dev),
-                                   dict(q=g_tok_s, k=g_anc, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(t2)))
+                                   dict(q=g_tok_s, k=g_anc, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s2)))
         att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
         x1 = r + self.res_scale * self._drop_path(F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp, self.training)

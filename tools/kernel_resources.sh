@@ -6,11 +6,11 @@
 set -u
 cd "$(dirname "$0")/../grl_image_restoration_amd/csrc"
 echo "# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage  (tools/kernel_resources.sh)"
-for f in attention attention_bwd mlp qkv conv grad misc linear; do
+for f in attention attention_bwd mlp qkv conv grad misc linear linear_k576; do
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -I../../include --cuda-device-only -c $f.hip -o /dev/null \
         -Rpass-analysis=kernel-resource-usage 2>&1 |
     awk '/remark: Function Name:/{name=$(NF-1)} /remark: +TotalSGPRs:/{s=$(NF-1)} /remark: +VGPRs:/{v=$(NF-1)} /remark: +AGPRs:/{a=$(NF-1)}
          /remark: +ScratchSize/{sc=$(NF-1)} /remark: +Occupancy/{o=$(NF-1)} /remark: +VGPRs Spill:/{sp=$(NF-1)}
          /remark: +LDS Size/{printf "Function Name: %s\tTotalSGPRs: %s\tVGPRs: %s\tAGPRs: %s\tScratchSize [bytes/lane]: %s\tVGPRs Spill: %s\tOccupancy [waves/SIMD]: %s\n", name, s, v, a, sc, sp, o}' |
-    if [ $f = linear ]; then grep -E "linear_kernelILi(6|12|18)ELi(6|8|12)E"; elif [ $f = conv ]; then grep -E "Lb0EEE|se_kernel"; else cat; fi
+    if [ ${f:0:6} = linear ]; then grep -E "linear_kernelILi(6|12|18)ELi(6|8|12)E"; else cat; fi
 done
