@@ -713,7 +713,8 @@ class GRL(nn.Module):
     @staticmethod
     def _to_planes(t, extra: int = 32):
         """[tokens, nh, d] -> fp32 head planes [nh, tokens, 32] (zero padded)."""
-        return F.pad(t.permute(1, 0, 2), (0, extra - t.shape[-1]))     # pads the permuted view: fill + one strided copy
+        return F.pad(t.permute(1, 0, 2), (0, extra - t.shape[-1])).contiguous()   # pads the permuted view: fill + one strided copy
+        #                                      (head_dim 32: nothing to pad, .contiguous() makes the copy)
 
     def _attn_table(self, m: _Affine, win, df, dev):
         key = (tuple(win), df, str(dev))
