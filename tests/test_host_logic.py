@@ -217,3 +217,61 @@ def test_training_contractions_are_registered_torch_ops():
     o, lse = torch.ops.grl.attention(q, q, q, torch.empty(3, 228, device="meta"), torch.empty(3, device="meta"), [16, 16, 8, 8, 4, 4],
                                      [16, 16, 8, 8, 4, 4], 1, 3, 30, True)
     assert o.shape == (3, 256, 32) and lse.shape == (3, 256)
+
+
+def test_training_operand_caches():
+    """autograd.py's operand preparation (host logic, runs on the CPU): one-launch padding with the ones column that carries
+    the bias gradient, and the per-parameter padded fp16 weights -- kept only for registered module parameters, refreshed when the
+    optimizer bumps the version counter, dropped when the addresses are registered again (a new model at a recycled address)."""
+    from grl_image_restoration_amd import autograd as AG
+
+    x = torch.randn(5, 180)
+    xp = AG._padded(x, 192, ones=True)
+    assert xp.shape == (5, 192) and xp.is_contiguous() and torch.equal(xp[:, :180], x)
+    assert torch.all(xp[:, 180] == 1) and torch.all(xp[:, 181:] == 0)
+    assert AG._padded(x, 192)[:, 180:].abs().max() == 0 and AG._padded(x, 180) is x
+    # dy^T [x | 1 | 0]: column 180 of the weight-gradient product is the bias gradient
+    dy = torch.randn(5, 7)
+    full = dy.t() @ xp
+    assert torch.allclose(full[:, 180], dy.sum(0), atol=1e-6) and torch.allclose(full[:, :180], dy.t() @ x, atol=1e-5)
+
+    lin = torch.nn.Linear(180, 100)
+    w = lin.weight
+    a = AG._padded_weight(w, 128, 192)
+    assert a.shape == (128, 192) and a.dtype == torch.float16 and torch.equal(a[:100, :180], w.detach().half()) and a[100:].abs().max() == 0
+    assert AG._padded_weight(w, 128, 192) is not a              # not registered: rebuilt every call (temporaries can alias)
+    AG.register_parameters(lin)
+    a = AG._padded_weight(w, 128, 192)
+    assert AG._padded_weight(w, 128, 192) is a                  # forward -> backward of the same step: the same copy
+    at = AG._padded_weight(w, 128, 192, transposed=True)
+    assert at.shape == (192, 128) and torch.equal(at, a.t()) and AG._padded_weight(w, 128, 192, transposed=True) is at
+    with torch.no_grad():
+        w.add_(1.0)                                             # an optimizer step bumps the version
+    b = AG._padded_weight(w, 128, 192)
+    assert torch.equal(b[:100, :180], w.detach().half())
+    assert torch.equal(AG._padded_weight(w, 128, 192, transposed=True), b.t())
+    AG.register_parameters(lin)                                 # re-registration forgets the copies made for the old owner
+    assert w.data_ptr() not in AG._WEIGHTS
+    del lin
+
+
+def test_diagonal_ring_reduction_index_math():
+    """The register-level diagonal sum of csrc/attention_bwd.hip (diag_ring), restated lane by lane in numpy: Horner from key
+    row 31 down to 0 on a 64-lane ring that rotates one lane towards lane 0 per row.  Lane p must end with the sum of the tile's
+    entries on the diagonal key - query = -p (p < 32) or 64 - p (p > 32) -- the table entry  ebase + key - query  the kernel
+    then adds it to with one atomic per lane."""
+    import numpy as np
+
+    rng = np.random.default_rng(0)
+    tile = rng.standard_normal((32, 32))          # [key row][query]
+    z = np.zeros(64)
+    for key in range(31, -1, -1):
+        z = np.roll(z, -1)                        # wave_rol:1 -- lane i takes lane (i + 1) mod 64
+        z[:32] += tile[key]                       # the row sits in lanes 0-31 over zeros (v_permlane32_swap against 0)
+    for p in range(64):
+        if p == 32:
+            assert z[p] == 0.0
+            continue
+        d = -p if p < 32 else 64 - p              # key - query
+        want = sum(tile[k, k - d] for k in range(32) if 0 <= k - d < 32)
+        assert abs(z[p] - want) < 1e-12, (p, d)
