@@ -342,7 +342,7 @@ def run(args, rank, world, local_rank):
             line["tiled"] = tiled
         if training:
             line["training"] = training
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: the other ranks would sit in the barrier
             line["cpu_baseline"] = cpu_baseline(cfg)
         print(json.dumps(line), flush=True)
     if world > 1:
