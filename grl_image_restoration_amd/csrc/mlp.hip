@@ -108,7 +108,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
     // fc2 bias and the norm affine live in LDS behind the ring (read once per tile by every lane)
     float* vec = (float*)(smem + 2 * S::BUFP);
     // Pad channels (>= n_real) of every vector are stored as 0: with the zero pad rows of the packed weights the pad
-    // accumulators are then exactly 0, the norm statistics need no per-channel masks (only a correction term), and the pad
+    // accumulators are then exactly 0, the norm statistics need per-channel masks in the last two n-tiles only, and the pad
     // outputs come out as the pad channels of x (0 in a padded token matrix) without compare/select in the epilogues.
     for (int i = tid; i < 3 * CP; i += THREADS) {
         const float v = i < CP ? p.b2[i] : (i < 2 * CP ? p.ln_g[i - CP] : p.ln_b[i - 2 * CP]);
@@ -119,7 +119,6 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             const float v = i < CP ? p.pb[i] : (i < 2 * CP ? p.n1_g[i - CP] : p.n1_b[i - 2 * CP]);
             vec[3 * CP + i] = (i % CP) < p.n_real ? v : 0.f;
         }
-    const float npad = (float)(CP - p.n_real);
     constexpr int VECF = PROJ ? 8 * CP : 3 * CP;
 
     // Token tile staging: the fp32 rows of the NEXT tile are DMA'd into LDS (rows padded by 16 B) in 1-KiB pieces
@@ -219,11 +218,12 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const float d = pacc[nt][e] - mean;
-                    s2 = fmaf(d, d, s2);
+                    // pad channels (< 32 of them, so only in the last two n-tiles) are left out of the variance: subtracting
+                    // their n_pad * mean^2 afterwards would cancel catastrophically for rows with |mean| >> std
+                    if (nt < NT2 - 2 || 16 * nt + 4 * g4 + e < p.n_real) s2 = fmaf(d, d, s2);
                 }
             s2 += __shfl_xor(s2, 16, 64);
             s2 += __shfl_xor(s2, 32, 64);
-            s2 = fmaxf(s2 - npad * mean * mean, 0.f);   // the pad channels contributed (0 - mean)^2 each
             const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
             const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
             const float* grow = vec + 6 * CP + ((int)(mc0 / p.rows_per_image) - img0) * CP;
@@ -345,11 +345,10 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const float d = acc[nt][e] - mean;
-                s2 = fmaf(d, d, s2);
+                if (nt < NT2 - 2 || 16 * nt + 4 * g4 + e < p.n_real) s2 = fmaf(d, d, s2);   // (see norm1 above)
             }
         s2 += __shfl_xor(s2, 16, 64);
         s2 += __shfl_xor(s2, 32, 64);
-        s2 = fmaxf(s2 - npad * mean * mean, 0.f);
         const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
         const int64_t mc = valid ? m : (int64_t)p.M - 1;
         float* orow = p.out + mc * p.ldo;
@@ -415,6 +414,7 @@ extern "C" int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad) {
 
 static bool mlp_args_ok(const void* x, int64_t ldx, const void* blob, const void* out, int64_t ldo, int M, int Cpad, int Hpad, int n_real) {
     if ((Cpad % 32) || (Hpad % 32) || Hpad <= 0 || (ldx % 4) || (ldo % 4) || ldx < Cpad || ldo < Cpad || n_real > Cpad || n_real <= 0) return false;
+    if (n_real + 32 <= Cpad) return false;   // Cpad = n_real rounded up to 32: the norm epilogues mask pad channels in the last 32 only
     if (x == nullptr || blob == nullptr || out == nullptr || x == out || ((uintptr_t)blob & 15) != 0) return false;
     return true;
 }
