@@ -275,3 +275,14 @@ def test_diagonal_ring_reduction_index_math():
         d = -p if p < 32 else 64 - p              # key - query
         want = sum(tile[k, k - d] for k in range(32) if 0 <= k - d < 32)
         assert abs(z[p] - want) < 1e-12, (p, d)
+
+
+@pytest.mark.parametrize("W,ww,shx", [(64, 32, 16), (256, 32, 16), (64, 64, 32), (128, 64, 32), (32, 32, 16), (256, 128, 64), (128, 64, 0)])
+def test_banded_shift_mask_assumption(W, ww, shx):
+    """The fast attention kernels (forward and backward) apply the shifted-window mask per 16-column band: with windows a whole
+    multiple of 32 wide and shifts a multiple of 16, the 16 consecutive keys (queries) of each half of a 32-aligned tile row
+    share one region label.  Checked against the closed-form region function for the shipped geometries."""
+    assert ww % 32 == 0 and shx % 16 == 0
+    for x0 in range(0, W, 16):
+        labels = {geometry.region1d(x, W, ww, shx) for x in range(x0, x0 + 16)}
+        assert len(labels) == 1, (x0, labels)
