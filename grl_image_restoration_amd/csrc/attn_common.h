@@ -48,4 +48,57 @@ __device__ __forceinline__ void locate(const GrlTokenGrid& g, int b, int wy, int
     rid = 3 * region1d(ry, g.Himg, g.wh, g.shy) + region1d(rx, g.Wimg, g.ww, g.shx);
 }
 
+// 16 x fp16 of one (query, head) slot half -> global as two 16-B stores.  A lane holds 4 x 4 consecutive head dims (8-B
+// pieces), its partner 32 lanes away the interleaved ones: the pair swaps two pieces each so that every lane owns 2 x 8
+// consecutive dims (the epilogue is store-issue bound: a token's 64-B slot is written by 2 lanes x 2 instructions, not 2 x 4).
+__device__ __forceinline__ void store_f16_slot(f16* slot, const float (&v)[16], int half) {
+    uint2 pk[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        pk[g].x = pack_f16(v[4 * g + 0], v[4 * g + 1]);
+        pk[g].y = pack_f16(v[4 * g + 2], v[4 * g + 3]);
+    }
+    const uint2 sa = half ? pk[0] : pk[1], sb = half ? pk[2] : pk[3];
+    uint2 ra, rb;
+    ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
+    rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
+    // half 0: dims 0-7 = own g0 | partner g0, dims 16-23 = own g2 | partner g2;  half 1: dims 8-15 = partner g1 | own g1, 24-31 likewise
+    const uint4 lo = half ? uint4{ra.x, ra.y, pk[1].x, pk[1].y} : uint4{pk[0].x, pk[0].y, ra.x, ra.y};
+    const uint4 hi = half ? uint4{rb.x, rb.y, pk[3].x, pk[3].y} : uint4{pk[2].x, pk[2].y, rb.x, rb.y};
+    *(uint4*)(slot + 8 * half) = lo;
+    *(uint4*)(slot + 8 * half + 16) = hi;
+}
+
+// normalised O^T fragment of one query tile -> global (lane holds head dims 8*g + 4*half + [0..3] of query l31)
+__device__ __forceinline__ void store_o(const GrlAttnArgs& p, const f32x16& O, float inv, int64_t qrow, int head, int half) {
+    if (p.out_dtype == GRL_DT_F32) {
+        float* dst = (float*)p.o.ptr + qrow * p.o.ld + p.o.col0 + head * p.o.hstride + 4 * half;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+            *(float4*)(dst + 8 * g) = float4{O[4 * g + 0] * inv, O[4 * g + 1] * inv, O[4 * g + 2] * inv, O[4 * g + 3] * inv};
+    } else {
+        const int64_t off = qrow * p.o.ld + p.o.col0 + head * p.o.hstride;
+        float v[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] = O[r] * inv;
+        store_f16_slot((f16*)p.o.ptr + off, v, half);
+        if (p.o_lo != nullptr) {   // rounding residual: the low half of a split-precision operand (precision "high")
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] -= (float)to_f16(v[r]);
+            store_f16_slot((f16*)p.o_lo + off, v, half);
+        }
+    }
+}
+
+// row `oc` of an O^T fragment (the ones-column of V: the softmax denominator), valid in both half-waves
+__device__ __forceinline__ float ones_row(const f32x16& O, int oc, int half) {
+    const int base_row = oc & ~4;  // row index with the half bit cleared
+    float cand = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+        if (mfma32_row(r, 0) == base_row) cand = O[r];
+    const float other = xhalf(cand);
+    return (half == ((oc >> 2) & 1)) ? cand : other;
+}
+
 }  // namespace
