@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 12
+ABI_VERSION = 13
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -23,6 +23,8 @@ EXPORTS = [
     "grl_proj_blob_bytes",
     "grl_qkv_fwd",
     "grl_qkv_blob_bytes",
+    "grl_qkv_anchor_fwd",
+    "grl_qkv_anchor_blob_bytes",
     "grl_attention_fwd",
     "grl_layernorm_fwd",
     "grl_layernorm_res_fwd",
@@ -131,6 +133,24 @@ class GrlTailArgs(_Strict):
         ("res_scale", C.c_float),
         ("out", C.c_void_p),
         ("ldo", C.c_int64),
+    ]
+
+
+class GrlQkvAnchorArgs(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("Cpad", C.c_int32),
+        ("blob", C.c_void_p),
+        ("nslots", C.c_int32),
+        ("nanc", C.c_int32),
+        ("out", C.c_void_p),
+        ("out_plane_stride", C.c_int64),
+        ("anc", C.c_void_p),
+        ("anc_plane_stride", C.c_int64),
     ]
 
 
@@ -333,6 +353,10 @@ def lib():
     L.grl_qkv_fwd.restype = C.c_int
     L.grl_qkv_blob_bytes.argtypes = [C.c_int32, C.c_int32]
     L.grl_qkv_blob_bytes.restype = C.c_int64
+    L.grl_qkv_anchor_fwd.argtypes = [C.c_void_p, C.POINTER(GrlQkvAnchorArgs)]
+    L.grl_qkv_anchor_fwd.restype = C.c_int
+    L.grl_qkv_anchor_blob_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
+    L.grl_qkv_anchor_blob_bytes.restype = C.c_int64
     L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
     L.grl_attention_fwd.restype = C.c_int
     L.grl_layernorm_fwd.argtypes = [

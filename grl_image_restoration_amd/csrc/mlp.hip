@@ -142,6 +142,14 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
     for (int q = wave_u; q < XPIECES; q += WV) fetch_x(blockIdx.x, q);
     fetch(0, 0);
     int it = 0;   // running chunk counter of the ring (chunk = it % nchunks, buffer = it & 1)
+    // Chunk-top wait.  The token pieces of the NEXT tile come from HBM (2-3 us under load, longer than a chunk lasts) and are
+    // issued BEHIND the chunk's weight pieces, so a counted wait that leaves this wave's newest DMA in flight still covers the
+    // weights (loads retire in order) and gives every token piece two chunk periods instead of stalling every chunk on it.
+    bool x_in_flight = false;   // wave-uniform: the last DMA this wave issued was a token piece of the next tile
+    auto chunk_wait = [&]() {
+        if (x_in_flight) asm volatile("s_waitcnt vmcnt(1) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
 
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m = tile * (WV * 16) + wave * 16 + r16;
@@ -171,10 +179,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             f32x4 pacc[NT2];
 #pragma unroll
             for (int j = 0; j < NP; ++j, ++it) {
-                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+                chunk_wait();
                 __builtin_amdgcn_s_barrier();
                 char* cur = smem + (it & 1) * S::BUFP;
                 fetch(j + 1, ((it + 1) & 1) * S::BUFP);   // j + 1 == NP is MLP chunk 0
+                x_in_flight = false;
                 if (j == (NP > 1 ? NP - 2 : 0)) {          // CAB rows: needed after the last projection step, two steps of cover
                     const gemm_t* crow = p.cab + mc0 * p.ldcab + 4 * g4;
 #pragma unroll
@@ -273,11 +282,12 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             // Every wave waits for its own DMA pieces (chunk `it` and the token pieces of the previous iteration) before
             // the barrier publishes them; after the barrier nobody reads ring buffer (it+1)&1 any more -- and, at c == 0,
             // everybody has copied its token rows into registers -- so the next DMAs may land.
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // lgkmcnt: my LDS reads of the token tile / last chunk are done
+            chunk_wait();   // (lgkmcnt: my LDS reads of the token tile / last chunk are done)
             __builtin_amdgcn_s_barrier();
             char* cur = smem + (it & 1) * S::BUFP;
             fetch(c + 1 < nchunks ? NP + c + 1 : 0, ((it + 1) & 1) * S::BUFP);
-            for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) fetch_x(next_tile, q);
+            x_in_flight = false;
+            for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) { fetch_x(next_tile, q); x_in_flight = true; }
 
             // ---- h = GELU(W1_c . x + b1_c): two n-tiles of 16 hidden channels ----
             // LDS fragment reads are issued in batches ahead of the MFMAs that consume them (the compiler

@@ -81,12 +81,16 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
     for (int q = wave_u; q < XPIECES; q += WV) fetch_x(blockIdx.x, q);
     fetch(0, 0);
     int it = 0;
+    // DMA completion is awaited just BEFORE a chunk's output stores, not at the top of the next chunk: vmcnt also counts
+    // stores, so a wait at the chunk top would sit out the write acknowledgements of the stores issued a moment earlier
+    // (and the HBM latency of the token pieces of the next tile) once per chunk -- the kernel was latency bound on it.
+    static_assert(true, "");
 
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int m = tile * (TOK * 16) + tg * 16 + r16;
         const bool valid = m < p.M;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_s_barrier();   // the tile's token pieces were awaited inside the previous tile's chunks (first tile: above)
         // operand slab: lane = token r16; k-slots 8*g4 + [0..7] of k-step s = channels 32s + 4*g4 + [0..3] and
         // 32s + 16 + 4*g4 + [0..3] (the weight columns are packed in the same order)
         gemm_x8 a[KSTEPS];
@@ -106,11 +110,13 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
 
 #pragma unroll 1
         for (int c = 0; c < nchunks; ++c, ++it) {
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (this wave's DMA pieces of chunk c were awaited before the previous chunk's stores)
             __builtin_amdgcn_s_barrier();
             const char* cur = smem + (it & 1) * S::BUFP;
             fetch(c + 1 < nchunks ? c + 1 : 0, ((it + 1) & 1) * S::BUFP);
+#ifndef QKV_ABL_NOXDMA
             for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) fetch_x(next_tile, q);
+#endif
 #pragma unroll
             for (int si = 0; si < SPC / SLS; ++si) {
                 const int sl = sl0 + si * SLS;
@@ -127,7 +133,11 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
                 __builtin_amdgcn_sched_barrier(0);
                 f32x4 h0 = f32x4{0, 0, 0, 0}, h1 = f32x4{0, 0, 0, 0};
 #pragma unroll
+#ifdef QKV_ABL_NOMFMA
+                for (int s = 0; s < 1; ++s) {
+#else
                 for (int s = 0; s < KSTEPS; ++s) {
+#endif
                     h0 = mfma16_gemm(wa[s], a[s], h0);
                     h1 = mfma16_gemm(wb_[s], a[s], h1);
                 }
@@ -145,7 +155,12 @@ __global__ __launch_bounds__(WV * 64) void qkv_kernel(GrlQkvArgs p) {
                 uint2 lo, hi;
                 lo.x = pack_f16(h0[0] * f, h0[1] * f); lo.y = pack_f16(h0[2] * f, h0[3] * f);
                 hi.x = pack_f16(h1[0] * f, h1[1] * f); hi.y = pack_f16(h1[2] * f, c31);
+                if (si == SPC / SLS - 1) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next chunk + token pieces landed; older stores long done
+#ifdef QKV_ABL_NOSTORE
+                if (valid && lo.x == 0x12345678u) {
+#else
                 if (valid) {
+#endif
                     f16* o = orow + (int64_t)(c * SPC + sl) * p.out_plane_stride;
                     *(uint2*)(o) = lo;           // channels 4*g4 + [0..3]
                     *(uint2*)(o + 16) = hi;      // channels 16 + 4*g4 + [0..3]

@@ -405,6 +405,8 @@ class GRL(nn.Module):
             bap[h * 32 : h * 32 + d_s] = ba[h * d_s : (h + 1) * d_s]
         pk.update(anc_w=ops.split3_weight(Wap) if hi else Wap.to(G16), anc_b=bap,
                   anc_gs=torch.full((nh_s,), -1.0 if one_s else 1.0, **f32))
+        if not hi and CP in (64, 128, 192):   # q/k/v + 2x2-pooled anchors in one pass over x (csrc/qkv_anchor.hip)
+            pk.update(qa_blob=ops.pack_qkv_anchor(Wp, bp, gs, Wap, bap, pk["anc_gs"]), qa_slots=(G, nh_s))
 
         # --- output projection over the slotted attention output + norm1 ---
         Wo = a.proj.weight.detach().float()
@@ -596,11 +598,14 @@ class GRL(nn.Module):
             return self._block_high(r, pk, geo, B, H, W)
         # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
-        if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
-            qkv = ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"])
+        if "qa_blob" in pk and df == 2 and H % 2 == 0 and W % 64 == 0 and os.environ.get("GRL_QKV_ANCHOR", "1") != "0":
+            qkv, anc = ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W)
         else:
-            qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
-        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
+            if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
+                qkv = ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"])
+            else:
+                qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
+            anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
         att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
         self._attention(qkv, anc, att, pk, geo, B, H, W)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)

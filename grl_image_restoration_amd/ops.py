@@ -240,6 +240,48 @@ def qkv(x: torch.Tensor, blob: torch.Tensor, nslots: int, out: Optional[torch.Te
     return out
 
 
+def pack_qkv_anchor(w: torch.Tensor, bias: torch.Tensor, gscale: torch.Tensor, wa: Optional[torch.Tensor] = None,
+                    ba: Optional[torch.Tensor] = None, ga: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight stream of grl_qkv_anchor_fwd: the slotted QKV matrix w [nslots*32, Cpad] followed by the slotted anchor matrix
+    wa [nanc*32, Cpad] (bias / gscale likewise), K in natural order (layout in include/grl_hip.h).  uint8 device tensor."""
+    dev = w.device
+    if wa is not None:
+        w, bias, gscale = torch.cat([w.float(), wa.float()]), torch.cat([bias.float(), ba.float()]), torch.cat([gscale.float(), ga.float()])
+    N, Cpad = w.shape
+    ns = N // 32
+    nanc = 0 if wa is None else wa.shape[0] // 32
+    assert N % 32 == 0 and Cpad % 32 == 0 and bias.numel() == N and gscale.numel() == ns
+    total = L.lib().grl_qkv_anchor_blob_bytes(Cpad, ns - nanc, nanc)
+    assert total > 0
+    nch = (ns + 1) // 2
+    wrow = Cpad * 2 + 16
+    slot_b = 32 * wrow + 128 + 16
+    img = torch.zeros(2 * nch, slot_b, dtype=torch.uint8, device=dev)
+    wp = w.detach().float().to(GEMM_DTYPE).contiguous()
+    img[:ns, : 32 * wrow].view(ns, 32, wrow)[:, :, : Cpad * 2] = wp.view(torch.uint8).view(ns, 32, Cpad * 2)
+    img[:ns, 32 * wrow : 32 * wrow + 128] = bias.detach().float().view(ns, 32).contiguous().view(torch.uint8).view(ns, 128)
+    img[:ns, 32 * wrow + 128 : 32 * wrow + 132] = gscale.detach().float().view(ns, 1).contiguous().view(torch.uint8).view(ns, 4)
+    blob = torch.zeros(nch, total // nch, dtype=torch.uint8, device=dev)
+    blob[:, : 2 * slot_b] = img.view(nch, 2 * slot_b)
+    return blob.contiguous()
+
+
+def qkv_anchor(x: torch.Tensor, blob: torch.Tensor, nslots: int, nanc: int, B: int, H: int, W: int):
+    """(q/k/v head planes [nslots, M, 32], anchor head planes [nanc, M/4, 32]) (fp16) of the token matrix x [B*H*W, Cpad]
+    (fp32): slotted, normalised QKV projection + 2x2-pooled anchor projection in one pass (grl_qkv_anchor_fwd)."""
+    _dev_check(x, blob)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and blob.dtype == torch.uint8 and blob.is_contiguous()
+    M, Cpad = x.shape
+    assert M == B * H * W and H % 2 == 0 and W % 64 == 0
+    out = torch.empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
+    anc = torch.empty(max(nanc, 1), M // 4, 32, dtype=PLANE_DTYPE, device=x.device)
+    args = L.GrlQkvAnchorArgs(x=_ptr(x), ldx=x.stride(0), B=B, H=H, W=W, Cpad=Cpad, blob=_ptr(blob), nslots=nslots, nanc=nanc,
+                              out=_ptr(out), out_plane_stride=M * 32, anc=_ptr(anc), anc_plane_stride=(M // 4) * 32)
+    with _timed("qkv_anchor"):
+        L.check(L.lib().grl_qkv_anchor_fwd(L.stream_ptr(), C.byref(args)), "grl_qkv_anchor_fwd")
+    return out, (anc if nanc > 0 else None)
+
+
 def pack_proj(w: torch.Tensor) -> torch.Tensor:
     """Projection weight stream of grl_block_tail_fwd from the padded matrix w [Cpad, Cpad] (rows = output channels,
     columns = the slotted attention-output K): chunks of 32 rows x (2*Cpad + 16) bytes fp16, padded to 1 KiB."""

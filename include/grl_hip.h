@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 12
+#define GRL_ABI_VERSION 13
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -175,6 +175,34 @@ typedef struct GrlQkvArgs {
 
 int grl_qkv_fwd(void* stream, const GrlQkvArgs* args);
 int64_t grl_qkv_blob_bytes(int32_t Cpad, int32_t nslots);
+
+/* ---------------------------------------------------------------------------------------------
+ * QKV projection AND anchor projection in one pass over x (round 3; csrc/qkv_anchor.hip).
+ *   replaces  QKVProjection.forward               models/common/mixed_attn_block.py:661-676
+ *             AnchorProjection / AnchorLinear     models/common/mixed_attn_block.py:714-736,739-785
+ *             (avg_pool2d(2) + Linear C -> C/2; the pool commutes with the linear map and is applied to its outputs)
+ *             F.normalize / logit scale of Attention.attn   models/common/mixed_attn_block_efficient.py:85-90,:39
+ * x is the token matrix of B images of H x W tokens (H even, W a multiple of 64; other shapes: GRL_ERR_UNSUPPORTED ->
+ * grl_qkv_fwd + grl_linear_fwd with pooling).  Anchor tokens are the 2 x 2 pooling cells in row-major order.
+ * Weight stream `blob`: chunks of 2 slots, padded to 1 KiB; a slot = 32 rows x (2*Cpad + 16) bytes fp16 (row n = output column
+ * n of the slot, K in natural order) | 32 fp32 bias | 1 fp32 gscale (+12 B); slots 0..nslots-1 = q/k/v, then nanc anchor slots.
+ * gscale as in grl_qkv_fwd.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct GrlQkvAnchorArgs {
+    const float* x;            /* [B*H*W, ldx] fp32 tokens                                            */
+    int64_t ldx;
+    int32_t B, H, W;
+    int32_t Cpad;              /* 64, 128 or 192                                                      */
+    const void* blob;          /* 16-B aligned; grl_qkv_anchor_blob_bytes(Cpad, nslots, nanc) bytes   */
+    int32_t nslots, nanc;
+    void* out;                 /* fp16 planes: element (m, slot, c) at slot*out_plane_stride + m*32 + c */
+    int64_t out_plane_stride;  /* >= B*H*W*32                                                         */
+    void* anc;                 /* fp16 planes of the anchors: (a, slot, c) at slot*anc_plane_stride + a*32 + c (nanc > 0) */
+    int64_t anc_plane_stride;  /* >= B*(H/2)*(W/2)*32                                                 */
+} GrlQkvAnchorArgs;
+
+int grl_qkv_anchor_fwd(void* stream, const GrlQkvAnchorArgs* args);
+int64_t grl_qkv_anchor_blob_bytes(int32_t Cpad, int32_t nslots, int32_t nanc);
 
 /* ---------------------------------------------------------------------------------------------
  * Cosine window / anchored-stripe attention (one call = one softmax(QK^T)V over all windows).

@@ -201,6 +201,59 @@ def test_fused_block_tail(M, C, Hd, rpi):
         assert out[:, C:].abs().max().item() == 0.0
 
 
+@pytest.mark.parametrize("B,H,W,C,nslots,nanc", [(2, 4, 64, 180, 18, 3), (1, 6, 128, 180, 18, 3), (3, 2, 64, 128, 12, 2), (1, 8, 64, 64, 12, 2),
+                                                  (2, 4, 64, 180, 18, 0)])
+def test_qkv_anchor_one_pass(B, H, W, C, nslots, nanc):
+    """grl_qkv_anchor_fwd (q/k/v + 2x2-pooled anchor projection in one pass, 32-token MFMA tiles) against fp64 torch on the
+    fp16-rounded operands, and against the two round-2 kernels it replaces (grl_qkv_fwd, grl_linear_fwd with pooling)."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    CP = (C + 31) // 32 * 32
+    M = B * H * W
+    g = torch.Generator().manual_seed(21)
+    x = torch.zeros(M, CP)
+    x[:, :C] = torch.randn(M, C, generator=g)
+
+    def slotted(n):
+        w = torch.zeros(n * 32, CP)
+        w[:, :C] = torch.randn(n * 32, C, generator=g) / math.sqrt(C)
+        return w, 0.1 * torch.randn(n * 32, generator=g)
+
+    w, b = slotted(nslots)
+    gs = torch.rand(nslots, generator=g) * 10
+    gs[2::3] = 0.0  # pass-through slots (v)
+    gs[1::3] *= -1.0  # K slots: column 31 := 1.0
+    w.view(nslots, 32, CP)[1::3, 31] = 0
+    d = _dev()
+    if nanc:
+        wa, ba = slotted(nanc)
+        wa.view(nanc, 32, CP)[:, 31] = 0
+        ga = torch.full((nanc,), -1.0)
+        blob = ops.pack_qkv_anchor(w.to(d), b.to(d), gs.to(d), wa.to(d), ba.to(d), ga.to(d))
+    else:
+        blob = ops.pack_qkv_anchor(w.to(d), b.to(d), gs.to(d))
+    out, anc = ops.qkv_anchor(x.to(d), blob, nslots, nanc, B, H, W)
+    out = out.cpu()
+    ref = (x.to(torch.float16).double() @ w.to(torch.float16).double().t() + b.double()).view(M, nslots, 32)
+    ref = _groupnorm_ref(ref, gs).permute(1, 0, 2)
+    err = (out.double() - ref).abs().max().item()
+    assert err < 2.5e-3 * max(1.0, ref.abs().max().item()), err
+    assert (out[1::3, :, 31] == 1.0).all()
+    old = ops.linear(x.to(d), w.to(torch.float16).to(d), b.to(d), epi=L.EPI_GROUPNORM, gscale=gs.to(d), planes=True).cpu()
+    assert (out.float() - old.float()).abs().max().item() <= 2.5e-3 * max(1.0, ref.abs().max().item())
+    if nanc:
+        anc = anc.cpu()
+        # the kernel pools the per-token projections (of fp16-rounded tokens); the reference pools first: same value up to rounding
+        y = (x.to(torch.float16).double() @ wa.to(torch.float16).double().t()).view(B, H, W, nanc * 32)
+        pooled = F.avg_pool2d(y.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(-1, nanc, 32) + ba.double().view(1, nanc, 32)
+        aref = _groupnorm_ref(pooled, ga).permute(1, 0, 2)
+        assert anc.shape == (nanc, M // 4, 32)
+        assert (anc.double() - aref).abs().max().item() < 2.5e-3
+        assert (anc[:, :, 31] == 1.0).all()
+        old_a = ops.linear(x.to(d), wa.to(torch.float16).to(d), ba.to(d), epi=L.EPI_GROUPNORM, gscale=ga.to(d), pool=(2, H, W), planes=True).cpu()
+        assert (anc.float() - old_a.float()).abs().max().item() < 4e-3   # (the old kernel rounds the POOLED token to fp16)
+
+
 def test_linear_pooled_anchor():
     """AnchorLinear: avg-pool df x df (mixed_attn_block.py:727-736) fused into the A load."""
     from grl_image_restoration_amd import _lib as L, ops

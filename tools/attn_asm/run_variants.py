@@ -10,7 +10,7 @@ try:
         shutil.copy(v, lib)
         out = subprocess.run([sys.executable, os.path.join(root, "tools", "bench_kernels.py"), "--tiles", "4", "--iters", "20", "--only", only],
                              capture_output=True, text=True, timeout=300)
-        lines = [l for l in out.stdout.splitlines() if l.startswith("attn_")]
+        lines = [l for l in out.stdout.splitlines() if l.split() and l.split()[0] in only.split(",")]
         print(f"{os.path.basename(v):28s}", " | ".join(f"{l.split()[0]} {l.split()[1]} us" for l in lines) or out.stderr[-300:], flush=True)
 finally:
     shutil.move(lib + ".orig", lib)

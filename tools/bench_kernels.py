@@ -67,6 +67,8 @@ def main():
     fl_s = 2 * L_ * N2 * C * B
 
     kernels = {
+        "qkv_anchor": (lambda: ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W), (6 * L_ * C * C + L_ * C * C // 2) * B,
+                       M * (CP * 4 + 18 * 32 * 2 + 3 * 32 * 2 // 4)),
         "qkv_stream": (lambda: ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"], out=qkv), 6 * L_ * C * C * B, M * (CP * 4 + 18 * 32 * 2)),
         "qkv": (lambda: ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv, planes=True),
                 6 * L_ * C * C * B, M * (CP * 4 + 576 * 2)),
