@@ -80,6 +80,25 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_x);
 }
 
+// Two GELUs at once on packed fp32 math (v_pk_mul/fma/add_f32: one issue slot for two elements -- the fused kernels are bound by
+// instruction issue, not by the VALU pipes): same formula and accuracy as gelu_erf, 19 instructions per pair instead of 28.
+typedef __attribute__((ext_vector_type(2))) float f32x2v;
+__device__ __forceinline__ f32x2v gelu_erf2(f32x2v x) {
+    const f32x2v ax = {fabsf(x.x), fabsf(x.y)};
+    const f32x2v z = ax * 0.70710678118654752440f;
+    const f32x2v d = z * 0.3275911f + 1.0f;
+    const f32x2v t = {__builtin_amdgcn_rcpf(d.x), __builtin_amdgcn_rcpf(d.y)};
+    f32x2v poly = t * 1.061405429f + (-1.453152027f);
+    poly = poly * t + 1.421413741f;
+    poly = poly * t + (-0.284496736f);
+    poly = poly * t + 0.254829592f;
+    const f32x2v a = z * z * (-LOG2E_F);
+    const f32x2v e = {__builtin_amdgcn_exp2f(a.x), __builtin_amdgcn_exp2f(a.y)};
+    const f32x2v erf_abs = 1.0f - poly * t * e;
+    const f32x2v erf_x = {copysignf(erf_abs.x, x.x), copysignf(erf_abs.y, x.y)};
+    return (x * 0.5f) * (erf_x + 1.0f);
+}
+
 // Cross-lane moves inside a 16-lane row as DPP modifiers (VALU only; __shfl_xor goes through ds_bpermute, i.e. the LDS pipe)
 template <int CTRL>
 __device__ __forceinline__ float dpp_move(float v) {

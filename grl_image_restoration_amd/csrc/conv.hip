@@ -177,8 +177,10 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                 const float4 b4 = *(const float4*)(p.bias + c);
                 float v[4] = {fmaf(acc[mt][nt][0], osc, b4.x), fmaf(acc[mt][nt][1], osc, b4.y), fmaf(acc[mt][nt][2], osc, b4.z), fmaf(acc[mt][nt][3], osc, b4.w)};
                 if (p.act == 1) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+{
+                        const f32x2v ga = gelu_erf2(f32x2v{v[0], v[1]}), gb = gelu_erf2(f32x2v{v[2], v[3]});
+                        v[0] = ga.x; v[1] = ga.y; v[2] = gb.x; v[3] = gb.y;
+                    }
                 } else if (p.act == 2) {
 #pragma unroll
                     for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;
@@ -221,8 +223,10 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             const float4 b4 = *(const float4*)(p.bias + c);
             float v[4] = {fmaf(acc[mt][nt][0], osc, b4.x), fmaf(acc[mt][nt][1], osc, b4.y), fmaf(acc[mt][nt][2], osc, b4.z), fmaf(acc[mt][nt][3], osc, b4.w)};
             if (p.act == 1) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = gelu_erf(v[e]);
+{
+                    const f32x2v ga = gelu_erf2(f32x2v{v[0], v[1]}), gb = gelu_erf2(f32x2v{v[2], v[3]});
+                    v[0] = ga.x; v[1] = ga.y; v[2] = gb.x; v[3] = gb.y;
+                }
             } else if (p.act == 2) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) v[e] = v[e] > 0.f ? v[e] : v[e] * p.slope;

@@ -172,7 +172,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             gemm_x8 a0[KSTEPS];
             gemm_x4 cb[NT2];
             {
+#ifdef MLP_ABL_NOATT
+                const gemm_t* arow = p.att + (mc0 & 127) * p.ldatt + 8 * g4;
+#else
                 const gemm_t* arow = p.att + mc0 * p.ldatt + 8 * g4;
+#endif
 #pragma unroll
                 for (int s = 0; s < KSTEPS; ++s) a0[s] = *(const gemm_x8*)(arow + 32 * s);
             }
@@ -185,7 +189,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
                 fetch(j + 1, ((it + 1) & 1) * S::BUFP);   // j + 1 == NP is MLP chunk 0
                 x_in_flight = false;
                 if (j == (NP > 1 ? NP - 2 : 0)) {          // CAB rows: needed after the last projection step, two steps of cover
+#ifdef MLP_ABL_NOATT
+                    const gemm_t* crow = p.cab + (mc0 & 127) * p.ldcab + 4 * g4;
+#else
                     const gemm_t* crow = p.cab + mc0 * p.ldcab + 4 * g4;
+#endif
 #pragma unroll
                     for (int nt = 0; nt < NT2; ++nt) cb[nt] = *(const gemm_x4*)(crow + 16 * nt);
                 }
@@ -287,7 +295,9 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             char* cur = smem + (it & 1) * S::BUFP;
             fetch(c + 1 < nchunks ? NP + c + 1 : 0, ((it + 1) & 1) * S::BUFP);
             x_in_flight = false;
+#ifndef MLP_ABL_NOXDMA
             for (int q = c * WV + wave_u; q < XPIECES; q += nchunks * WV) { fetch_x(next_tile, q); x_in_flight = true; }
+#endif
 
             // ---- h = GELU(W1_c . x + b1_c): two n-tiles of 16 hidden channels ----
             // LDS fragment reads are issued in batches ahead of the MFMAs that consume them (the compiler
@@ -295,7 +305,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             const float4 bA = *(const float4*)(cur + S::W1B + S::W2B + (4 * g4) * 4);
             const float4 bB = *(const float4*)(cur + S::W1B + S::W2B + (16 + 4 * g4) * 4);
             f32x4 h0 = f32x4{0, 0, 0, 0}, h1 = f32x4{0, 0, 0, 0};
+#ifdef MLP_KB
+            constexpr int KB = MLP_KB;
+#else
             constexpr int KB = KSTEPS > 4 ? KSTEPS / 2 : KSTEPS;   // k-steps per read batch (register budget)
+#endif
 #pragma unroll
             for (int s0 = 0; s0 < KSTEPS; s0 += KB) {
                 gemm_x8 wa[KB], wb[KB];
@@ -312,16 +326,26 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
             }
-            constexpr int QB = 4, NB = NT2 / QB;   // fc2 n-tiles per read batch; batch k+1 is in flight while k multiplies (deeper prefetch measured slower: the kernel is LDS-bandwidth bound)
+#ifdef MLP_QB
+            constexpr int QB = MLP_QB, NB = NT2 / QB;
+#else
+            constexpr int QB = 4, NB = NT2 / QB;
+#endif   // fc2 n-tiles per read batch; batch k+1 is in flight while k multiplies (deeper prefetch measured slower: the kernel is LDS-bandwidth bound)
             gemm_x8 w2[2][QB];
 #pragma unroll
             for (int j = 0; j < QB; ++j) w2[0][j] = *(const gemm_x8*)(cur + S::W1B + (16 * j + r16) * S::W2ROW + 16 * g4);
             __builtin_amdgcn_sched_barrier(0);
             gemm_x8 hb;   // k-slots 8*g4 + [0..7] of this chunk for token r16 (see the header comment)
-            hb[0] = to_f16(gelu_erf(h0[0] + bA.x)); hb[1] = to_f16(gelu_erf(h0[1] + bA.y));
-            hb[2] = to_f16(gelu_erf(h0[2] + bA.z)); hb[3] = to_f16(gelu_erf(h0[3] + bA.w));
-            hb[4] = to_f16(gelu_erf(h1[0] + bB.x)); hb[5] = to_f16(gelu_erf(h1[1] + bB.y));
-            hb[6] = to_f16(gelu_erf(h1[2] + bB.z)); hb[7] = to_f16(gelu_erf(h1[3] + bB.w));
+#ifdef MLP_ABL_NOGELU
+            hb[0] = (f16)h0[0]; hb[1] = (f16)h0[1]; hb[2] = (f16)h0[2]; hb[3] = (f16)h0[3]; hb[4] = (f16)h1[0]; hb[5] = (f16)h1[1]; hb[6] = (f16)h1[2]; hb[7] = (f16)h1[3];
+            if (false)
+#endif
+            {
+                const f32x2v g0 = gelu_erf2(f32x2v{h0[0] + bA.x, h0[1] + bA.y}), g1 = gelu_erf2(f32x2v{h0[2] + bA.z, h0[3] + bA.w});
+                const f32x2v g2 = gelu_erf2(f32x2v{h1[0] + bB.x, h1[1] + bB.y}), g3 = gelu_erf2(f32x2v{h1[2] + bB.z, h1[3] + bB.w});
+                hb[0] = to_f16(g0.x); hb[1] = to_f16(g0.y); hb[2] = to_f16(g1.x); hb[3] = to_f16(g1.y);
+                hb[4] = to_f16(g2.x); hb[5] = to_f16(g2.y); hb[6] = to_f16(g3.x); hb[7] = to_f16(g3.y);
+            }
             __builtin_amdgcn_sched_barrier(0);
             // ---- acc += W2[:, chunk] . h ----
 #pragma unroll
@@ -333,7 +357,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
+#ifndef MLP_ABL_NOFC2
                 for (int j = 0; j < QB; ++j) acc[QB * k + j] = mfma16_gemm(w2[k & 1][j], hb, acc[QB * k + j]);
+#else
+                for (int j = 0; j < QB; ++j) acc[QB * k + j][0] += (float)w2[k & 1][j][0] * (float)hb[0];
+#endif
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -373,7 +401,11 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             o4.y = res.y + p.res_scale * ((acc[nt][1] - mean) * rstd * g.y + bb.y);
             o4.z = res.z + p.res_scale * ((acc[nt][2] - mean) * rstd * g.z + bb.z);
             o4.w = res.w + p.res_scale * ((acc[nt][3] - mean) * rstd * g.w + bb.w);
+#ifdef MLP_ABL_NOSTORE
+            if (valid && o4.x == 12345.678f) *(float4*)(orow + col) = o4;
+#else
             if (valid) *(float4*)(orow + col) = o4;
+#endif
         }
     }
 }
