@@ -110,8 +110,10 @@ def cpu_baseline(cfg):
         "host_cpus": ncpu,
         "kind": "port",
         "thread_sweep_s_per_64x64_tile": {str(k): round(v, 2) for k, v in sweep.items()},
-        "sample": f"one 128x128 LQ tile (1/4 of a bench tile, same network/geometry), fp32 torch CPU, 1 warm-up + median of 2: "
-                  f"{dt:.1f} s per forward on {best} threads",
+        "sample": f"one 128x128 LQ tile (1/4 of the pixels of a bench tile, same network / window / stripe geometry), fp32 torch CPU, "
+                  f"1 warm-up + median of 2: {dt:.1f} s per forward on {best} threads.  `value` is that tile's own pixels per second; "
+                  f"a 256x256 tile costs 4x the pixel-wise work at the same per-pixel attention cost (window 32, stripe 64x64 "
+                  f"divide both sizes), i.e. ~{4 * dt:.0f} s per bench tile at the same rate (SURVEY 8(d) measured 99 s on 8 threads)",
     }
 
 
@@ -319,13 +321,15 @@ def run(args, rank, world, local_rank):
             "data": "synthetic",
             "config": conf,
             "roofline": {
-                "kernel": "attn_fast_kernel (cosine window / anchored-stripe attention)",
+                "kernel": "attn_rows_kernel (cosine window / anchored-stripe attention, csrc/attention_rows.hip)",
                 "bound": "mfma",
                 "achieved": round(ach, 2),
                 "peak": PEAK_F16_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(ach / PEAK_F16_TFLOPS, 4),
                 "traffic": traffic,
+                "traffic_source": "profiles/attention_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the round, "
+                                  "not measured in this run)" if traffic else None,
                 "launches_timed": len(att),
                 "mean_launch_ms": round(att_ms, 4),
                 "flops_per_launch": fl,
@@ -360,8 +364,8 @@ def _spawned(local_rank, args, world, port):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--tiles", type=int, default=8, help="LQ tiles per GPU per step")
     ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS), help="BASELINE config (3 = the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -294,7 +294,10 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
                     pack_acc(dS, dsp);
                     dQ[t] = mfma32_f16(ktf[0], dsp[0], dQ[t]);
                     dQ[t] = mfma32_f16(ktf[1], dsp[1], dQ[t]);
-                    if (toeplitz)   // masked pairs carry dS = 0 exactly; there are no pad rows in this geometry
+                    // masked pairs carry dS = 0 exactly; there are no pad rows in this geometry.  A clamped (invalid) query tile --
+                    // Nq % 64 == 32: the last wave's second tile repeats query Nq - 1 -- must not reach the table gradient
+                    // (qvalid is wave-uniform per tile here: query tiles are whole 32-wide row segments)
+                    if (toeplitz && __builtin_amdgcn_readfirstlane((int)qvalid[t]))
                         diag_ring<GHIST>(dS, lane, dtab, gtab, __builtin_amdgcn_readfirstlane(U[t]) + kbase, inv_g);
                 }
             };

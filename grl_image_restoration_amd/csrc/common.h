@@ -29,10 +29,10 @@ __device__ __forceinline__ uint32_t pack_bf16(float lo, float hi) {
     return __builtin_bit_cast(uint32_t, v);
 }
 
-// GEMM / convolution operand type.  The attention contractions run on bf16 (they need its exponent
-// range for the un-normalised softmax weights); the token-wise linears and the 3x3 convolutions
-// use fp16 operands at the same MFMA rate: with bf16 weights+activations the network output is
-// 2.2e-3 away from the fp32 reference (weights alone 1.0e-3), with fp16 2e-4 (precision).
+// Operand type of every MFMA contraction (attention since round 2, token-wise linears, 3x3 convolutions): fp16, fp32
+// accumulation.  With bf16 weights + activations the network output is 2.2e-3 away from the fp32 reference (weights alone
+// 1.0e-3), with fp16 2e-4 (precision); the attention weights stay inside the fp16 range through the running
+// softmax offset (csrc/attention_rows.hip).
 typedef _Float16 f16;
 typedef __attribute__((__vector_size__(8 * sizeof(_Float16)))) _Float16 f16x8;
 typedef __attribute__((__vector_size__(4 * sizeof(_Float16)))) _Float16 f16x4;

@@ -213,7 +213,11 @@ __global__ __launch_bounds__(QW * 64) void qkv_anchor_kernel(GrlQkvAnchorArgs p)
                     if (gs != 0.0f) store_slot<false>(o, v, half); else store_slot<true>(o, v, half);
                 }
             } else {
+#ifdef QA_TOKEN_MAJOR   // timing experiment: token-major output rows [m][nslots * 32]
+                f16* o = (f16*)p.out + m_tok * (p.nslots * 32) + slot * 32;
+#else
                 f16* o = (f16*)p.out + (int64_t)slot * p.out_plane_stride + m_tok * 32;
+#endif
                 if (gs != 0.0f) store_slot<false>(o, v, half); else store_slot<true>(o, v, half);
             }
         }

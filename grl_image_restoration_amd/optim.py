@@ -25,7 +25,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def _group_tables(self, gi, plist):
         """Device pointer / size tables of a parameter group (rebuilt when the set of tensors or their storage changes)."""
-        key = tuple((p.data_ptr(), p.numel()) for p in plist)
+        # (the moment buffers are part of the key: load_state_dict replaces them while the parameters stay where they are)
+        key = tuple((p.data_ptr(), p.numel(), self.state[p]["exp_avg"].data_ptr(), self.state[p]["exp_avg_sq"].data_ptr()) for p in plist)
         ent = self._tables.get(gi)
         if ent is not None and ent["key"] == key:
             return ent
@@ -50,6 +51,26 @@ class FusedAdamW(torch.optim.Optimizer):
         self._tables[gi] = ent
         return ent
 
+    def load_state_dict(self, state_dict):
+        """Accepts this class's own state and the one of ``torch.optim.AdamW`` (what the reference's Lightning checkpoints hold
+        under ``optimizer_states``: ``step`` as a 0-dim tensor per parameter)."""
+        super().load_state_dict(state_dict)
+        self._tables = {}
+        self._normalise_state()
+
+    def __setstate__(self, state):
+        super().__setstate__(state)
+        self._tables = {}
+        self._normalise_state()
+
+    def _normalise_state(self):
+        for p, s in self.state.items():
+            if "step" in s and torch.is_tensor(s["step"]):
+                s["step"] = int(s["step"].item())
+            for k in ("exp_avg", "exp_avg_sq"):
+                if k in s and (s[k].dtype != torch.float32 or not s[k].is_contiguous() or s[k].device != p.device):
+                    s[k] = s[k].to(device=p.device, dtype=torch.float32).contiguous()
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = None
@@ -70,7 +91,7 @@ class FusedAdamW(torch.optim.Optimizer):
                     s["step"] = 0
                     s["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
                     s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
-            steps = {self.state[p]["step"] for p in plist}
+            steps = {int(self.state[p]["step"]) for p in plist}
             if len(steps) != 1:
                 raise RuntimeError("FusedAdamW: parameters of one group must share their step count")
             step = steps.pop() + 1

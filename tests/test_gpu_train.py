@@ -6,6 +6,7 @@ oracle's attention) for the attention backward, and the frozen gradients of one 
 (like the forward): 1e-2 relative (norm-wise) per tensor.
 """
 import json
+import copy
 import math
 import os
 
@@ -79,6 +80,9 @@ ATT_CASES = [
     # accumulates its table gradient in global memory
     ("w2a_64x128_df2_bigtable", "w2a", (64, 128), (64, 128), (32, 64), 2, 1, 30, 1),
     ("a2w_64x128_df2_bigtable", "a2w", (64, 128), (64, 128), (32, 64), 2, 1, 30, 1),
+    # 3 x 32 anchors per stripe: Nq % 64 == 32 -- the last wave's second query tile is a clamped duplicate that must not reach the
+    # bias-table gradient
+    ("a2w_6x64_df2_odd_tiles", "a2w", (12, 64), (6, 64), (0, 0), 2, 3, 30),
 ]
 
 
@@ -219,6 +223,49 @@ def test_fused_adamw_matches_torch():
     sa, sb = oa.state[pa[0]], ob.state[pb[0]]
     assert torch.allclose(sa["exp_avg"], sb["exp_avg"], rtol=1e-4, atol=1e-8) and torch.allclose(sa["exp_avg_sq"], sb["exp_avg_sq"], rtol=1e-4, atol=1e-10)
     assert pa[0]._version > 0                                  # the raw-pointer update is visible to autograd / plan stamps
+
+
+def test_fused_adamw_resumes_from_and_into_torch_adamw():
+    """Mid-run restore: the reference's Lightning checkpoints carry a torch.optim.AdamW state (``step`` as a 0-dim tensor
+    per parameter).  FusedAdamW must load it, must not keep pointing at the moment buffers it had before the load, and its own
+    state must load into torch.optim.AdamW again; the two optimizers stay in lock-step across the hand-overs."""
+    from grl_image_restoration_amd import FusedAdamW
+
+    g = torch.Generator().manual_seed(46)
+    shapes = [(96, 40), (300,), (1,), (8, 20, 3, 3), (5000,)]
+    p0 = [torch.randn(s, generator=g) for s in shapes]
+    pa = [t.clone().cuda().requires_grad_(True) for t in p0]
+    pb = [t.clone().cuda().requires_grad_(True) for t in p0]
+    kw = dict(lr=1e-3, weight_decay=1e-2)
+    oa, ob = FusedAdamW(pa, **kw), torch.optim.AdamW(pb, **kw)
+
+    def both_step(k):
+        for a, b in zip(pa, pb):
+            gr = torch.randn(a.shape, generator=g).cuda() * (0.5 ** k)
+            a.grad, b.grad = gr.clone(), gr.clone()
+        oa.step()
+        ob.step()
+
+    for k in range(3):
+        both_step(k)
+    # torch -> fused, into an optimizer that has ALREADY stepped (its pointer tables are built): the loaded moments must be used
+    with torch.no_grad():
+        for a, b in zip(pa, pb):
+            a.copy_(b)
+    oa.load_state_dict(copy.deepcopy(ob.state_dict()))   # (a live state_dict shares its tensors with the optimizer it came from)
+    assert all(isinstance(oa.state[a]["step"], int) for a in pa)
+    for k in range(3, 5):
+        both_step(k)
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() <= 3e-6 * max(1.0, b.abs().max().item())
+    # fused -> torch
+    oc = torch.optim.AdamW(pb, **kw)
+    oc.load_state_dict(copy.deepcopy(oa.state_dict()))
+    ob = oc
+    for k in range(5, 7):
+        both_step(k)
+    for a, b in zip(pa, pb):
+        assert (a - b).abs().max().item() <= 3e-6 * max(1.0, b.abs().max().item())
 
 
 def test_train_mode_steps_reduce_the_loss_and_inference_sees_the_update():

@@ -42,7 +42,7 @@ def ref_attention_slots(q, k, v, table2, index, mask, head_dim):
     """fp32 reference of what grl_attention_fwd computes from its *already prepared* operands.
 
     q (B_, nh, Nq, 32) = normalised*scale*log2e, k (B_, nh, Nk, 32) normalised, v raw, all holding
-    the bf16-rounded values the kernel sees; table2 (nh, rows) in the exp2 domain; index (Nq, Nk);
+    the fp16-rounded values the kernel sees; table2 (nh, rows) in the exp2 domain; index (Nq, Nk);
     mask (nW, Nq, Nk) of 0/-100 or None.  Returns (B_, nh, Nq, 32) float32.
     """
     B_, nh, Nq, _ = q.shape
