@@ -207,6 +207,7 @@ class GrlAttnArgs(_Strict):
         ("k_lo", C.c_void_p),
         ("v_lo", C.c_void_p),
         ("o_lo", C.c_void_p),
+        ("lazy_ceil", C.c_void_p),
     ]
 
 

@@ -22,6 +22,8 @@ import math
 import weakref
 from typing import Optional, Sequence
 
+import threading
+
 import torch
 import torch.nn.functional as F
 
@@ -39,12 +41,18 @@ def pad_width(n: int) -> int:
 
 
 class _State:
-    scale = 1.0          # gradient operand scale of the current backward pass (power of two)
+    # gradient operand scale (a power of two) of the backward pass running on (thread, device): two models -- or two device
+    # threads -- in one process do not see each other's scale, and a pass that never went through GradScaleTop runs at 1.0
+    scales: dict = {}
     target = 64.0        # the largest incoming gradient is brought to about this magnitude
 
 
-def grad_scale() -> float:
-    return _State.scale
+def _scale_key(device) -> tuple:
+    return (threading.get_ident(), torch.device(device).index if device is not None else torch.cuda.current_device())
+
+
+def grad_scale(device=None) -> float:
+    return _State.scales.get(_scale_key(device), 1.0)
 
 
 class GradScaleTop(torch.autograd.Function):
@@ -57,7 +65,7 @@ class GradScaleTop(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         amax = float(dy.abs().max())
-        _State.scale = 2.0 ** math.floor(math.log2(_State.target / amax)) if amax > 0 and math.isfinite(amax) else 1.0
+        _State.scales[_scale_key(dy.device)] = 2.0 ** math.floor(math.log2(_State.target / amax)) if amax > 0 and math.isfinite(amax) else 1.0
         return dy
 
 
@@ -166,7 +174,7 @@ def _linear_setup(ctx, inputs, output):
 def _linear_backward(ctx, dy):
     x, w = ctx.saved_tensors
     xp, wp, _, (M, K, N, Kp, Np) = _linear_operands(x, w, None)
-    s = grad_scale()
+    s = grad_scale(dy.device)
     dyp = _padded(dy.float(), Np)
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
@@ -213,7 +221,7 @@ def _conv_backward(ctx, dy):
     B, H, W = ctx.bhw
     Cout, Cin = w.shape[:2]
     CinP = (Cin + 31) // 32 * 32
-    s = grad_scale()
+    s = grad_scale(dy.device)
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
         # data gradient = the same convolution with the taps flipped and the channel roles swapped
@@ -284,7 +292,7 @@ def _attn_backward(ctx, d_o, d_lse):
     TG = ops.TokenGrid
     dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o.float().contiguous(),
                                          lse, B=B, nh=nh, table=table.detach().contiguous(), masked=masked, ones_col=d if d < 32 else -1,
-                                         head_dim=d, g_scale=grad_scale())
+                                         head_dim=d, g_scale=grad_scale(d_o.device))
     return dq, dk, dv, dtab, None, None, None, None, None, None, None
 
 

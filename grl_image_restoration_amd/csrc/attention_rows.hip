@@ -35,6 +35,7 @@ constexpr int KBUF = RKC * 64;        // bytes of one K (or V) chunk buffer
 constexpr int TBUF = 4096;            // bytes of one table-window buffer
 constexpr int ROWS_LDS = 4 * KBUF + 2 * TBUF;
 constexpr float ROWS_REST = 4.0f;     // after an offset move the row maximum sits in (2^3, 2^4]
+constexpr float ROWS_EXTRA = 3.0f;    // ... unless up to this much more reaches the level where the overflow test can go (msafe)
 
 struct RowsGeom {
     int qseg, units, upw, nqs;
@@ -199,12 +200,15 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         bl = lds0 + TOFF + 4 * (4 * half - l31);
     }
     const int d4 = __builtin_amdgcn_readfirstlane(4 * D);
+    // offsets at or above msafe: logit - offset <= 13.5 for every key of the head (GrlAttnArgs.lazy_ceil)
+    const float msafe = p.lazy_ceil != nullptr ? __builtin_ceilf(p.lazy_ceil[head] - 13.5f) : 3.0e38f;
 
     // BORDER is a compile-time tag: each instance of the chunk loop holds ONE asm statement (with both variants in one loop
     // the register allocator shuffled and spilled the O / Q operands around every statement)
     auto chunks = [&](auto border_tag) {
     constexpr bool BORDER = decltype(border_tag)::value;
     int sk = 0, hk0 = 0;
+    int nochk = 0;   // wave-uniform: every query's offset is within 13.5 of the head's logit bound, no weight can reach 2^14 any more
     DBG_T(t_loop);
     DBG_ADD(0, t_loop - t_start);
 #pragma unroll 1
@@ -250,19 +254,19 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         DBG_ADD(3, t_c3 - t_c2);
         while (true) {
             int done;
-            const int rs_u = __builtin_amdgcn_readfirstlane(rs);
+            const int rs_u = __builtin_amdgcn_readfirstlane(rs), nochk_u = __builtin_amdgcn_readfirstlane(nochk);
             if constexpr (BORDER) {
                 uint32_t t0, t1, t2;
                 asm volatile(ATTN_ROWS4_MASK1
                              : [o0] "+v"(O0), [o1] "+v"(O1), [sb] "+s"(sb), [done] "=s"(done), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)
                              : [ka0] "v"(ka0), [va] "v"(va), [bl] "v"(bl), [q00] "v"(q00), [q01] "v"(q01), [q10] "v"(q10), [q11] "v"(q11),
-                               [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par), [ids] "s"(ids), [idq0] "v"(idq0), [idq1] "v"(idq1)
+                               [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par), [nochk] "s"(nochk_u), [ids] "s"(ids), [idq0] "v"(idq0), [idq1] "v"(idq1)
                              : ATTN_ROWS_CLOBBER);
             } else {
                 asm volatile(ATTN_ROWS4_MASK0
                              : [o0] "+v"(O0), [o1] "+v"(O1), [sb] "+s"(sb), [done] "=s"(done)
                              : [ka0] "v"(ka0), [va] "v"(va), [bl] "v"(bl), [q00] "v"(q00), [q01] "v"(q01), [q10] "v"(q10), [q11] "v"(q11),
-                               [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par)
+                               [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par), [nochk] "s"(nochk_u)
                              : ATTN_ROWS_CLOBBER);
             }
             if (done == RROWS) { DBG_T(t_c4); DBG_ADD(4, t_c4 - t_c3); break; }
@@ -306,7 +310,16 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
                 for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, S0[r]); mx1 = fmaxf(mx1, S1[r]); }
                 mx0 = fmaxf(mx0, xhalf(mx0));
                 mx1 = fmaxf(mx1, xhalf(mx1));
-                const float d0 = fmaxf(0.f, __builtin_ceilf(mx0) - ROWS_REST), d1 = fmaxf(0.f, __builtin_ceilf(mx1) - ROWS_REST);
+                float d0 = fmaxf(0.f, __builtin_ceilf(mx0) - ROWS_REST), d1 = fmaxf(0.f, __builtin_ceilf(mx1) - ROWS_REST);
+                {
+                    // offsets within ROWS_EXTRA of the level where the overflow test becomes unnecessary go there right away
+                    // (the row maximum then rests at 2^(ROWS_REST - ROWS_EXTRA) at worst: ample for fp16 weights)
+                    const float t0 = (float)q01[7], t1 = (float)q11[7], u0 = xhalf(t0), u1 = xhalf(t1);
+                    float m0 = d0 - (half ? t0 : u0), m1 = d1 - (half ? t1 : u1);   // the new offsets
+                    if (m0 < msafe && m0 >= msafe - ROWS_EXTRA) { d0 += msafe - m0; m0 = msafe; }
+                    if (m1 < msafe && m1 >= msafe - ROWS_EXTRA) { d1 += msafe - m1; m1 = msafe; }
+                    nochk = __builtin_amdgcn_ballot_w64(!(m0 >= msafe && m1 >= msafe)) == 0;
+                }
                 if (half) { q01[7] = (f16)((float)q01[7] - d0); q11[7] = (f16)((float)q11[7] - d1); }   // slot 31 holds -m
                 const float f0 = __builtin_amdgcn_exp2f(-d0), f1 = __builtin_amdgcn_exp2f(-d1);
 #pragma unroll

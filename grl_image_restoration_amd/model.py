@@ -450,6 +450,8 @@ class GRL(nn.Module):
         pk["tab_w"] = table(a.window_attn.attn_transform, geo.window, 1)
         pk["tab_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df)
         pk["tab_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df)
+        pk.update(ceil_w=tables.lazy_ceil(sc_w, pk["tab_w"]), ceil_a2w=tables.lazy_ceil(sc_1, pk["tab_a2w"]),
+                  ceil_w2a=tables.lazy_ceil(sc_2, pk["tab_w2a"]))
         assert pk["tab_w"].shape[1] == (table_rows(geo.window, geo.window) + 3) // 4 * 4
         assert pk["tab_a2w"].shape[1] == (table_rows(geo.anchor_stripe, geo.stripe) + 3) // 4 * 4
 
@@ -569,7 +571,7 @@ class GRL(nn.Module):
             TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w, H, W, ws[0], ws[1], sh, sh),
             TG(qkv, 2 * nh_w, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
             B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0,
-            ones_col=d_w if d_w < 32 else -1, head_dim=d_w, k_one31=pk["one_w"], lazy_floor=pk["floor_w"], lse=ls[0],
+            ones_col=d_w if d_w < 32 else -1, head_dim=d_w, k_one31=pk["one_w"], lazy_floor=pk["floor_w"], lse=ls[0], lazy_ceil=pk.get("ceil_w"),
             q_lo=qkv_lo, k_lo=qkv_lo, v_lo=qkv_lo,
         )
         s0 = 3 * nh_w
@@ -582,11 +584,11 @@ class GRL(nn.Module):
         g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         oc = d_s if d_s < 32 else -1
         ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
-                      ones_col=oc, head_dim=d_s, k_one31=pk["one_s"], lazy_floor=pk["floor_a2w"], lse=ls[1],
+                      ones_col=oc, head_dim=d_s, k_one31=pk["one_s"], lazy_floor=pk["floor_a2w"], lse=ls[1], lazy_ceil=pk.get("ceil_a2w"),
                       q_lo=anc_lo, k_lo=qkv_lo, v_lo=qkv_lo, o_lo=y_lo)
         ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s, table=pk["tab_w2a"],
                       masked=geo.stripe_shift, ones_col=oc, head_dim=d_s, k_one31=pk["one_s"],
-                      lazy_floor=pk["floor_w2a"], lse=ls[2], q_lo=qkv_lo, k_lo=anc_lo, v_lo=y_lo)
+                      lazy_floor=pk["floor_w2a"], lse=ls[2], q_lo=qkv_lo, k_lo=anc_lo, v_lo=y_lo, lazy_ceil=pk.get("ceil_w2a"))
         return y
 
     def _block(self, r, pk, geo: BlockGeo, B, H, W):

@@ -372,7 +372,7 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
               masked: bool, ones_col: int, head_dim: int, k_one31: bool = False,
               lazy_floor: Optional[torch.Tensor] = None, lse: Optional[torch.Tensor] = None,
               q_lo: Optional[torch.Tensor] = None, k_lo: Optional[torch.Tensor] = None, v_lo: Optional[torch.Tensor] = None,
-              o_lo: Optional[torch.Tensor] = None):
+              o_lo: Optional[torch.Tensor] = None, lazy_ceil: Optional[torch.Tensor] = None):
     """softmax(q k^T + bias(+mask)) v over every window of every image; see grl_attention_fwd.
     ``q_lo / k_lo / v_lo``: fp16 rounding residuals of q / k / v (same tensors' layout; ``TokenGrid.t`` twins) for the
     split-precision mode, ``o_lo``: residual output twin of ``o.t``.
@@ -385,6 +385,8 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
     assert q.tokens >= B * q.Himg * q.Wimg and k.tokens >= B * k.Himg * k.Wimg
     if lazy_floor is not None:
         assert lazy_floor.dtype == torch.float32 and lazy_floor.is_contiguous() and lazy_floor.numel() == nh
+    if lazy_ceil is not None:
+        assert lazy_ceil.dtype == torch.float32 and lazy_ceil.is_contiguous() and lazy_ceil.numel() == nh and lazy_ceil.device == table.device
     if lse is not None:
         assert lse.dtype == torch.float32 and lse.is_contiguous() and lse.shape[0] == nh and lse.shape[1] >= q.tokens
     def twin(g: TokenGrid, t: Optional[torch.Tensor]):
@@ -397,7 +399,7 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
                          trows=(q.wh + k.wh - 1) * (q.ww + k.ww - 1), tstride=table.shape[1], masked=int(masked), ones_col=ones_col,
                          head_dim=head_dim, out_dtype=_KIND[o.t.dtype], k_one31=int(k_one31), lazy_floor=_ptr(lazy_floor),
                          lse=_ptr(lse), lse_stride=lse.stride(0) if lse is not None else 0,
-                         q_lo=twin(q, q_lo), k_lo=twin(k, k_lo), v_lo=twin(v, v_lo), o_lo=twin(o, o_lo))
+                         q_lo=twin(q, q_lo), k_lo=twin(k, k_lo), v_lo=twin(v, v_lo), o_lo=twin(o, o_lo), lazy_ceil=_ptr(lazy_ceil))
     with _timed("attention"):
         L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
     return o.t

@@ -57,3 +57,10 @@ def lazy_floor(scale: torch.Tensor) -> torch.Tensor:
     """Integer-valued lower bound (log2 domain) of every unmasked logit ``scale*cos + bias`` of a head
     (|cos| <= 1, bias >= 0): the start value of the attention kernel's running softmax offset."""
     return (-torch.ceil(scale * LOG2E) - 1.0).float().contiguous()
+
+
+def lazy_ceil(scale: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """Upper bound (log2 domain) of every logit ``scale*cos + bias`` of a head: |cos| <= 1 and the largest entry of the head's
+    kernel table (nh, rows4).  Masked logits only go down.  See GrlAttnArgs.lazy_ceil."""
+    # (q and k are unit vectors rounded to fp16 element by element: the 0.4 % + 0.05 covers that with a wide margin)
+    return (scale.reshape(-1).float() * (LOG2E * 1.004) + 0.05 + table.max(dim=1).values.clamp_min(0.0)).float().contiguous()

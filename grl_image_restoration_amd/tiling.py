@@ -46,14 +46,15 @@ def stitch(outs: Sequence[torch.Tensor], origins: Sequence[Tuple[int, int]], sha
 
 
 def forward_tiled(model: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor, tile: int, overlap: int, scale: int,
-                  out_channels: Optional[int] = None, tile_batch: int = 8, group=None) -> torch.Tensor:
+                  out_channels: Optional[int] = None, tile_batch: int = 8, group=None, force_collective: bool = False) -> torch.Tensor:
     """Tiled inference of ``x`` (b, c, h, w).  With an initialised process group every rank passes the
-    SAME ``x`` and receives the SAME stitched output; without one it is the single-GPU batched loop."""
+    SAME ``x`` and receives the SAME stitched output; without one it is the single-GPU batched loop.
+    ``force_collective``: run the all-gather branch even at world size 1 (RCCL smoke test on a single GPU)."""
     b, c, h, w = x.shape
     oc = out_channels or c
     tile, origins = tile_list(h, w, tile, overlap)
     n = len(origins)
-    distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    distributed = dist.is_available() and dist.is_initialized() and (dist.get_world_size(group) > 1 or force_collective)
     rank, world = (dist.get_rank(group), dist.get_world_size(group)) if distributed else (0, 1)
     lo, hi, per = shard_bounds(n, rank, world)
 

@@ -256,6 +256,9 @@ typedef struct GrlAttnArgs {
     const void* k_lo;        /* the grids of q, k, v (same ld / hstride / col0).  With any of them the generic kernel forms */
     const void* v_lo;        /* S = q_hi k_hi + q_lo k_hi + q_hi k_lo and O = P v_hi + P v_lo (~22-bit operands)            */
     void* o_lo;              /* optional, GRL_DT_F16 output: residual o - fp16(o) on o's grid (the next attention's v_lo)    */
+    const float* lazy_ceil;  /* optional [nh]: upper bound of every logit of the head (log2 domain: ceil(scale*log2e) + max of its   */
+                             /* table).  Once the running offsets of a wave's queries are within 13.5 of it no weight can reach     */
+                             /* 2^14 any more and the row-streaming kernel stops testing for it (NULL: always test)                 */
 } GrlAttnArgs;
 
 int grl_attention_fwd(void* stream, const GrlAttnArgs* args);

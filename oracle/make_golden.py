@@ -40,6 +40,9 @@ FIXTURES = [
     ("tiny_sr2_ckpt_64_hiscale", "tiny", "sr_ckpt_df4", 2, 64, (64, 64), "sr", dict(sd=dict(logit_scale_mean=LN100))),
     # the bench shape itself: two 256x256 LQ tiles (4x4 stripes, 8x8 windows per tile, both tile groups of the 2-stream split)
     ("base_sr4_ckpt_256", "base", "sr_ckpt_df2", 4, 256, (256, 256), "sr", dict(batch=2, quantise=True, sub2=4)),
+    # the bench shape with checkpoint-like logit scales (around ln 100: about half of the heads at the clamp) -- the headline is
+    # measured on this kernel path, so its parity is pinned at the benchmarked shape, not only at 64x64
+    ("base_sr4_ckpt_256_hiscale", "base", "sr_ckpt_df2", 4, 256, (256, 256), "sr", dict(batch=1, quantise=True, sd=dict(logit_scale_mean=LN100))),
     # BASELINE config 4 at a real tile: 384x384 (2 x 4 tiles of the 1280x720 frame), window 12, stripes 48x96, anchors /4
     ("base_deblur_384", "base", "deblur", 1, 384, (384, 384), "deblur", dict(frame=(720, 1280), tile=384, overlap=48, tiles=(0, 5))),
 ]
@@ -91,8 +94,9 @@ def main(only=None):
         if ex.get("quantise"):
             q, lo, step = quantise(y[:1])
             arrays.update(output_q=q, q_lo=np.float64(lo), q_step=np.float64(step))
-            s = ex["sub2"]
-            arrays["output_b1_sub"] = y[1:, :, ::s, ::s].contiguous().numpy()
+            s = ex.get("sub2", 1)
+            if y.shape[0] > 1:
+                arrays["output_b1_sub"] = y[1:, :, ::s, ::s].contiguous().numpy()
             meta.update(sub2=s, out_shape=list(y.shape),
                         out_sum=[float(y[i].double().sum()) for i in range(y.shape[0])],
                         out_abs_sum=[float(y[i].double().abs().sum()) for i in range(y.shape[0])])

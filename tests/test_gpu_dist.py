@@ -1,0 +1,69 @@
+"""RCCL smoke on ONE MI355X (SURVEY 8(e) / VERDICT r2 #7): the "nccl" backend at world size 1 through the product's two
+distributed code paths -- the tile all-gather of tiling.forward_tiled and one DDP training step (ddp.wrap + FusedAdamW) -- so
+that the first multi-GPU run cannot fail on plumbing (process-group init, device binding, collectives on GPU tensors, bucket
+views).  Numerics across ranks are covered by the gloo world-2/3 tests (tests/test_tiling_distributed.py, test_ddp_gloo.py)."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+@pytest.fixture()
+def nccl_world1():
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()))
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    yield
+    dist.destroy_process_group()
+
+
+def test_tile_all_gather_over_rccl(nccl_world1):
+    from grl_image_restoration_amd import GRL, make_config, tiling
+    from oracle import engine_oracle as E
+
+    cfg = make_config("tiny", "sr_ckpt_df4", upscale=2, img_size=64)
+    torch.manual_seed(0)
+    m = GRL(**cfg).eval().cuda()
+    x = torch.rand(1, 3, 96, 160, generator=torch.Generator().manual_seed(5)).cuda()
+    with torch.no_grad():
+        want = E.forward_tile(m, x, 64, 16, 2)                                             # the reference's serial loop
+        got = tiling.forward_tiled(m, x, 64, 16, 2, tile_batch=2, force_collective=True)   # all_gather_into_tensor on RCCL
+    assert got.shape == want.shape and torch.isfinite(got).all()
+    # same per-tile outputs up to the batch composition (tiles run 2 at a time here, 1 at a time in the serial loop)
+    assert (got - want).abs().max().item() < 2e-4
+
+
+def test_ddp_step_over_rccl(nccl_world1):
+    from grl_image_restoration_amd import GRL, FusedAdamW, ddp, make_config
+
+    cfg = make_config("tiny", "sr_ckpt_df4", upscale=2, img_size=64)
+    torch.manual_seed(0)
+    m = GRL(**cfg).cuda().train()
+    w = ddp.wrap(m, torch.device("cuda", 0), bucket_mb=32, compress_bf16=True)   # the bf16 wire hook goes through all_reduce
+    opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.rand(2, 3, 64, 64, generator=g).cuda(), torch.rand(2, 3, 128, 128, generator=g).cuda()
+    before = [p.detach().clone() for p in m.parameters()]
+    losses = []
+    for _ in range(2):
+        opt.zero_grad(set_to_none=True)
+        loss = torch.nn.functional.l1_loss(w(x), y)
+        loss.backward()
+        assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
+        opt.step()
+        losses.append(float(loss))
+    assert all(l == l and abs(l) < 10 for l in losses)                                   # (stochastic depth is on: no monotonic claim)
+    assert sum(int((a != b.detach()).any()) for a, b in zip(before, m.parameters())) > len(before) // 2   # the update went through

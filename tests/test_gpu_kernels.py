@@ -408,6 +408,7 @@ def _attention_case(case, offset, planes, scale_hi, out_dtype=torch.float16, wan
         TG(out, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
         B=B, nh=nh, table=tab_k.to(dev), masked=masked, ones_col=d if ones else -1, head_dim=d,
         k_one31=one31, lazy_floor=tables.lazy_floor(scale).to(dev) if offset == "lazy" else None, lse=lse,
+        lazy_ceil=tables.lazy_ceil(scale, tab_k).to(dev) if offset == "lazy" else None,
     )
     torch.cuda.synchronize()
     got = (out.permute(1, 0, 2) if planes else out.view(-1, nh, 32)).float().cpu()[..., :d]

@@ -36,8 +36,34 @@ def f32bits(x):
 
 
 def gen(rows, mask, kstride=2048, abl=()):
+    """Two copies of the row loop in one statement: with the overflow test, and -- entered when %[nochk] != 0: the offsets of
+    all the wave's queries are within 13.5 of the head's logit bound, nothing can trip -- without it (a per-row skip would be
+    a taken branch per row)."""
+    L = []
+    if mask:
+        L.append(f"s_mov_b32 %[t2], 0x{f32bits(-MASK_L2):08x}")    # +144.27: multiplied by -|id_k - id_q|
+    L.append("s_cmp_lg_u32 %[nochk], 0")
+    L.append("s_cbranch_scc1 200f")
+    L += body(rows, mask, kstride, abl, True, 0)
+    L.append("s_branch 99f")
+    L.append("200:")
+    L += body(rows, mask, kstride, abl + ("nocheck",), False, 100)
+    if "nocheck" not in abl:
+        L.append("s_branch 99f")
+        for r in range(rows):
+            L.append(f"{90 + r}:")
+            L.append("s_waitcnt lgkmcnt(0)")        # the V^T reads of the abandoned row still target VF
+            L.append(f"s_mov_b32 %[done], {r}")
+            if r + 1 < rows:
+                L.append("s_branch 99f")
+    L.append("99:")
+    return L
+
+
+def body(rows, mask, kstride, abl, check, lb):
     L = []
     e = L.append
+    lab = lambda n: str(lb + n)
 
     def gather(dst):
         # the address register is the fragment's own last register: it is read at issue, the data arrives later
@@ -45,26 +71,24 @@ def gen(rows, mask, kstride=2048, abl=()):
             e(f"ds_read2_b32 {v(dst + 2 * i, 2)}, {v(dst + 15)} offset0:{o0} offset1:{o1}")
 
     # ---- entry: the carry fragment of tile 1 (= tile 0's fragment of the previous key row) goes where row rs expects it
-    if mask:
-        e(f"s_mov_b32 %[t2], 0x{f32bits(-MASK_L2):08x}")    # +144.27: multiplied by -|id_k - id_q|
     e("s_bitcmp1_b32 %[rs], 0")
-    e("s_cbranch_scc1 80f")
+    e(f"s_cbranch_scc1 {lab(80)}f")
     e(f"v_add_u32 {v(B + 15)}, %[sb], %[bl]")
     e(f"v_subrev_u32 {v(B + 15)}, %[d4], {v(B + 15)}")
     gather(B)                              # even start row: carry in B
-    e("s_branch 81f")
-    e("80:")
+    e(f"s_branch {lab(81)}f")
+    e(f"{lab(80)}:")
     e(f"v_add_u32 {v(A + 15)}, %[sb], %[bl]")
     e(f"v_subrev_u32 {v(A + 15)}, %[d4], {v(A + 15)}")
     gather(A)                              # odd start row: carry in A
-    e("81:")
+    e(f"{lab(81)}:")
     for r in range(1, rows):
         e(f"s_cmp_eq_u32 %[rs], {r}")
-        e(f"s_cbranch_scc1 7{r}f")
+        e(f"s_cbranch_scc1 {lab(70 + r)}f")
     for r in range(rows):
         X, Y = (A, B) if r % 2 == 0 else (B, A)
         off = r * kstride
-        e(f"7{r}:")
+        e(f"{lab(70 + r)}:")
         e(f"v_add_u32 {v(KF)}, %[par], %[ka0]")           # chunk buffer parity
         e(f"v_xor_b32 {v(KF + 4)}, 32, {v(KF)}")          # k-step 1: 16-B segment (2 + half) ^ sw = segment of k-step 0 ^ 2
         e(f"ds_read_b128 {v(KF, 4)}, {v(KF)} offset:{off}")
@@ -116,10 +140,8 @@ def gen(rows, mask, kstride=2048, abl=()):
         # overflow test: largest packed weight of the two tiles >= 2^14 ?
         t = [KF, KF + 1, KF + 2, KF + 3]
         if "nocheck" in abl:
-            e("s_nop 1")
-            e(f"s_cmp_eq_u32 %[rs], 77")
-            e(f"s_cbranch_scc1 9{r}f")
             e("s_waitcnt lgkmcnt(0)")
+            e("s_nop 1")                   # the last cvt_pk is 2 states ahead of the MFMA that reads it
         if "nocheck" not in abl:
           e(f"v_pk_maximum3_f16 {v(t[0])}, {v(Z)}, {v(Z + 1)}, {v(Z + 2)}")
           e(f"v_pk_maximum3_f16 {v(t[1])}, {v(Z + 3)}, {v(Z + 4)}, {v(Z + 5)}")
@@ -131,7 +153,7 @@ def gen(rows, mask, kstride=2048, abl=()):
           e(f"v_pk_max_f16 {v(t[0])}, {v(t[0])}, {v(t[1])}")
           e(f"v_pk_max_f16 {v(t[0])}, {v(t[0])}, {v(t[0])} op_sel:[0,1] op_sel_hi:[1,0]")
           e(f"v_cmp_le_u32 vcc, 0x{TRIP:08x}, {v(t[0])}")
-          e(f"s_cbranch_vccnz 9{r}f")
+          e(f"s_cbranch_vccnz {lab(90 + r)}f")
           e("s_waitcnt lgkmcnt(0)")
         if "prio" in abl or "priopv" in abl:
             e("s_setprio 1")
@@ -144,14 +166,6 @@ def gen(rows, mask, kstride=2048, abl=()):
             e("s_setprio 0")
         e("s_add_u32 %[sb], %[sb], %[d4]")
     e(f"s_mov_b32 %[done], {rows}")
-    e("s_branch 99f")
-    for r in range(rows):
-        e(f"9{r}:")
-        e("s_waitcnt lgkmcnt(0)")        # the V^T reads of the abandoned row still target VF
-        e(f"s_mov_b32 %[done], {r}")
-        if r + 1 < rows:
-            e("s_branch 99f")
-    e("99:")
     return L
 
 

@@ -38,6 +38,7 @@ def main():
     M = B * H * W
     plan = m._plan((H, W), torch.device("cuda"))
     pk, geo = plan["stages"][0]["blocks"][a.block], plan["sched"][0][a.block]
+    ceil = lambda k: None if os.environ.get("GRL_ATTN_NOCEIL") else pk.get(k)   # A/B: attention with / without the overflow test
     st = plan["stages"][0]
     r = torch.randn(M, CP, device="cuda")
     r[:, C:] = 0
@@ -76,13 +77,13 @@ def main():
                    L_ * C * C * B // (df * df), M * CP * 4),
         "attn_window": (lambda: ops.attention(TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh, H, W, ws[0], ws[1], sh, sh),
                                               TG(qkv, 2 * nh, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
-                                              B=B, nh=nh, table=pk["tab_w"], masked=sh > 0, ones_col=30, head_dim=30, k_one31=True, lazy_floor=pk["floor_w"]),
+                                              B=B, nh=nh, table=pk["tab_w"], masked=sh > 0, ones_col=30, head_dim=30, k_one31=True, lazy_floor=pk["floor_w"], lazy_ceil=ceil("ceil_w")),
                         fl_att, M * 4 * 96 * 2),
         "attn_a2w": (lambda: ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh, table=pk["tab_a2w"], masked=geo.stripe_shift,
-                                           ones_col=30, head_dim=30, k_one31=True, lazy_floor=pk["floor_a2w"]), fl_s, M * 2 * 96 * 2),
+                                           ones_col=30, head_dim=30, k_one31=True, lazy_floor=pk["floor_a2w"], lazy_ceil=ceil("ceil_a2w")), fl_s, M * 2 * 96 * 2),
         "attn_w2a": (lambda: ops.attention(g_q, g_a, g_y, TG(att, nh, H, W, stp[0], stp[1], ss[0], ss[1]), B=B, nh=nh,
                                            table=pk["tab_w2a"], masked=geo.stripe_shift, ones_col=30,
-                                           head_dim=30, k_one31=True, lazy_floor=pk["floor_w2a"]), fl_s, M * 2 * 96 * 2),
+                                           head_dim=30, k_one31=True, lazy_floor=pk["floor_w2a"], lazy_ceil=ceil("ceil_w2a")), fl_s, M * 2 * 96 * 2),
         "cab_conv1": (lambda: ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid), 2 * 9 * L_ * C * 45 * B, M * (CP * 4 + 96)),
         "cab_conv2": (lambda: ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out=cab), 2 * 9 * L_ * C * 45 * B, M * (128 + CP * 2)),
         "se": (lambda: ops.se_scale(pool, B, CP, C, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"]), 0, pool.numel() * 4),
