@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 13
+ABI_VERSION = 14
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -25,6 +25,8 @@ EXPORTS = [
     "grl_qkv_blob_bytes",
     "grl_qkv_anchor_fwd",
     "grl_qkv_anchor_blob_bytes",
+    "grl_cab_conv2_fwd",
+    "grl_cab_conv2_blob_bytes",
     "grl_attention_fwd",
     "grl_layernorm_fwd",
     "grl_layernorm_res_fwd",
@@ -151,6 +153,23 @@ class GrlQkvAnchorArgs(_Strict):
         ("out_plane_stride", C.c_int64),
         ("anc", C.c_void_p),
         ("anc_plane_stride", C.c_int64),
+    ]
+
+
+class GrlCabConv2Args(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("ldx", C.c_int64),
+        ("blob", C.c_void_p),
+        ("bias", C.c_void_p),
+        ("B", C.c_int32),
+        ("H", C.c_int32),
+        ("W", C.c_int32),
+        ("wgs_per_image", C.c_int32),
+        ("out", C.c_void_p),
+        ("ldo", C.c_int64),
+        ("pool_partial", C.c_void_p),
+        ("pool_stride", C.c_int64),
     ]
 
 
@@ -358,6 +377,10 @@ def lib():
     L.grl_qkv_anchor_fwd.restype = C.c_int
     L.grl_qkv_anchor_blob_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.grl_qkv_anchor_blob_bytes.restype = C.c_int64
+    L.grl_cab_conv2_fwd.argtypes = [C.c_void_p, C.POINTER(GrlCabConv2Args)]
+    L.grl_cab_conv2_fwd.restype = C.c_int
+    L.grl_cab_conv2_blob_bytes.argtypes = []
+    L.grl_cab_conv2_blob_bytes.restype = C.c_int64
     L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
     L.grl_attention_fwd.restype = C.c_int
     L.grl_layernorm_fwd.argtypes = [

@@ -473,6 +473,8 @@ class GRL(nn.Module):
                 se3_w=se[3].weight.detach().float().reshape(C, -1).to(dev).clone(),
                 se3_b=se[3].bias.detach().float().to(dev).clone(),
             )
+            if not hi and CP == 192 and Cm <= 48 and CmI >= 56 and os.environ.get("GRL_CAB_CONV2", "1") != "0":
+                pk["cab2_blob"], pk["cab2_bias"] = ops.pack_cab_conv2(c2.weight.to(dev), c2.bias.to(dev))   # csrc/cab_conv2.hip
         return pk
 
     def _plan(self, x_size, dev):
@@ -548,7 +550,10 @@ class GRL(nn.Module):
         sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
         mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=sp)
-        raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=dt, x_split=sp)
+        if "cab2_blob" in pk:
+            raw, pool = ops.cab_conv2(mid, pk["cab2_blob"], pk["cab2_bias"], B, H, W)
+        else:
+            raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=dt, x_split=sp)
         gate = ops.se_scale(pool, B, CP, self.embed_dim, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"])
         return raw, gate
 

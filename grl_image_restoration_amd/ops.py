@@ -521,6 +521,36 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     return (out, pool) if want_pool else out
 
 
+def pack_cab_conv2(w: torch.Tensor, bias: torch.Tensor):
+    """(blob, bias[192]) of grl_cab_conv2_fwd from a Conv2d weight [Cout <= 192, Cin <= 48, 3, 3]: K = tap * 48 + cin padded to
+    14 k-steps of 32, stored in MFMA fragment order (layout in include/grl_hip.h)."""
+    Cout, Cin = w.shape[:2]
+    assert Cout <= 192 and Cin <= 48 and tuple(w.shape[2:]) == (3, 3)
+    wk = torch.zeros(192, 14 * 32, dtype=torch.float32, device=w.device)
+    wk[:Cout, : 9 * 48].view(Cout, 9, 48)[:, :, :Cin] = w.detach().float().permute(0, 2, 3, 1).reshape(Cout, 9, Cin)
+    blob = wk.to(GEMM_DTYPE).view(12, 16, 14, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(torch.uint8).reshape(-1)
+    assert blob.numel() == L.lib().grl_cab_conv2_blob_bytes()
+    b = torch.zeros(192, dtype=torch.float32, device=w.device)
+    b[:Cout] = bias.detach().float()
+    return blob, b
+
+
+def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int):
+    """(out [B*H*W, 192] fp16, pool partial sums [B * wgs_per_image, 192]) = conv3x3(x) + bias of the CAB's second convolution
+    (grl_cab_conv2_fwd: filter bank in registers); x [B*H*W, >= 56] fp16 with zero pad channels."""
+    _dev_check(x, blob, bias)
+    assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == GEMM_DTYPE and x.shape[0] == B * H * W and x.shape[1] >= 56
+    out = torch.empty(B * H * W, 192, dtype=GEMM_DTYPE, device=x.device)
+    tiles = ((H + 7) // 8) * ((W + 31) // 32)
+    wgs = max(1, min(tiles, 256 // B))
+    pool = torch.empty(B * wgs, 192, dtype=torch.float32, device=x.device)
+    args = L.GrlCabConv2Args(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), bias=_ptr(bias), B=B, H=H, W=W, wgs_per_image=wgs,
+                             out=_ptr(out), ldo=192, pool_partial=_ptr(pool), pool_stride=192)
+    with _timed("conv3x3"):
+        L.check(L.lib().grl_cab_conv2_fwd(L.stream_ptr(), C.byref(args)), "grl_cab_conv2_fwd")
+    return out, pool
+
+
 def se_scale(pool: torch.Tensor, B: int, CP: int, C_: int, HW: int, w1, b1, w2, b2) -> torch.Tensor:
     """scale[B, CP] = sigmoid(W2 relu(W1 mean + b1) + b2) from the conv kernel's partial channel sums."""
     _dev_check(pool, w1, b1, w2, b2)

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 13
+#define GRL_ABI_VERSION 14
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -304,6 +304,30 @@ typedef struct GrlConvArgs {
 
 int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args);
 int grl_conv3x3_num_workgroups(int32_t B, int32_t H, int32_t W);
+
+/* CAB.cab[2] of the GRL-Base shape with the filter bank resident in registers (csrc/cab_conv2.hip): the same result as
+ * grl_conv3x3_fwd on a 16-bit input with <= 48 (padded) input and 192 (padded) output channels, bias, no activation,
+ * 16-bit output + the partial channel sums of the SE pool.   models/common/mixed_attn_block.py:948-983
+ *   blob: grl_cab_conv2_blob_bytes() bytes, fp16 [12 channel groups][14 k-steps][64 lanes][8]: lane (g4 = lane / 16,
+ *         r = lane % 16) of (group G, k-step s) holds W[16 G + r][k = 32 s + 8 g4 .. + 7], k = (ky * 3 + kx) * 48 + cin,
+ *         zero for cin >= Cin, k >= 432 and output channels >= Cout.
+ *   pool_partial: optional [B * wgs_per_image, pool_stride] -- one row of channel sums per workgroup (grl_se_scale_fwd's input
+ *         with this wgs_per_image).  wgs_per_image persistent workgroups share the 8 x 32 pixel tiles of an image. */
+typedef struct GrlCabConv2Args {
+    const void* x;          /* GRL_DT_F16 [B*H*W, ldx], ldx >= 56, channels >= Cin are zero                  */
+    int64_t ldx;
+    const void* blob;
+    const float* bias;      /* [192], zero beyond Cout                                                       */
+    int32_t B, H, W;
+    int32_t wgs_per_image;
+    void* out;              /* GRL_DT_F16 [B*H*W, ldo], ldo >= 192: all 192 channels are written            */
+    int64_t ldo;
+    float* pool_partial;
+    int64_t pool_stride;    /* >= 192 */
+} GrlCabConv2Args;
+
+int grl_cab_conv2_fwd(void* stream, const GrlCabConv2Args* args);
+int64_t grl_cab_conv2_blob_bytes(void);
 
 /* Squeeze-excite gate from the pooled sums: scale[b,c] = sigmoid(W2 relu(W1 mean_b + b1) + b2)
  *   replaces  ChannelAttention.attention   models/common/mixed_attn_block.py:956-967            */

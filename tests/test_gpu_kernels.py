@@ -697,3 +697,33 @@ def test_attention_split_precision_operands(case):
     print(f"{name}: split operands {e_split:.2e}, fp16 operands {e_plain:.2e} (ref max {ref.abs().max().item():.2f})")
     assert e_split < 5e-4 * max(1.0, ref.abs().max().item()) and e_split < 0.5 * e_plain
     assert (o16.float() + o16lo.float() - out).abs().max().item() < 2e-6 * max(1.0, ref.abs().max().item())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape", [(2, 16, 64), (1, 20, 50), (3, 8, 32), (1, 64, 96), (5, 9, 33)])
+def test_cab_conv2_register_resident_filters(shape):
+    """grl_cab_conv2_fwd (csrc/cab_conv2.hip) against torch's fp32 conv2d on the same fp16-rounded operands: output, zero pad
+    channels and the partial channel sums of the SE pool; ragged tiles (H % 8, W % 32 != 0) and several images per launch."""
+    from grl_image_restoration_amd import ops
+    B, H, W = shape
+    dev = _dev()
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + W)
+    Cin, Cout = 45, 180
+    w = torch.randn(Cout, Cin, 3, 3, generator=g) * 0.05
+    bias = torch.randn(Cout, generator=g) * 0.1
+    x = torch.randn(B, Cin, H, W, generator=g)
+    xm = torch.zeros(B * H * W, 64, dtype=torch.float16)
+    xm[:, :Cin] = x.permute(0, 2, 3, 1).reshape(-1, Cin).half()
+    blob, b192 = ops.pack_cab_conv2(w.to(dev), bias.to(dev))
+    out, pool = ops.cab_conv2(xm.to(dev), blob, b192, B, H, W)
+    torch.cuda.synchronize()
+    ref = F.conv2d(xm[:, :Cin].float().view(B, H, W, Cin).permute(0, 3, 1, 2), w.half().float(), bias, padding=1)
+    ref = ref.permute(0, 2, 3, 1).reshape(-1, Cout)
+    got = out.float().cpu()
+    assert (got[:, Cout:] == 0).all()
+    err = (got[:, :Cout] - ref).abs().max().item()
+    print(f"cab_conv2 {shape}: max|err| = {err:.3e} (ref max {ref.abs().max().item():.2f})")
+    assert err < 2e-3 * max(1.0, ref.abs().max().item()), err
+    sums = pool.view(B, -1, 192).sum(1).cpu()
+    ref_s = ref.view(B, H * W, Cout).sum(1)
+    assert (sums[:, :Cout] - ref_s).abs().max().item() < 1e-3 * max(1.0, ref_s.abs().max().item())

@@ -47,7 +47,7 @@ __global__ __launch_bounds__(WAVES * 64, MINW) void proto(float* out, long long*
         if (barrier) __builtin_amdgcn_s_barrier();
         asm volatile(ATTN_ROWS4_MASK0 : [o0] "+v"(O0), [o1] "+v"(O1), [sb] "+s"(sb), [done] "=s"(done)
                      : [ka0] "v"(ka0b), [va] "v"(vab), [bl] "v"(bl), [q00] "v"(q00), [q01] "v"(q01), [q10] "v"(q10), [q11] "v"(q11),
-                       [d4] "s"(4 * D), [rs] "s"(0), [par] "s"(0) : ATTN_ROWS_CLOBBER);
+                       [d4] "s"(4 * D), [rs] "s"(0), [par] "s"(0), [nochk] "s"(nochk) : ATTN_ROWS_CLOBBER);
         tripped += done != 4;
     }
     long long t1 = __builtin_amdgcn_s_memtime();

@@ -86,6 +86,7 @@ def main():
                                            head_dim=30, k_one31=True, lazy_floor=pk["floor_w2a"], lazy_ceil=ceil("ceil_w2a")), fl_s, M * 2 * 96 * 2),
         "cab_conv1": (lambda: ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid), 2 * 9 * L_ * C * 45 * B, M * (CP * 4 + 96)),
         "cab_conv2": (lambda: ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out=cab), 2 * 9 * L_ * C * 45 * B, M * (128 + CP * 2)),
+        "cab_conv2_regs": (lambda: ops.cab_conv2(mid, pk["cab2_blob"], pk["cab2_bias"], B, H, W), 2 * 9 * L_ * C * 45 * B, M * (128 + CP * 2)),
         "se": (lambda: ops.se_scale(pool, B, CP, C, H * W, pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"]), 0, pool.numel() * 4),
         "proj_ln": (lambda: ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
                                        ln_b=pk["n1_b"], n_real=C, resid=r, add2=cab, add2_scale=gate, rows_per_image=H * W),
