@@ -62,7 +62,40 @@ __device__ __forceinline__ uint32_t pack16(float lo, float hi, int kind) {
 }
 
 // exchange with the lane 32 apart (both halves of a wave64)
-__device__ __forceinline__ float xhalf(float v) { return __shfl_xor(v, 32, 64); }
+// (gfx950 v_permlane32_swap / v_permlane16_swap: one VALU instruction instead of a ds_bpermute round trip through the LDS)
+// swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b
+__device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+    a = r[0];
+    b = r[1];
+}
+// (Precaution: the second operand of a swap of a value with itself goes through an empty asm, so that the compiler cannot
+// reason about the two results being "the same" -- see sum_rows16 for what the 16-lane builtin did.)
+__device__ __forceinline__ uint32_t opaque_copy(uint32_t a) {
+    uint32_t b = a;
+    asm volatile("" : "+v"(b));
+    return b;
+}
+__device__ __forceinline__ float xhalf(float v) {
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+    swap32(a, b);   // a = {lo, lo}, b = {hi, hi}
+    const bool lower = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32u) == 0;
+    return __builtin_bit_cast(float, lower ? b : a);
+}
+// v + (v of lane ^ 32), v + (v of lane ^ 16)
+__device__ __forceinline__ float sum_halves(float v) {
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+    swap32(a, b);
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
+}
+__device__ __forceinline__ float sum_rows16(float v) {
+    // v_permlane16_swap_b32 a, b: odd 16-lane rows of a <-> even rows of b.  Written as asm: with the ROCm 7.2 builtin the sum of
+    // the two results was compiled as 2 * (first result) (tools/ubench/permlane.hip).  s_nop: the wait states the compiler puts
+    // around the builtin form.
+    float a = v, b = v;
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // {r0, r0, r2, r2}, {r1, r1, r3, r3}
+    return a + b;
+}
 
 // exact-GELU x*Phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32
 // round-off level; the reference uses torch's erf-GELU, swin_v1_block.py:23,38).  ~14 VALU ops with two
