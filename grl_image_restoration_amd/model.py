@@ -392,6 +392,12 @@ class GRL(nn.Module):
         pk = dict(qkv_b=bp, qkv_gs=gs, one_w=one_w, one_s=one_s, floor_w=tables.lazy_floor(sc_w),
                   floor_a2w=tables.lazy_floor(sc_1), floor_w2a=tables.lazy_floor(sc_2))
         pk["qkv_w"] = ops.split3_weight(Wp) if hi else Wp.to(G16)
+        # fast mode, logit scales beyond GRL_HIQ_SCALE (trained checkpoints sit at the clamp, 100): the q / k / anchor planes come from
+        # the split-operand projection -- at scale 100 the fp16 rounding of x and W in this one GEMM is the largest single
+        # contribution to the output error (tools/precision_sites.py: rms 8.9e-5 of 1.6e-4), amplified by the scale itself
+        hiq = (not hi) and float(max(sc_w.max(), sc_1.max(), sc_2.max())) > float(os.environ.get("GRL_HIQ_SCALE", "50"))
+        if hiq:
+            pk.update(hiq=True, qkv_w3=ops.split3_weight(Wp))
         if not hi and CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
             pk.update(qkv_blob=ops.pack_qkv(Wp, bp, gs), qkv_slots=G)
 
@@ -405,6 +411,8 @@ class GRL(nn.Module):
             bap[h * 32 : h * 32 + d_s] = ba[h * d_s : (h + 1) * d_s]
         pk.update(anc_w=ops.split3_weight(Wap) if hi else Wap.to(G16), anc_b=bap,
                   anc_gs=torch.full((nh_s,), -1.0 if one_s else 1.0, **f32))
+        if hiq:
+            pk["anc_w3"] = ops.split3_weight(Wap)
         if not hi and CP in (64, 128, 192):   # q/k/v + 2x2-pooled anchors in one pass over x (csrc/qkv_anchor.hip)
             pk.update(qa_blob=ops.pack_qkv_anchor(Wp, bp, gs, Wap, bap, pk["anc_gs"]), qa_slots=(G, nh_s))
 
@@ -508,7 +516,11 @@ class GRL(nn.Module):
                 sched=sched, stages=stages, split=sp,
                 ns_g=padv(self.norm_start.weight), ns_b=padv(self.norm_start.bias),
                 ne_g=padv(self.norm_end.weight), ne_b=padv(self.norm_end.bias),
-                first=pconv(self.conv_first, _pad32(self.in_channels), CP), after=pconv(self.conv_after_body, CP, CP),
+                # conv_first always runs on split operands: K = 27, the cost is nil, and its operand rounding alone is 4e-4 of the
+                # 1e-3 budget of a clamp-scale checkpoint (tools/precision_sites.py base_sr4_ckpt_256_hiscale)
+                first=(ops.pack_conv_weight(self.conv_first.weight.to(dev), _pad32(self.in_channels), CP, split=3),
+                       ops.pack_conv_bias(self.conv_first.bias.to(dev), CP)),
+                after=pconv(self.conv_after_body, CP, CP),
             )
             out_p = (self.out_channels + 15) // 16 * 16
             if self.upsampler == "pixelshuffle":
@@ -605,7 +617,10 @@ class GRL(nn.Module):
             return self._block_high(r, pk, geo, B, H, W)
         # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
-        if "qa_blob" in pk and df == 2 and H % 2 == 0 and W % 64 == 0 and os.environ.get("GRL_QKV_ANCHOR", "1") != "0":
+        if pk.get("hiq"):
+            qkv = ops.linear(r, pk["qkv_w3"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3)
+            anc = ops.linear(r, pk["anc_w3"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True, a_split=3)
+        elif "qa_blob" in pk and df == 2 and H % 2 == 0 and W % 64 == 0 and os.environ.get("GRL_QKV_ANCHOR", "1") != "0":
             qkv, anc = ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W)
         else:
             if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":
@@ -937,7 +952,7 @@ class GRL(nn.Module):
         # fast: 16-bit intermediates of the tail feed fp16-operand convolutions; high: fp32 + split operands
         bf = torch.float32 if sp == 3 else ops.GEMM_DTYPE
 
-        f = conv(self._tokens(x, plan["first"][0].shape[2] // sp), *plan["first"], B, H, W)           # conv_first
+        f = ops.conv3x3(self._tokens(x, plan["first"][0].shape[2] // 3), *plan["first"], B, H, W, x_split=3)   # conv_first
         body = conv(self.forward_features(f, plan, B, H, W), *plan["after"], B, H, W, resid=f)  # conv_after_body + f
         if self.upsampler == "pixelshuffle":
             y = conv(body, *plan["cbu"], B, H, W, act=2, slope=0.01, out_dtype=bf)
