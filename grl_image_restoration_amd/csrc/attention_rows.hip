@@ -201,10 +201,11 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
     }
     const int d4 = __builtin_amdgcn_readfirstlane(4 * D);
     // offsets at or above msafe: logit - offset <= 13.5 for every key of the head (GrlAttnArgs.lazy_ceil)
-    const float msafe = p.lazy_ceil != nullptr ? __builtin_ceilf(p.lazy_ceil[head] - 13.5f) : 3.0e38f;
+    const int msafe_i = __builtin_amdgcn_readfirstlane(p.lazy_ceil != nullptr ? (int)__builtin_ceilf(p.lazy_ceil[head] - 13.5f) : 0x40000000);
 
     // BORDER is a compile-time tag: each instance of the chunk loop holds ONE asm statement (with both variants in one loop
     // the register allocator shuffled and spilled the O / Q operands around every statement)
+    int poison = 0;  // wave-uniform: a row kept tripping (non-finite logits): the outputs of this wave's queries become NaN
     auto chunks = [&](auto border_tag) {
     constexpr bool BORDER = decltype(border_tag)::value;
     int sk = 0, hk0 = 0;
@@ -275,8 +276,7 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
             if (done == last_trip) {
                 // the row tripped again right after its offsets were raised: only non-finite logits do that.  Poison the
                 // outputs (the reference yields NaN as well) and move on.
-#pragma unroll
-                for (int r = 0; r < 16; ++r) { O0[r] = __builtin_nanf(""); O1[r] = __builtin_nanf(""); }
+                poison = 1;
                 rs = done + 1;
                 sb += 4 * D;
                 if (rs == RROWS) break;
@@ -290,7 +290,13 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
                 const int kk = 32 * done + l31;
                 const f16x8 kf0 = *(const f16x8*)(Kc + kk * 64 + (((0 + half) ^ sw) << 4));
                 const f16x8 kf1 = *(const f16x8*)(Kc + kk * 64 + (((2 + half) ^ sw) << 4));
-                const float* t0p = (const float*)(smem + (bl + sb - lds0));   // tile 0's fragment of this row; tile 1's is one table row below
+                // (Nothing the repair path needs may be kept in a spill slot across the statement: a scratch reload here is "pending" at
+                // the head of the loop on every path, and the compiler then puts s_waitcnt vmcnt(0) in front of the statement -- which
+                // also waits for the DMA of the next chunk, issued a few instructions earlier.  Hence the opaque copy of bl, which keeps
+                // bl - lds0 from being hoisted out of the chunk loop, and msafe as an integer in an SGPR.)
+                uint32_t blx = bl;
+                asm volatile("" : "+v"(blx));
+                const float* t0p = (const float*)(smem + (blx + sb - lds0));   // tile 0's fragment of this row; tile 1's is one table row below
                 f32x16 S0, S1;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { S0[r] = t0p[(r & 3) + 8 * (r >> 2)]; S1[r] = t0p[(r & 3) + 8 * (r >> 2) - D]; }
@@ -314,6 +320,7 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
                 {
                     // offsets within ROWS_EXTRA of the level where the overflow test becomes unnecessary go there right away
                     // (the row maximum then rests at 2^(ROWS_REST - ROWS_EXTRA) at worst: ample for fp16 weights)
+                    const float msafe = (float)msafe_i;
                     const float t0 = (float)q01[7], t1 = (float)q11[7], u0 = xhalf(t0), u1 = xhalf(t1);
                     float m0 = d0 - (half ? t0 : u0), m1 = d1 - (half ? t1 : u1);   // the new offsets
                     if (m0 < msafe && m0 >= msafe - ROWS_EXTRA) { d0 += msafe - m0; m0 = msafe; }
@@ -349,10 +356,12 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         const float mq0 = -xhalf((float)q01[7]), mq1 = -xhalf((float)q11[7]);   // lower half-wave <- the upper one's slot 31
         locate(p.q, b, wy, wx, hq0 * p.q.ww + wq, row, rid);
         float l = ones_row(O0, p.ones_col, half);
+        if (poison) l = __builtin_nanf("");
         store_o(p, O0, 1.0f / l, row, head, half);
         if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + row] = mq0 + __builtin_amdgcn_logf(l);
         locate(p.q, b, wy, wx, (hq0 + 1) * p.q.ww + wq, row, rid);
         l = ones_row(O1, p.ones_col, half);
+        if (poison) l = __builtin_nanf("");
         store_o(p, O1, 1.0f / l, row, head, half);
         if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + row] = mq1 + __builtin_amdgcn_logf(l);
     }

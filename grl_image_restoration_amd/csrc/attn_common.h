@@ -58,13 +58,11 @@ __device__ __forceinline__ void store_f16_slot(f16* slot, const float (&v)[16], 
         pk[g].x = pack_f16(v[4 * g + 0], v[4 * g + 1]);
         pk[g].y = pack_f16(v[4 * g + 2], v[4 * g + 3]);
     }
-    const uint2 sa = half ? pk[0] : pk[1], sb = half ? pk[2] : pk[3];
-    uint2 ra, rb;
-    ra.x = __shfl_xor(sa.x, 32, 64); ra.y = __shfl_xor(sa.y, 32, 64);
-    rb.x = __shfl_xor(sb.x, 32, 64); rb.y = __shfl_xor(sb.y, 32, 64);
     // half 0: dims 0-7 = own g0 | partner g0, dims 16-23 = own g2 | partner g2;  half 1: dims 8-15 = partner g1 | own g1, 24-31 likewise
-    const uint4 lo = half ? uint4{ra.x, ra.y, pk[1].x, pk[1].y} : uint4{pk[0].x, pk[0].y, ra.x, ra.y};
-    const uint4 hi = half ? uint4{rb.x, rb.y, pk[3].x, pk[3].y} : uint4{pk[2].x, pk[2].y, rb.x, rb.y};
+    swap32(pk[0].x, pk[1].x); swap32(pk[0].y, pk[1].y);   // (upper half of the first <-> lower half of the second operand)
+    swap32(pk[2].x, pk[3].x); swap32(pk[2].y, pk[3].y);
+    const uint4 lo = uint4{pk[0].x, pk[0].y, pk[1].x, pk[1].y};
+    const uint4 hi = uint4{pk[2].x, pk[2].y, pk[3].x, pk[3].y};
     *(uint4*)(slot + 8 * half) = lo;
     *(uint4*)(slot + 8 * half + 16) = hi;
 }

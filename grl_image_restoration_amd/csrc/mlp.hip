@@ -226,8 +226,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
                 pacc[nt][0] += b4.x; pacc[nt][1] += b4.y; pacc[nt][2] += b4.z; pacc[nt][3] += b4.w;
                 s1 += (pacc[nt][0] + pacc[nt][1]) + (pacc[nt][2] + pacc[nt][3]);   // pad channels are exactly 0
             }
-            s1 += __shfl_xor(s1, 16, 64);
-            s1 += __shfl_xor(s1, 32, 64);
+            s1 = sum_halves(sum_rows16(s1));
             const float mean = s1 / (float)p.n_real;
             float s2 = 0.f;
 #pragma unroll
@@ -239,8 +238,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
                     // their n_pad * mean^2 afterwards would cancel catastrophically for rows with |mean| >> std
                     if (nt < NT2 - 2 || 16 * nt + 4 * g4 + e < p.n_real) s2 = fmaf(d, d, s2);
                 }
-            s2 += __shfl_xor(s2, 16, 64);
-            s2 += __shfl_xor(s2, 32, 64);
+            s2 = sum_halves(sum_rows16(s2));
             const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
             const char* rowp = xt + (wave * 16 + r16) * XROW + 16 * g4;
             const float* grow = vec + 6 * CP + ((int)(mc0 / p.rows_per_image) - img0) * CP;
@@ -374,8 +372,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
             acc[nt][0] += b4.x; acc[nt][1] += b4.y; acc[nt][2] += b4.z; acc[nt][3] += b4.w;
             s1 += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);   // pad channels are exactly 0
         }
-        s1 += __shfl_xor(s1, 16, 64);
-        s1 += __shfl_xor(s1, 32, 64);
+        s1 = sum_halves(sum_rows16(s1));
         const float mean = s1 / (float)p.n_real;
         float s2 = 0.f;
 #pragma unroll
@@ -385,8 +382,7 @@ __global__ __launch_bounds__(WV * 64) void mlp_kernel(TailP p) {
                 const float d = acc[nt][e] - mean;
                 if (nt < NT2 - 2 || 16 * nt + 4 * g4 + e < p.n_real) s2 = fmaf(d, d, s2);   // (see norm1 above)
             }
-        s2 += __shfl_xor(s2, 16, 64);
-        s2 += __shfl_xor(s2, 32, 64);
+        s2 = sum_halves(sum_rows16(s2));
         const float rstd = rsqrtf(s2 / (float)p.n_real + p.ln_eps);
         const int64_t mc = valid ? m : (int64_t)p.M - 1;
         float* orow = p.out + mc * p.ldo;
