@@ -61,40 +61,35 @@ __device__ __forceinline__ uint32_t pack16(float lo, float hi, int kind) {
     return kind == GRL_DT_BF16 ? pack_bf16(lo, hi) : pack_f16(lo, hi);
 }
 
-// exchange with the lane 32 apart (both halves of a wave64)
-// (gfx950 v_permlane32_swap / v_permlane16_swap: one VALU instruction instead of a ds_bpermute round trip through the LDS)
-// swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b
+// ---- lane exchanges across the 16- and 32-lane boundaries (gfx950 v_permlane16_swap / v_permlane32_swap: one VALU instruction
+// instead of a ds_bpermute round trip through the LDS pipe, which is what __shfl_xor compiles to).  Written as inline asm:
+// with this toolchain's builtins the two results of a swap can come back as the same value (permlane32: tools/probes/
+// permlane32_swap_codegen.hip, round 2; permlane16: r[0] + r[1] compiled as 2 * r[0], tools/ubench/permlane.hip).  The s_nops
+// are the wait states the compiler places around the builtin form (VALU write -> swap, swap -> VALU / DPP read).
+// swap32(a, b): lanes 32..63 of a <-> lanes 0..31 of b;  swap16(a, b): 16-lane rows 1, 3 of a <-> rows 0, 2 of b
 __device__ __forceinline__ void swap32(uint32_t& a, uint32_t& b) {
-    const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
-    a = r[0];
-    b = r[1];
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
-// (Precaution: the second operand of a swap of a value with itself goes through an empty asm, so that the compiler cannot
-// reason about the two results being "the same" -- see sum_rows16 for what the 16-lane builtin did.)
-__device__ __forceinline__ uint32_t opaque_copy(uint32_t a) {
-    uint32_t b = a;
-    asm volatile("" : "+v"(b));
-    return b;
+__device__ __forceinline__ void swap16(uint32_t& a, uint32_t& b) {
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));
 }
+// value of the lane 32 apart
 __device__ __forceinline__ float xhalf(float v) {
-    uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
     swap32(a, b);   // a = {lo, lo}, b = {hi, hi}
     const bool lower = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 32u) == 0;
     return __builtin_bit_cast(float, lower ? b : a);
 }
 // v + (v of lane ^ 32), v + (v of lane ^ 16)
 __device__ __forceinline__ float sum_halves(float v) {
-    uint32_t a = __builtin_bit_cast(uint32_t, v), b = opaque_copy(a);
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
     swap32(a, b);
     return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 __device__ __forceinline__ float sum_rows16(float v) {
-    // v_permlane16_swap_b32 a, b: odd 16-lane rows of a <-> even rows of b.  Written as asm: with the ROCm 7.2 builtin the sum of
-    // the two results was compiled as 2 * (first result) (tools/ubench/permlane.hip).  s_nop: the wait states the compiler puts
-    // around the builtin form.
-    float a = v, b = v;
-    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\ts_nop 1" : "+v"(a), "+v"(b));   // {r0, r0, r2, r2}, {r1, r1, r3, r3}
-    return a + b;
+    uint32_t a = __builtin_bit_cast(uint32_t, v), b = a;
+    swap16(a, b);   // {r0, r0, r2, r2}, {r1, r1, r3, r3}
+    return __builtin_bit_cast(float, a) + __builtin_bit_cast(float, b);
 }
 
 // exact-GELU x*Phi(x) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7 absolute, i.e. fp32

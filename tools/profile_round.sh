@@ -16,7 +16,7 @@ DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-trained-scales" > $OUT/kernel_stats.txt
 tail -1 $OUT/prof_bench_stdout.txt >> $OUT/kernel_stats.txt
 python $ROOT/tools/rocprof_summary.py "$DB" 30 >> $OUT/kernel_stats.txt 2>&1
-KERN=attn_window,attn_a2w,attn_w2a,qkv_stream,block_tail,cab_conv1,cab_conv2,stage_conv,anchor
+KERN=attn_window,attn_a2w,attn_w2a,qkv_anchor,block_tail,cab_conv1,cab_conv2_regs,se,stage_conv
 : > $OUT/pmc_hbm.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/prof_$c
