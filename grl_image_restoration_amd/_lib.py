@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 14
+ABI_VERSION = 15
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -170,6 +170,15 @@ class GrlCabConv2Args(_Strict):
         ("ldo", C.c_int64),
         ("pool_partial", C.c_void_p),
         ("pool_stride", C.c_int64),
+        ("gate", C.c_void_p),
+        ("se_counter", C.c_void_p),
+        ("se_w1", C.c_void_p),
+        ("se_b1", C.c_void_p),
+        ("se_w2", C.c_void_p),
+        ("se_b2", C.c_void_p),
+        ("se_c", C.c_int32),
+        ("se_mid", C.c_int32),
+        ("inv_hw", C.c_float),
     ]
 
 

@@ -183,6 +183,47 @@ __global__ __launch_bounds__(C2_THREADS) void cab_conv2_kernel(GrlCabConv2Args p
             for (int g = 0; g < C2_NG; ++g) *(f32x4*)(red + ph * 192 + 48 * cs + 16 * g + 4 * g4) = pool[g];
         __syncthreads();
         if (tid < 192) p.pool_partial[(int64_t)blockIdx.x * p.pool_stride + tid] = red[tid] + red[192 + tid];
+
+        // ---- squeeze-excite gate by the LAST workgroup of the image (ChannelAttention, mixed_attn_block.py:956-963):
+        //   gate[c] = sigmoid(W2 . relu(W1 . mean + b1) + b2).  As a launch of its own (grl_se_scale_fwd) the 10-us kernel sat in
+        //   its stream for ~90 us behind the other tile group's CU-filling kernels, 640 times per step.
+        if (p.gate != nullptr) {
+            __shared__ int s_last;
+            __threadfence();                      // this workgroup's row is visible device-wide before it is counted
+            __syncthreads();
+            if (tid == 0) s_last = atomicAdd(p.se_counter + img, 1) == p.wgs_per_image - 1;
+            __syncthreads();
+            if (s_last) {
+                __threadfence();                  // acquire: the other workgroups' rows
+                float* mean = red + 384;          // [192]
+                float* hid = red + 576;           // [64]
+                if (tid < 192) {
+                    const float* pp = p.pool_partial + (int64_t)img * p.wgs_per_image * p.pool_stride + tid;
+                    float sum = 0.f;
+                    for (int i = 0; i < p.wgs_per_image; ++i) sum += __builtin_nontemporal_load(pp + (int64_t)i * p.pool_stride);   // fixed order
+                    mean[tid] = sum * p.inv_hw;
+                }
+                __syncthreads();
+                for (int jj = wave_u; jj < p.se_mid; jj += C2_WAVES) {      // one wave per hidden unit
+                    float sum = 0.f;
+                    for (int k = lane; k < p.se_c; k += 64) sum += p.se_w1[jj * p.se_c + k] * mean[k];
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) sum += __shfl_xor(sum, o, 64);
+                    if (lane == 0) hid[jj] = fmaxf(sum + p.se_b1[jj], 0.f);
+                }
+                __syncthreads();
+                if (tid < 192) {
+                    float o = 0.f;
+                    if (tid < p.se_c) {
+                        float sum = p.se_b2[tid];
+                        for (int jj = 0; jj < p.se_mid; ++jj) sum += p.se_w2[tid * p.se_mid + jj] * hid[jj];
+                        o = 1.0f / (1.0f + __expf(-sum));
+                    }
+                    p.gate[(int64_t)img * 192 + tid] = o;
+                }
+                if (tid == 0) p.se_counter[img] = 0;   // ready for the next launch on this stream
+            }
+        }
     }
 }
 
@@ -196,6 +237,9 @@ extern "C" int grl_cab_conv2_fwd(void* stream, const GrlCabConv2Args* args) {
     if (p.ldx < 56 || (p.ldx % 8) || p.ldo < 192 || (p.ldo % 4)) return GRL_ERR_BAD_ARG;   // 7 segments of every pixel row are read
     if ((int64_t)p.H * p.W * p.ldx * 2 >= 0xfffffff0ll) return GRL_ERR_UNSUPPORTED;          // 32-bit buffer offsets per image
     if (p.pool_partial != nullptr && p.pool_stride < 192) return GRL_ERR_BAD_ARG;
+    if (p.gate != nullptr && (p.pool_partial == nullptr || p.se_counter == nullptr || p.se_w1 == nullptr || p.se_b1 == nullptr ||
+                              p.se_w2 == nullptr || p.se_b2 == nullptr || p.se_c <= 0 || p.se_c > 192 || p.se_mid <= 0 || p.se_mid > 64))
+        return GRL_ERR_BAD_ARG;
     hipError_t e = hipFuncSetAttribute((const void*)cab_conv2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * C2_HALO_B + 1024);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(cab_conv2_kernel, dim3(p.B * p.wgs_per_image), dim3(C2_THREADS), 2 * C2_HALO_B + 1024, (hipStream_t)stream, p);

@@ -205,16 +205,25 @@ class GRL(nn.Module):
         self.input_resolution = to_2tuple(img_size)
         self.pad_size = pad_multiple(self.window_size[0], self.stripe_size, self.stripe_groups, self.df)
         # Operand precision of the linear / conv contractions (attention always runs on fp16 operands):
-        #   fast : fp16 operands (2^-11 relative rounding), fused block-tail / streaming kernels
-        #   high : split operands a = hi + lo, w = hi + lo (3 MFMA terms, ~22 mantissa bits), fp32 intermediates
-        #   auto : high for the narrow models (embed_dim < 160: GRL-Tiny / GRL-Small), whose few channels average the
-        #          rounding noise least, and for the same-resolution tasks (no upsampler: denoising / deblurring), whose
-        #          output is x + conv_last(body) with no smoothing tail -- with fp16 operands both sit AT the 1e-3 parity bar
-        #          (tools/precision_sites.py: 0.9e-3 .. 1.1e-3 max-abs from operand rounding alone); fast for GRL-Base SR (2e-4).
+        #   fast : fp16 operands (2^-11 relative rounding), fused block-tail / register-resident / streaming kernels; per-site
+        #          exceptions on split operands: conv_first always, the convolutions named in `split_sites`, and the q / k /
+        #          anchor projection of blocks whose logit scale exceeds `hiq_scale`
+        #   high : split operands a = hi + lo, w = hi + lo (3 MFMA terms, ~22 mantissa bits) everywhere, fp32 intermediates
+        #   auto : measured on the fixtures (max |err| against the reference, bar 1e-3; tests/test_gpu_model.py):
+        #          GRL-Base SR                 fast                                    2.1e-4 (clamp-scale checkpoints 6.5e-4)
+        #          GRL-Base deblur (no upsampler: y = x + conv_last(body), no smoothing tail)
+        #                                      fast 1.16e-3 -> + stage/after/last convs split 1.0e-3 -> + q/k projection split 7.8e-4
+        #          GRL-Small denoise           fast 1.14e-3 -> + stage/after/last convs split 7.2e-4
+        #          GRL-Tiny                    high (fast + splits 6e-4 .. 8e-4, but 8e-3 at clamp scales)
         precision = os.environ.get("GRL_PRECISION", precision)
         if precision not in ("auto", "fast", "high"):
             raise ValueError(f"precision={precision!r}: expected 'auto', 'fast' or 'high'")
-        self.precision = precision if precision != "auto" else ("high" if (embed_dim < 160 or not upsampler) else "fast")
+        narrow = embed_dim < 160 or not upsampler
+        self.precision = precision if precision != "auto" else ("high" if embed_dim < 100 else "fast")
+        # fast mode: comma list of conv sites kept on split operands (see _plan); logit scale above which a block's q / k / anchor
+        # planes come from the split-operand projection (0: always)
+        self.split_sites = "stage_conv,after,last" if narrow else ""
+        self.hiq_scale = 0.0 if (embed_dim >= 160 and not upsampler) else 50.0
         if embed_dim % 2 or any((embed_dim // 2) % h for h in self.num_heads_window + self.num_heads_stripe):
             raise ValueError("embed_dim/2 must be divisible by the number of heads")
         if max((embed_dim // 2) // h for h in self.num_heads_window + self.num_heads_stripe) > 32:
@@ -395,7 +404,7 @@ class GRL(nn.Module):
         # fast mode, logit scales beyond GRL_HIQ_SCALE (trained checkpoints sit at the clamp, 100): the q / k / anchor planes come from
         # the split-operand projection -- at scale 100 the fp16 rounding of x and W in this one GEMM is the largest single
         # contribution to the output error (tools/precision_sites.py: rms 8.9e-5 of 1.6e-4), amplified by the scale itself
-        hiq = (not hi) and float(max(sc_w.max(), sc_1.max(), sc_2.max())) > float(os.environ.get("GRL_HIQ_SCALE", "50"))
+        hiq = (not hi) and float(max(sc_w.max(), sc_1.max(), sc_2.max())) > float(os.environ.get("GRL_HIQ_SCALE", str(self.hiq_scale)))
         if hiq:
             pk.update(hiq=True, qkv_w3=ops.split3_weight(Wp))
         if not hi and CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
@@ -502,25 +511,30 @@ class GRL(nn.Module):
             out[:C] = v.detach().float()
             return out
 
-        def pconv(conv, cin_pad, cout_pad, r=0, cg=0):
-            return (ops.pack_conv_weight(conv.weight.to(dev), cin_pad, cout_pad, r, cg, split=sp),
+        # fast mode: convolutions named in GRL_SPLIT_SITES (stage_conv, after, last) still run on split operands -- per-site
+        # precision for the models whose fast-mode error sits at the 1e-3 limit (tools/precision_sites.py)
+        sites = set(x for x in os.environ.get("GRL_SPLIT_SITES", self.split_sites).split(",") if x)
+        xs = {k: (3 if hi or k in sites else 1) for k in ("stage_conv", "after", "last")}
+
+        def pconv(conv, cin_pad, cout_pad, r=0, cg=0, site=None):
+            return (ops.pack_conv_weight(conv.weight.to(dev), cin_pad, cout_pad, r, cg, split=xs.get(site, sp)),
                     ops.pack_conv_bias(conv.bias.to(dev), cout_pad, r, cg))
 
         with torch.no_grad():
             stages = []
             for si, stage in enumerate(self.layers):
                 blocks = [self._pack_block(blk, sched[si][bi], dev) for bi, blk in enumerate(stage.blocks)]
-                cw, cb = pconv(stage.conv, CP, CP)
+                cw, cb = pconv(stage.conv, CP, CP, site="stage_conv")
                 stages.append(dict(blocks=blocks, conv_w=cw, conv_b=cb))
             plan = dict(
-                sched=sched, stages=stages, split=sp,
+                sched=sched, stages=stages, split=sp, xs=xs,
                 ns_g=padv(self.norm_start.weight), ns_b=padv(self.norm_start.bias),
                 ne_g=padv(self.norm_end.weight), ne_b=padv(self.norm_end.bias),
                 # conv_first always runs on split operands: K = 27, the cost is nil, and its operand rounding alone is 4e-4 of the
                 # 1e-3 budget of a clamp-scale checkpoint (tools/precision_sites.py base_sr4_ckpt_256_hiscale)
                 first=(ops.pack_conv_weight(self.conv_first.weight.to(dev), _pad32(self.in_channels), CP, split=3),
                        ops.pack_conv_bias(self.conv_first.bias.to(dev), CP)),
-                after=pconv(self.conv_after_body, CP, CP),
+                after=pconv(self.conv_after_body, CP, CP, site="after"),
             )
             out_p = (self.out_channels + 15) // 16 * 16
             if self.upsampler == "pixelshuffle":
@@ -539,7 +553,7 @@ class GRL(nn.Module):
                 plan["up1"], plan["up2"] = pconv(self.conv_up1, 64, 64), pconv(self.conv_up2, 64, 64)
                 plan["hr"], plan["last"] = pconv(self.conv_hr, 64, 64), pconv(self.conv_last, 64, out_p)
             else:
-                plan["last"] = pconv(self.conv_last, CP, out_p)
+                plan["last"] = pconv(self.conv_last, CP, out_p, site="last")
         self._plan_cache = {key: plan}  # one geometry at a time keeps memory bounded (captured graphs hold their own plan)
         return plan
 
@@ -562,7 +576,10 @@ class GRL(nn.Module):
         sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
         mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=sp)
-        if "cab2_blob" in pk:
+        if "cab2_blob" in pk and os.environ.get("GRL_SE_FOLD", "1") != "0":   # conv2 + pool + squeeze-excite gate in one launch
+            return ops.cab_conv2(mid, pk["cab2_blob"], pk["cab2_bias"], B, H, W,
+                                 se=(pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"], self.embed_dim))
+        elif "cab2_blob" in pk:
             raw, pool = ops.cab_conv2(mid, pk["cab2_blob"], pk["cab2_bias"], B, H, W)
         else:
             raw, pool = ops.conv3x3(mid, pk["cab2_w"], pk["cab2_b"], B, H, W, want_pool=True, out_dtype=dt, x_split=sp)
@@ -686,7 +703,7 @@ class GRL(nn.Module):
                 if check:
                     print(f"GRL_CHECK_RANGE layers.{si}.blocks.{bi}: max|x| = {r.abs().max().item():.4g}  (fp16 operand limit 65504)")
             # TransformerStage.forward (grl.py:164-170): conv3x3 + residual
-            t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t, x_split=plan["split"])
+            t = ops.conv3x3(r, st["conv_w"], st["conv_b"], B, H, W, resid=t, x_split=plan["xs"]["stage_conv"])
         return ops.layernorm(t, plan["ne_g"], plan["ne_b"], C)
 
     @staticmethod
@@ -719,7 +736,7 @@ class GRL(nn.Module):
                         r[g] = self._block(r[g], pk, plan["sched"][si][bi], Bg, H, W)
             for g in range(n):
                 with torch.cuda.stream(pool[g]):
-                    parts[g] = ops.conv3x3(r[g], st["conv_w"], st["conv_b"], Bg, H, W, resid=parts[g], x_split=plan["split"])
+                    parts[g] = ops.conv3x3(r[g], st["conv_w"], st["conv_b"], Bg, H, W, resid=parts[g], x_split=plan["xs"]["stage_conv"])
         out = torch.empty_like(t)
         for g in range(n):
             with torch.cuda.stream(pool[g]):
@@ -953,7 +970,7 @@ class GRL(nn.Module):
         bf = torch.float32 if sp == 3 else ops.GEMM_DTYPE
 
         f = ops.conv3x3(self._tokens(x, plan["first"][0].shape[2] // 3), *plan["first"], B, H, W, x_split=3)   # conv_first
-        body = conv(self.forward_features(f, plan, B, H, W), *plan["after"], B, H, W, resid=f)  # conv_after_body + f
+        body = ops.conv3x3(self.forward_features(f, plan, B, H, W), *plan["after"], B, H, W, resid=f, x_split=plan["xs"]["after"])  # conv_after_body + f
         if self.upsampler == "pixelshuffle":
             y = conv(body, *plan["cbu"], B, H, W, act=2, slope=0.01, out_dtype=bf)
             h, w, r = H, W, plan["ups_r"]
@@ -975,7 +992,7 @@ class GRL(nn.Module):
             y = conv(y, *plan["hr"], B, 4 * H, 4 * W, act=2, slope=0.2, out_dtype=bf)
             y = self._image(conv(y, *plan["last"], B, 4 * H, 4 * W), B, 4 * H, 4 * W, oc)
         else:
-            y = self._image(conv(body, *plan["last"], B, H, W), B, H, W, oc)
+            y = self._image(ops.conv3x3(body, *plan["last"], B, H, W, x_split=plan["xs"]["last"]), B, H, W, oc)
             if self.in_channels == self.out_channels:
                 y = x + y
         y = y / self.img_range + mean

@@ -535,9 +535,13 @@ def pack_cab_conv2(w: torch.Tensor, bias: torch.Tensor):
     return blob, b
 
 
-def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int):
+_SE_COUNTERS = {}   # (device, stream) -> zeroed int32 counters the kernel returns to zero (one launch at a time per stream)
+
+
+def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int, se=None):
     """(out [B*H*W, 192] fp16, pool partial sums [B * wgs_per_image, 192]) = conv3x3(x) + bias of the CAB's second convolution
-    (grl_cab_conv2_fwd: filter bank in registers); x [B*H*W, >= 56] fp16 with zero pad channels."""
+    (grl_cab_conv2_fwd: filter bank in registers); x [B*H*W, >= 56] fp16 with zero pad channels.  ``se=(w1, b1, w2, b2, C)``:
+    the squeeze-excite gate [B, 192] is computed by the kernel's last workgroup per image and returned instead of the sums."""
     _dev_check(x, blob, bias)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == GEMM_DTYPE and x.shape[0] == B * H * W and x.shape[1] >= 56
     out = torch.empty(B * H * W, 192, dtype=GEMM_DTYPE, device=x.device)
@@ -546,9 +550,21 @@ def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H
     pool = torch.empty(B * wgs, 192, dtype=torch.float32, device=x.device)
     args = L.GrlCabConv2Args(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), bias=_ptr(bias), B=B, H=H, W=W, wgs_per_image=wgs,
                              out=_ptr(out), ldo=192, pool_partial=_ptr(pool), pool_stride=192)
+    gate = None
+    if se is not None:
+        w1, b1, w2, b2, C_ = se
+        _dev_check(w1, b1, w2, b2)
+        key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
+        cnt = _SE_COUNTERS.get(key)
+        if cnt is None or cnt.numel() < B:
+            cnt = _SE_COUNTERS[key] = torch.zeros(max(B, 64), dtype=torch.int32, device=x.device)
+        gate = torch.empty(B, 192, dtype=torch.float32, device=x.device)
+        args.gate, args.se_counter = _ptr(gate), _ptr(cnt)
+        args.se_w1, args.se_b1, args.se_w2, args.se_b2 = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
+        args.se_c, args.se_mid, args.inv_hw = C_, w1.shape[0], 1.0 / (H * W)
     with _timed("conv3x3"):
         L.check(L.lib().grl_cab_conv2_fwd(L.stream_ptr(), C.byref(args)), "grl_cab_conv2_fwd")
-    return out, pool
+    return out, (gate if se is not None else pool)
 
 
 def se_scale(pool: torch.Tensor, B: int, CP: int, C_: int, HW: int, w1, b1, w2, b2) -> torch.Tensor:

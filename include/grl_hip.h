@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 14
+#define GRL_ABI_VERSION 15
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -324,6 +324,16 @@ typedef struct GrlCabConv2Args {
     int64_t ldo;
     float* pool_partial;
     int64_t pool_stride;    /* >= 192 */
+    /* optional squeeze-excite gate (ChannelAttention.attention, mixed_attn_block.py:956-963) computed by the last workgroup   */
+    /* of every image from the partial sums: gate[b][c] = sigmoid(W2 . relu(W1 . mean_b + b1) + b2), 0 for c >= se_c           */
+    float* gate;            /* [B, 192] or NULL (then the fields below are ignored)                           */
+    int32_t* se_counter;    /* [B] zero-initialised once; the kernel leaves it zero (one launch at a time per buffer) */
+    const float* se_w1;     /* [se_mid, se_c] */
+    const float* se_b1;     /* [se_mid]       */
+    const float* se_w2;     /* [se_c, se_mid] */
+    const float* se_b2;     /* [se_c]         */
+    int32_t se_c, se_mid;   /* <= 192, <= 64  */
+    float inv_hw;           /* 1 / (H * W)    */
 } GrlCabConv2Args;
 
 int grl_cab_conv2_fwd(void* stream, const GrlCabConv2Args* args);

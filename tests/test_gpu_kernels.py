@@ -727,3 +727,14 @@ def test_cab_conv2_register_resident_filters(shape):
     sums = pool.view(B, -1, 192).sum(1).cpu()
     ref_s = ref.view(B, H * W, Cout).sum(1)
     assert (sums[:, :Cout] - ref_s).abs().max().item() < 1e-3 * max(1.0, ref_s.abs().max().item())
+    # the squeeze-excite gate from the kernel's last workgroup per image (twice: the arrival counters return to zero)
+    Cm = 45
+    w1, b1 = (torch.randn(Cm, Cout, generator=g) * 0.2).to(dev), (torch.randn(Cm, generator=g) * 0.1).to(dev)
+    w2, b2 = (torch.randn(Cout, Cm, generator=g) * 0.2).to(dev), (torch.randn(Cout, generator=g) * 0.1).to(dev)
+    for _ in range(2):
+        out2, gate = ops.cab_conv2(xm.to(dev), blob, b192, B, H, W, se=(w1, b1, w2, b2, Cout))
+        torch.cuda.synchronize()
+        assert torch.equal(out2, out)
+        mean = ref_s.to(dev).float() / (H * W)
+        gref = torch.sigmoid(torch.relu(mean @ w1.t() + b1) @ w2.t() + b2)
+        assert (gate[:, :Cout] - gref).abs().max().item() < 1e-4 and (gate[:, Cout:] == 0).all()

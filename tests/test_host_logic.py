@@ -113,7 +113,7 @@ def test_ctypes_layout_matches_the_c_header(tmp_path):
     import subprocess
 
     structs = {"GrlLinearArgs": _lib.GrlLinearArgs, "GrlTokenGrid": _lib.GrlTokenGrid, "GrlAttnArgs": _lib.GrlAttnArgs,
-               "GrlConvArgs": _lib.GrlConvArgs, "GrlMlpArgs": _lib.GrlMlpArgs, "GrlQkvArgs": _lib.GrlQkvArgs, "GrlQkvAnchorArgs": _lib.GrlQkvAnchorArgs,
+               "GrlConvArgs": _lib.GrlConvArgs, "GrlMlpArgs": _lib.GrlMlpArgs, "GrlQkvArgs": _lib.GrlQkvArgs, "GrlQkvAnchorArgs": _lib.GrlQkvAnchorArgs, "GrlCabConv2Args": _lib.GrlCabConv2Args,
                "GrlTailArgs": _lib.GrlTailArgs,
                "GrlLnResArgs": _lib.GrlLnResArgs, "GrlGemmTnArgs": _lib.GrlGemmTnArgs, "GrlAttnBwdArgs": _lib.GrlAttnBwdArgs,
                "GrlAdamWArgs": _lib.GrlAdamWArgs}
