@@ -576,7 +576,10 @@ class GRL(nn.Module):
         sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
         mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=sp)
-        if "cab2_blob" in pk and os.environ.get("GRL_SE_FOLD", "1") != "0":   # conv2 + pool + squeeze-excite gate in one launch
+        # (GRL_SE_FOLD=1: conv2 + pool + squeeze-excite gate in one launch, the gate by the last workgroup of each image.  Measured
+        # SLOWER in the two-stream bench, 88.1 against 82.6 ms/step: the serial tail of one workgroup per image holds the whole
+        # launch, while the separate 10-us se_kernel hides behind the other tile group's kernels.  Kept as an option, off.)
+        if "cab2_blob" in pk and os.environ.get("GRL_SE_FOLD", "0") == "1":
             return ops.cab_conv2(mid, pk["cab2_blob"], pk["cab2_bias"], B, H, W,
                                  se=(pk["se1_w"], pk["se1_b"], pk["se3_w"], pk["se3_b"], self.embed_dim))
         elif "cab2_blob" in pk:
