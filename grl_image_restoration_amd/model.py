@@ -212,7 +212,8 @@ class GRL(nn.Module):
         #   auto : measured on the fixtures (max |err| against the reference, bar 1e-3; tests/test_gpu_model.py):
         #          GRL-Base SR                 fast                                    2.1e-4 (clamp-scale checkpoints 6.5e-4)
         #          GRL-Base deblur (no upsampler: y = x + conv_last(body), no smoothing tail)
-        #                                      fast 1.16e-3 -> + stage/after/last convs split 1.0e-3 -> + q/k projection split 7.8e-4
+        #                                      fast 1.16e-3 -> + stage/after/last convs split 1.0e-3 -> + CAB conv1 split 8.2e-4
+        #                                      (with the q/k projection split instead: 7.8e-4, but 4.0 instead of 5.6 MP/s)
         #          GRL-Small denoise           fast 1.14e-3 -> + stage/after/last convs split 7.2e-4
         #          GRL-Tiny                    high (fast + splits 6e-4 .. 8e-4, but 8e-3 at clamp scales)
         precision = os.environ.get("GRL_PRECISION", precision)
@@ -222,8 +223,8 @@ class GRL(nn.Module):
         self.precision = precision if precision != "auto" else ("high" if embed_dim < 100 else "fast")
         # fast mode: comma list of conv sites kept on split operands (see _plan); logit scale above which a block's q / k / anchor
         # planes come from the split-operand projection (0: always)
-        self.split_sites = "stage_conv,after,last" if narrow else ""
-        self.hiq_scale = 0.0 if (embed_dim >= 160 and not upsampler) else 50.0
+        self.split_sites = ("stage_conv,after,last,cab0" if embed_dim >= 160 else "stage_conv,after,last") if narrow else ""
+        self.hiq_scale = float(os.environ.get("GRL_HIQ_SCALE", "50"))
         if embed_dim % 2 or any((embed_dim // 2) % h for h in self.num_heads_window + self.num_heads_stripe):
             raise ValueError("embed_dim/2 must be divisible by the number of heads")
         if max((embed_dim // 2) // h for h in self.num_heads_window + self.num_heads_stripe) > 32:
@@ -404,7 +405,7 @@ class GRL(nn.Module):
         # fast mode, logit scales beyond GRL_HIQ_SCALE (trained checkpoints sit at the clamp, 100): the q / k / anchor planes come from
         # the split-operand projection -- at scale 100 the fp16 rounding of x and W in this one GEMM is the largest single
         # contribution to the output error (tools/precision_sites.py: rms 8.9e-5 of 1.6e-4), amplified by the scale itself
-        hiq = (not hi) and float(max(sc_w.max(), sc_1.max(), sc_2.max())) > float(os.environ.get("GRL_HIQ_SCALE", str(self.hiq_scale)))
+        hiq = (not hi) and float(max(sc_w.max(), sc_1.max(), sc_2.max())) > self.hiq_scale
         if hiq:
             pk.update(hiq=True, qkv_w3=ops.split3_weight(Wp))
         if not hi and CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
@@ -481,8 +482,10 @@ class GRL(nn.Module):
             if hi:
                 CmO = CmI   # fp32 mid tensor written by the plain store path: every channel of its row comes from the conv
             sp = 3 if hi else 1
+            sites = set(x for x in os.environ.get("GRL_SPLIT_SITES", self.split_sites).split(",") if x)
+            pk["cab0_split"] = 3 if (hi or "cab0" in sites) else 1   # the CAB's first conv on split operands (per-site precision, see _plan)
             pk.update(
-                cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO, split=sp), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
+                cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO, split=pk["cab0_split"]), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
                 cab2_w=ops.pack_conv_weight(c2.weight.to(dev), CmI, CP, split=sp), cab2_b=ops.pack_conv_bias(c2.bias.to(dev), CP),
                 cab_mid=CmI,
                 se1_w=se[1].weight.detach().float().reshape(se[1].weight.shape[0], C).to(dev).clone(),   # copies: a plan never aliases
@@ -575,7 +578,7 @@ class GRL(nn.Module):
         hi = self.precision == "high"
         sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
         mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
-        ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=sp)
+        ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=pk["cab0_split"])
         # (GRL_SE_FOLD=1: conv2 + pool + squeeze-excite gate in one launch, the gate by the last workgroup of each image.  Measured
         # SLOWER in the two-stream bench, 88.1 against 82.6 ms/step: the serial tail of one workgroup per image holds the whole
         # launch, while the separate 10-us se_kernel hides behind the other tile group's kernels.  Kept as an option, off.)
