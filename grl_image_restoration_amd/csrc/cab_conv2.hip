@@ -88,7 +88,7 @@ __global__ __launch_bounds__(C2_THREADS) void cab_conv2_kernel(GrlCabConv2Args p
         const int ty = tile / tiles_x, tx = tile - ty * tiles_x;
         const int y0 = ty * C2_TH - 1, x0 = tx * C2_TW - 1;
         int hy = h0 >> 16, hx = (h0 >> 4) & 0xfff, seg = h0 & 15;
-#pragma unroll
+#pragma unroll 1   // (unrolled, the five pieces' addresses were hoisted out of the tile loop and spilled)
         for (int j = 0; j < C2_ROUNDS; ++j) {
             if (j > 0) {   // 512 pieces on = 73 pixels + 1 segment = 2 halo rows + 5 pixels + 1 segment
                 static_assert(C2_THREADS == 73 * C2_SEG + 1 && 73 == 2 * C2_HW + 5, "piece stepping");
@@ -99,7 +99,7 @@ __global__ __launch_bounds__(C2_THREADS) void cab_conv2_kernel(GrlCabConv2Args p
             const int gy = y0 + hy, gx = x0 + hx;
             const bool ok = hy < C2_HH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
             const uint32_t voff = ok ? (uint32_t)(((int64_t)gy * p.W + gx) * p.ldx * 2 + seg * 16) : 0xfffffff0u;
-            const uint32_t m0v = lds0 + buf * C2_HALO_B + (j * C2_THREADS + wave_u * 64) * 16;
+            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + buf * C2_HALO_B + (j * C2_THREADS + wave_u * 64) * 16);
             asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds" ::"s"(m0v), "v"(voff), "s"(xsrd) : "memory");
         }
     };
