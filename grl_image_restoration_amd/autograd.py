@@ -101,6 +101,12 @@ def _zeros(n: int, device) -> torch.Tensor:
 _REGISTERED = weakref.WeakKeyDictionary()   # module -> storage addresses of its parameters (long-lived: safe cache keys)
 
 
+def forget_parameters(module: torch.nn.Module) -> None:
+    """Drops the cached padded fp16 copies of ``module``'s weights (GRL.invalidate_plan: weights changed behind autograd's back)."""
+    for p in module.parameters():
+        _WEIGHTS.pop(p.data_ptr(), None)
+
+
 def register_parameters(module: torch.nn.Module) -> None:
     """Allow the padded fp16 copies of this module's weights to be kept between the forward and the backward of a step (and
     across steps until the optimizer changes them).  Only registered parameters are cached: a temporary tensor's address can be

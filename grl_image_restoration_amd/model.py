@@ -332,12 +332,17 @@ class GRL(nn.Module):
         return state_dict
 
     def invalidate_plan(self):
-        """Drops the packed weights / tables (rebuilt lazily) and every captured graph that points at them.  Called by the
-        load_state_dict post-hook; in-place parameter updates (optimizer, EMA copy) are caught by the version stamp
-        in ``_plan``."""
+        """Drops the packed weights / tables (rebuilt lazily), every captured graph that points at them, the cached fp16
+        training weights and the cached parameter list.  Called by the load_state_dict post-hook; in-place parameter updates
+        through autograd-visible ops (optimizer steps, ``p.mul_()``, ``p.copy_()``) are caught by the version stamp in ``_plan``.
+        NOT caught -- call this method yourself afterwards: updates through ``.data`` (``p.data.mul_()``, ``m.weight.data *= s``:
+        torch does not bump the version counter for them) and parameters REPLACED by new tensors
+        (``load_state_dict(assign=True)``, ``m.weight = nn.Parameter(...)``)."""
         self._plan_cache = {}
+        self._plist = None
         if getattr(self, "_graphs", None):
             self._graphs = {}
+        AG.forget_parameters(self)
 
     def _param_stamp(self):
         """Changes whenever a parameter is modified in place or replaced (torch bumps ``_version`` on every in-place op)."""
