@@ -22,7 +22,6 @@ import math
 import weakref
 from typing import Optional, Sequence
 
-import threading
 
 import torch
 import torch.nn.functional as F
@@ -41,14 +40,16 @@ def pad_width(n: int) -> int:
 
 
 class _State:
-    # gradient operand scale (a power of two) of the backward pass running on (thread, device): two models -- or two device
-    # threads -- in one process do not see each other's scale, and a pass that never went through GradScaleTop runs at 1.0
+    # gradient operand scale (a power of two) of the backward pass running on a device: autograd runs the backward of a device's
+    # nodes on that device's own engine thread, so models on different GPUs of one process do not see each other's scale
+    # (keying by thread as well would hide the value from the thread that called backward())
     scales: dict = {}
     target = 64.0        # the largest incoming gradient is brought to about this magnitude
 
 
-def _scale_key(device) -> tuple:
-    return (threading.get_ident(), torch.device(device).index if device is not None else torch.cuda.current_device())
+def _scale_key(device) -> int:
+    idx = torch.device(device).index if device is not None else None
+    return idx if idx is not None else torch.cuda.current_device()
 
 
 def grad_scale(device=None) -> float:

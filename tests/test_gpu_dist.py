@@ -64,6 +64,6 @@ def test_ddp_step_over_rccl(nccl_world1):
         loss.backward()
         assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in m.parameters())
         opt.step()
-        losses.append(float(loss))
+        losses.append(float(loss.detach()))
     assert all(l == l and abs(l) < 10 for l in losses)                                   # (stochastic depth is on: no monotonic claim)
     assert sum(int((a != b.detach()).any()) for a, b in zip(before, m.parameters())) > len(before) // 2   # the update went through
