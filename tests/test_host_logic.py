@@ -145,6 +145,45 @@ def test_softmax_offset_tables():
     assert torch.equal(fl, torch.round(fl)) and (fl <= -scale * tables.LOG2E).all() and fl.abs().max() < 2048
 
 
+def test_lazy_ceil_bounds_every_logit():
+    """GrlAttnArgs.lazy_ceil: the per-head bound the row-streaming attention kernel uses to stop testing for overflow must
+    dominate every logit scale*log2e*cos + bias the kernel can form from fp16-rounded unit vectors (element-wise rounding of q
+    and k, the scale folded into q before rounding, as the QKV epilogue does)."""
+    g = torch.Generator().manual_seed(3)
+    nh, d, n = 4, 30, 4096
+    scale = torch.tensor([4.0, 10.0, 37.5, 100.0])
+    bias = torch.rand(200, nh, generator=g) * 16
+    tab = tables.kernel_table(bias)
+    ceil = tables.lazy_ceil(scale, tab)
+    assert ceil.shape == (nh,) and ceil.dtype == torch.float32
+    k = torch.nn.functional.normalize(torch.randn(n, nh, d, generator=g), dim=-1)
+    q = k.clone()                                  # the worst case: q parallel to k (cos = 1 before rounding)
+    q16 = (q * (scale * tables.LOG2E).view(1, nh, 1)).half().float()
+    k16 = k.half().float()
+    logits = (q16 * k16).sum(-1) + tab.max(dim=1).values.view(1, nh)
+    assert (logits.max(dim=0).values <= ceil).all()
+    assert (ceil - logits.max(dim=0).values < 1.0 + 0.01 * scale * tables.LOG2E).all()   # and it is not sloppy either
+
+
+def test_cab_conv2_blob_layout():
+    """ops.pack_cab_conv2 writes the MFMA-fragment layout include/grl_hip.h documents for grl_cab_conv2_fwd: lane (g4, r) of
+    (group G, k-step s) holds W[16 G + r][k = 32 s + 8 g4 ..], k = (ky * 3 + kx) * 48 + cin; zero beyond Cin / Cout / 432."""
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    Cout, Cin = 180, 45
+    w = torch.randn(Cout, Cin, 3, 3, generator=g)
+    b = torch.randn(Cout, generator=g)
+    blob, b192 = ops.pack_cab_conv2(w, b)
+    assert blob.dtype == torch.uint8 and blob.numel() == 12 * 14 * 64 * 16
+    assert torch.equal(b192[:Cout], b) and torch.equal(b192[Cout:], torch.zeros(192 - Cout))
+    frag = blob.view(torch.float16).view(12, 14, 4, 16, 8)      # [G][s][g4][r][8]
+    wk = frag.permute(0, 3, 1, 2, 4).reshape(192, 14 * 32).float()   # [16 G + r][32 s + 8 g4 + j]
+    want = torch.zeros(192, 14 * 32)
+    want[:Cout, : 9 * 48].view(Cout, 9, 48)[:, :, :Cin] = w.permute(0, 2, 3, 1).reshape(Cout, 9, Cin).half().float()
+    assert torch.equal(wk, want)
+
+
 def test_ctypes_structs_refuse_unknown_fields():
     """ctypes would silently ignore a misspelt keyword and leave the C field zero."""
     with pytest.raises(TypeError):
