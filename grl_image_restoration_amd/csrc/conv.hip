@@ -380,7 +380,8 @@ extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;
     if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    if (p.CinP % 64 == 0) return launch_conv_nt<64>(p, st);
+    static const int kc_env = getenv("GRL_CONV_KC") ? atoi(getenv("GRL_CONV_KC")) : 0;   // tuning knob: 32 forces the 32-channel chunks
+    if (p.CinP % 64 == 0 && kc_env != 32) return launch_conv_nt<64>(p, st);
     return launch_conv_nt<32>(p, st);
 }
 
