@@ -473,6 +473,9 @@ extern "C" int64_t grl_proj_blob_bytes(int32_t Cpad) {
     return (int64_t)(Cpad / 32) * proj_chunk_bytes(Cpad);
 }
 
+// csrc/tail_regs.hip: DRAFT of the weights-stationary tail, never run on hardware yet; only with GRL_TAIL_REGS=1
+int grl_tail_regs_launch(const GrlTailArgs& a, hipStream_t st);
+
 extern "C" int grl_block_tail_fwd(void* stream, const GrlTailArgs* args) {
     const GrlTailArgs& a = *args;
     if (a.M <= 0) return 0;
@@ -481,6 +484,11 @@ extern "C" int grl_block_tail_fwd(void* stream, const GrlTailArgs* args) {
         (a.ldatt % 8) || a.ldatt < a.Cpad || (a.ldcab % 4) || a.ldcab < a.Cpad || a.pb == nullptr || a.n1_g == nullptr || a.n1_b == nullptr)
         return GRL_ERR_BAD_ARG;
     if (a.rows_per_image < 128) return GRL_ERR_UNSUPPORTED;   // a 128-token tile may touch at most two images
+    static const bool regs_draft = getenv("GRL_TAIL_REGS") && atoi(getenv("GRL_TAIL_REGS")) == 1;
+    if (regs_draft) {
+        const int rc = grl_tail_regs_launch(a, (hipStream_t)stream);
+        if (rc != GRL_ERR_UNSUPPORTED) return rc;
+    }
     TailP p = {};
     p.x = a.x; p.ldx = a.ldx; p.blob = a.blob; p.M = a.M; p.Cpad = a.Cpad; p.Hpad = a.Hpad;
     p.b2 = a.b2; p.ln_g = a.n2_g; p.ln_b = a.n2_b; p.n_real = a.n_real; p.ln_eps = a.ln_eps; p.res_scale = a.res_scale;

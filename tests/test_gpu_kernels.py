@@ -201,6 +201,15 @@ def test_fused_block_tail(M, C, Hd, rpi):
         assert out[:, C:].abs().max().item() == 0.0
 
 
+@pytest.mark.skipif(__import__("os").environ.get("GRL_TAIL_REGS") != "1",
+                    reason="csrc/tail_regs.hip is a draft that has not run on hardware yet: GRL_TAIL_REGS=1 pytest -k tail_regs_draft")
+@pytest.mark.parametrize("M,rpi", [(2048, 1024), (4096, 4096), (8192, 256)])
+def test_block_tail_regs_draft(M, rpi):
+    """The weights-stationary block tail (GRL_TAIL_REGS=1 routes grl_block_tail_fwd to it for Cpad 192 / Hpad 384 / M % 32 == 0):
+    same checks as the shipped kernel's test."""
+    test_fused_block_tail(M, 180, 360, rpi)
+
+
 @pytest.mark.parametrize("B,H,W,C,nslots,nanc", [(2, 4, 64, 180, 18, 3), (1, 6, 128, 180, 18, 3), (3, 2, 64, 128, 12, 2), (1, 8, 64, 64, 12, 2),
                                                   (2, 4, 64, 180, 18, 0)])
 def test_qkv_anchor_one_pass(B, H, W, C, nslots, nanc):
