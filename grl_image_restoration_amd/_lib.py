@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 15
+ABI_VERSION = 16
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -24,6 +24,7 @@ EXPORTS = [
     "grl_qkv_fwd",
     "grl_qkv_blob_bytes",
     "grl_qkv_anchor_fwd",
+    "grl_qkv_anchor_lo_blob_bytes",
     "grl_qkv_anchor_blob_bytes",
     "grl_cab_conv2_fwd",
     "grl_cab_conv2_blob_bytes",
@@ -153,6 +154,7 @@ class GrlQkvAnchorArgs(_Strict):
         ("out_plane_stride", C.c_int64),
         ("anc", C.c_void_p),
         ("anc_plane_stride", C.c_int64),
+        ("lo_blob", C.c_void_p),
     ]
 
 
@@ -386,6 +388,8 @@ def lib():
     L.grl_qkv_anchor_fwd.restype = C.c_int
     L.grl_qkv_anchor_blob_bytes.argtypes = [C.c_int32, C.c_int32, C.c_int32]
     L.grl_qkv_anchor_blob_bytes.restype = C.c_int64
+    L.grl_qkv_anchor_lo_blob_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.grl_qkv_anchor_lo_blob_bytes.restype = C.c_int64
     L.grl_cab_conv2_fwd.argtypes = [C.c_void_p, C.POINTER(GrlCabConv2Args)]
     L.grl_cab_conv2_fwd.restype = C.c_int
     L.grl_cab_conv2_blob_bytes.argtypes = []

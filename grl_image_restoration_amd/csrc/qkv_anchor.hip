@@ -431,6 +431,417 @@ int launch_qr(const GrlQkvAnchorArgs& p, hipStream_t st) {
     return 0;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-precision variant of the kernel above (round 4; GrlQkvAnchorArgs.lo_blob): blocks whose logit scales sit near the clamp.
+//
+// The q.k logits multiply the fp16 rounding of x and W by up to 144 (scale 100 x log2 e), and BOTH roundings matter (CPU
+// emulation of every rounding point on the clamp-scale fixture: weights exact or inputs exact alone change nothing measurable,
+// both exact 8.4e-4 -> 5.9e-4).  Round 3 sent such blocks through the generic three-term split linear + a separate anchor
+// launch (x1.57 per step).  Here the low parts ride on what the register-resident design already has:
+//   * x_lo = fp16(x - x_hi) is a second token tile in LDS and meets the SAME A fragments (W_hi in registers): one more
+//     fp16 MFMA per k-step, no more registers;
+//   * W_lo only has to be known to a few bits: e4m3((W - W_hi) 2^(e+4)), 96 KB for the 15 normalised slots, resident in LDS
+//     for the whole launch, multiplied with x_8 = e4m3(x_hi / 16) -- converted in registers from the fp16 B operand, the fp8
+//     32x32x16 MFMA has the same lane <-> k layout -- at twice the fp16 MFMA rate;
+//   * the split slots are all normalised per token (q, k, anchors), so a common factor is free: W_hi and the bias are scaled by
+//     2^e in registers once per launch (exact; e <= 8 chosen by the host so that nothing overflows) and the main term
+//     accumulates at the scale 2^e of the two low terms -- ONE accumulator per slot, no fold; v slots (gscale 0, not
+//     normalised, not multiplied by a logit scale) are not split.
+// LDS: 96 KB of W_lo8 leave room for 32-token tiles (hi + lo, double buffered: 51 KB), so a tile is one token group of the
+// kernel above and there is one barrier per 32 tokens.  Wave w computes a PAIR of split slots together (the B fragments and
+// their fp8 conversion are shared) and then a single slot; wave 3 -- it shares its SIMD with the loader wave -- takes the three
+// anchor slots, all split.
+constexpr int QS_XT = 32 * QR_XROW;                   // one 32-token fp16 plane (hi or lo)
+constexpr int QS_X8ROW = 192 + 16;                    // e4m3 token row (16 B pad: conflict-free ds_read_b128)
+constexpr int QS_XBUF = 2 * QS_XT + 32 * QS_X8ROW;    // hi | lo | x8: 32256
+constexpr int QS_NLO = 15, QS_LROW = 192, QS_LSLOT = 32 * QS_LROW;   // W_lo8 rows are not padded but XOR-swizzled (below)
+constexpr int QS_OFF_LO = 2 * QS_XBUF;                // 64512
+constexpr int QS_OFF_VEC = QS_OFF_LO + QS_NLO * QS_LSLOT;
+constexpr int QS_LDS = QS_OFF_VEC + QR_VEC;           // 159696
+
+typedef __attribute__((__vector_size__(2 * sizeof(short)))) short s16x2;
+typedef __attribute__((__vector_size__(8 * sizeof(int)))) int i32x8;
+
+// the low-part contraction over 64 channels: one v_mfma_f32_32x32x64_f8f6f4 (e4m3 x e4m3, no block scales).  A and B index k
+// the same way, so any (lane half, register, byte) <-> k assignment is right as long as both operands use the same one: here
+// registers 2u, 2u+1 of half h hold k = 16 u + 8 h + [0..7] of the 64-block -- the k order of the fp16 fragments -- and
+// ops.pack_qkv_anchor_lo / the loader wave store rows with byte 64 c + 32 h + 8 u + t = channel 64 c + 16 u + 8 h + t, so a lane
+// half's operand is 32 contiguous bytes.  W_lo8 rows have no pad: 16-B segment s of row j sits at s ^ ((j >> 2) & 3).
+__device__ __forceinline__ f32x16 mfma64_fp8(i32x8 a, i32x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_scale_f32_32x32x64_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
+
+#ifdef QS_DEBUG   // timing probes (s_memtime ticks, 10 ns): [wave 0..7][region 0..7], summed over workgroups and tiles
+__device__ unsigned long long qs_dbg[64];
+#define QS_T(x) const long long x = __builtin_amdgcn_s_memtime()
+#define QS_ADD(i, v) qs_acc[i] += (unsigned long long)(v)
+#else
+#define QS_T(x)
+#define QS_ADD(i, v)
+#endif
+
+__global__ __launch_bounds__(QR_W * 64) void qkv_split_kernel(GrlQkvAnchorArgs p) {
+    using S = QaShape<QR_KS>;
+#ifdef QS_DEBUG
+    unsigned long long qs_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    extern __shared__ __attribute__((aligned(1024))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int half = lane >> 5, j = lane & 31;
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const bool compute = wave_u < 7;
+    const char* blob = (const char*)p.blob;
+    const int tiles_x = p.W >> 6, tiles_img = (p.H >> 1) * tiles_x;
+    const int ntiles = p.B * tiles_img;
+    if ((int)blockIdx.x >= ntiles) return;
+    const int nsub = 4 * ((ntiles - (int)blockIdx.x + (int)gridDim.x - 1) / (int)gridDim.x);   // 32-token tiles of this workgroup
+    const float two_e = ((const float*)p.lo_blob)[1];   // 2^e: scale of the low terms, and of W_hi / the bias of the split slots
+
+    float* vec = (float*)(smem + QS_OFF_VEC);      // [slot][36]: bias, gscale
+    for (int i = tid; i < QR_SLOTS * 33; i += QR_W * 64) {
+        const int slot = i / 33, c = i - 33 * slot;
+        vec[slot * 36 + c] = *(const float*)(blob + (size_t)(slot >> 1) * S::BUFP + (slot & 1) * S::SLOT + 32 * S::WROW + 4 * c);
+    }
+    for (int i = tid; i < QS_NLO * QS_LSLOT / 16; i += QR_W * 64)
+        *(uint4*)(smem + QS_OFF_LO + 16 * i) = *(const uint4*)((const char*)p.lo_blob + 16 + 16 * i);
+
+    // 32-token tile number `it` of this workgroup: token group it & 3 of its 2-row x 64-column tile number it >> 2
+    auto sub_origin = [&](int it, int64_t& cell0) -> int64_t {
+        const int tile = (int)blockIdx.x + (it >> 2) * (int)gridDim.x, grp = it & 3;
+        const int b = tile / tiles_img, t = tile - b * tiles_img;
+        const int y2 = t / tiles_x, c64 = t - y2 * tiles_x;
+        cell0 = ((int64_t)b * (p.H >> 1) + y2) * (p.W >> 1) + 32 * c64 + 8 * grp;
+        return ((int64_t)b * p.H + 2 * y2) * p.W + 64 * c64 + 16 * grp;
+    };
+    // 4 channels of a token (fp32) -> the hi / lo fp16 planes at byte offset `off`, the e4m3 plane at `off8` (x_hi / 16, clamped:
+    // the fp8 conversion does not saturate -- probed, tools/probes/fp8_probe.hip: beyond +-448 it yields NaN)
+    auto x_put = [&](char* buf, int off, int off8, float4 v) {
+        typedef __attribute__((__vector_size__(2 * sizeof(float)))) float f32x2;
+        // x_hi: saturating fp32 -> fp16 (common.h, sat16), two values per conversion
+        const f16x2 a = __builtin_convertvector(f32x2{sat16(v.x), sat16(v.y)}, f16x2), b = __builtin_convertvector(f32x2{sat16(v.z), sat16(v.w)}, f16x2);
+        const uint32_t h0 = __builtin_bit_cast(uint32_t, a), h1 = __builtin_bit_cast(uint32_t, b);
+        // x_lo = x - x_hi, one mixed-precision FMA each (the half is read in place), not scaled: it meets the same (scaled) A
+        // fragments as x_hi.  Residuals below 2^-14 (|x| < 1/4) are fp16 subnormals: at worst lost, never wrong.  No saturation needed.
+        auto resid = [](uint32_t h, float x, bool hi_half) {
+            float r;
+            if (hi_half) asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+            else asm("v_fma_mix_f32 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "=v"(r) : "v"(h), "v"(x));
+            return r;
+        };
+        const f16x2 l0 = __builtin_convertvector(f32x2{resid(h0, v.x, false), resid(h0, v.y, true)}, f16x2);
+        const f16x2 l1 = __builtin_convertvector(f32x2{resid(h1, v.z, false), resid(h1, v.w, true)}, f16x2);
+        *(uint2*)(buf + off) = uint2{h0, h1};
+        *(uint2*)(buf + QS_XT + off) = uint2{__builtin_bit_cast(uint32_t, l0), __builtin_bit_cast(uint32_t, l1)};
+        // x_8 = e4m3(x_hi / 16) straight from the packed halves, clamped to +-7168 first
+        const f16x2 top = {(f16)7168.0f, (f16)7168.0f}, bot = {(f16)-7168.0f, (f16)-7168.0f};
+        s16x2 w8 = {0, 0};
+        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, __builtin_elementwise_max(__builtin_elementwise_min(a, top), bot), 16.0f, false);
+        w8 = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(w8, __builtin_elementwise_max(__builtin_elementwise_min(b, top), bot), 16.0f, true);
+        *(int*)(buf + 2 * QS_XT + off8) = __builtin_bit_cast(int, w8);
+    };
+    // byte offset of channels 4 c4 .. 4 c4 + 3 in an e4m3 token row: 64 c + 32 h + 8 u + t for channel 64 c + 16 u + 8 h + t
+    auto x8_col = [](int c4) { const int k = 4 * c4; return (k & ~63) + 32 * ((k >> 3) & 1) + 8 * ((k >> 4) & 3) + (k & 7); };
+
+    {   // first tile: 3 float4 per thread (token slot ts: image row ts >> 4, column ts & 15)
+        int64_t c0;
+        const int64_t o0 = sub_origin(0, c0);
+#pragma unroll
+        for (int ph = 0; ph < 3; ++ph) {
+            const int idx = ph * 512 + tid, ts = idx / 48, c4 = idx - 48 * ts;
+            const int64_t m = o0 + (int64_t)(ts >> 4) * p.W + (ts & 15);
+            x_put(smem, ts * QR_XROW + 8 * c4, ts * QS_X8ROW + x8_col(c4), *(const float4*)(p.x + m * p.ldx + 4 * c4));
+        }
+    }
+
+    if (!compute) {
+        // ---- loader wave: 24 float4 per lane and tile (token quad q = slots 4 q .. 4 q + 3: image row q >> 2, columns 4 (q & 3) ..;
+        // 4 tokens x 48 float4 = 3 wave-wide loads).  Tile it + 2 is in flight while the compute waves work on tile it + 1's
+        // predecessor: its loads are issued right after tile it + 1 has been converted and have a whole tile period to land.
+        int goff[3], woff[3], woff8[3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int e = 64 * r + lane, d = e / 48, c4 = e - 48 * d;
+            goff[r] = d * (int)p.ldx + 4 * c4;          // floats from the quad's first token
+            woff[r] = d * QR_XROW + 8 * c4;
+            woff8[r] = d * QS_X8ROW + x8_col(c4);
+        }
+        // The loads are inline asm on purpose: the compiler's own wait-count bookkeeping put "s_waitcnt vmcnt(9)" right behind
+        // the 24 loads of a tile (it wants a fixed number in flight at the loop head), i.e. the loader sat out an HBM round trip
+        // per tile and everybody waited for it at the barrier.  Hidden from the compiler, the loads are ordered by hand: issued
+        // at the end of a tile period, awaited (vmcnt(0), tied to the registers) at the start of the next one.  The ISA has been
+        // checked for copies of these registers between issue and wait (there are none: tools/kernel_resources.sh).
+        f32x4 nb[24];
+        auto issue = [&](int it) {
+            int64_t cn;
+            const int64_t o = sub_origin(it, cn);
+#pragma unroll
+            for (int k = 0; k < 24; ++k) {
+                const int q = k / 3;
+                const float* src = p.x + (o + (int64_t)(q >> 2) * p.W + 4 * (q & 3)) * p.ldx + goff[k % 3];
+                asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(nb[k]) : "v"(src) : "memory");
+            }
+        };
+        auto landed = [&]() {
+            asm volatile("s_waitcnt vmcnt(0)"
+                         : "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]), "+v"(nb[4]), "+v"(nb[5]), "+v"(nb[6]), "+v"(nb[7]),
+                           "+v"(nb[8]), "+v"(nb[9]), "+v"(nb[10]), "+v"(nb[11]), "+v"(nb[12]), "+v"(nb[13]), "+v"(nb[14]), "+v"(nb[15]),
+                           "+v"(nb[16]), "+v"(nb[17]), "+v"(nb[18]), "+v"(nb[19]), "+v"(nb[20]), "+v"(nb[21]), "+v"(nb[22]), "+v"(nb[23])
+                         :: "memory");
+        };
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // (the compiler-tracked loads of the prologue)
+        if (nsub > 1) issue(1);
+        for (int it = 0; it < nsub; ++it) {
+            QS_T(l0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            QS_T(l1);
+            QS_ADD(0, l1 - l0);
+            if (it + 1 >= nsub) continue;
+            char* xn = smem + ((it + 1) & 1) * QS_XBUF;
+            landed();
+            QS_T(l2);
+            QS_ADD(1, l2 - l1);
+#pragma unroll
+            for (int k = 0; k < 24; ++k)
+                x_put(xn, (k / 3) * 4 * QR_XROW + woff[k % 3], (k / 3) * 4 * QS_X8ROW + woff8[k % 3], float4{nb[k][0], nb[k][1], nb[k][2], nb[k][3]});
+            QS_T(l3);
+            QS_ADD(2, l3 - l2);
+            if (it + 2 < nsub) issue(it + 2);
+            QS_T(l4);
+            QS_ADD(3, l4 - l3);
+        }
+#ifdef QS_DEBUG
+        if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&qs_dbg[8 * wave_u + i], qs_acc[i]);
+#endif
+        return;
+    }
+
+    // ---- this wave's slots: a pair of split slots (sa, sb) and a single slot sc (split for the anchor wave only) ----
+    int sa, sc;
+    bool c_split;
+    if (wave_u == 3) { sa = 18; sc = 20; c_split = true; }
+    else {
+        const int w = wave_u < 3 ? wave_u : wave_u - 1, br = w / 3, i = w - 3 * br;   // branch (window | stripe), head
+        sa = 9 * br + 2 * i; sc = 9 * br + 6 + i; c_split = false;                    // q/k slots 9 br .. 9 br + 5, v slots 9 br + 6 ..
+    }
+    sa = __builtin_amdgcn_readfirstlane(sa); sc = __builtin_amdgcn_readfirstlane(sc);
+    const int sb = sa + 1;
+    auto lo_index = [](int slot) { return slot < 6 ? slot : (slot < 15 ? slot - 3 : slot - 6); };   // rank among the normalised slots
+    f16x8 A[3][QR_KS];
+    {
+        const int sl[3] = {sa, sb, sc};
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const char* wb = blob + (size_t)(sl[i] >> 1) * S::BUFP + (sl[i] & 1) * S::SLOT + j * S::WROW + 16 * half;
+            const f16 ws = (f16)((i < 2 || c_split) ? two_e : 1.0f);
+#pragma unroll
+            for (int s = 0; s < QR_KS; ++s) A[i][s] = *(const f16x8*)(wb + 32 * s) * ws;
+        }
+    }
+    // this lane's two 16-B segments of a 64-channel block of W_lo8 row j (swizzled, see mfma64_fp8): + 64 c per block
+    const int sw = (j >> 2) & 3;
+    const int seg0 = 16 * ((2 * half) ^ sw), seg1 = 16 * ((2 * half + 1) ^ sw);
+    const char* la = smem + QS_OFF_LO + lo_index(sa) * QS_LSLOT + j * QS_LROW;
+    const char* lb = la + QS_LSLOT;
+    const char* lc = smem + QS_OFF_LO + lo_index(c_split ? sc : sa) * QS_LSLOT + j * QS_LROW;
+    typedef __attribute__((__vector_size__(4 * sizeof(int)))) int i32x4;
+    auto ld32 = [](const char* p0, const char* p1) {   // two 16-B LDS reads -> one 32-byte MFMA operand
+        const i32x4 a = *(const i32x4*)p0, b = *(const i32x4*)p1;
+        return i32x8{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    };
+    const bool anc_lane = (j & 17) == 0;   // first lane of a 2 x 2 cell (even column, upper row)
+
+    auto bias_init = [&](int slot, float ws) -> f32x16 {
+        const float* vb = vec + slot * 36;
+        f32x16 acc;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const float4 b4 = *(const float4*)(vb + 8 * g + 4 * half);
+            acc[4 * g] = b4.x * ws; acc[4 * g + 1] = b4.y * ws; acc[4 * g + 2] = b4.z * ws; acc[4 * g + 3] = b4.w * ws;
+        }
+        return acc;
+    };
+    // pooling (anchor slots), per-slot L2 norm, store: the epilogue of qkv_regs_kernel; `ws2` = square of the factor the slot's
+    // values carry (it only moves the 1e-12 floor of the norm)
+    auto finish = [&](const f32x16& acc, int slot, float ws2, int64_t m_tok, int64_t m_anc) {
+        const float gs = vec[slot * 36 + 32];
+        float v[16];
+        const bool is_anc = slot >= p.nslots;
+        if (is_anc) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float t = acc[r];
+                t += dpp_move<DPP_QUAD_XOR1>(t);
+                v[r] = sum_rows16(t);
+            }
+        } else {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = acc[r];
+        }
+        float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) { s0 = fmaf(v[4 * g], v[4 * g], s0); s1 = fmaf(v[4 * g + 1], v[4 * g + 1], s1); s2 = fmaf(v[4 * g + 2], v[4 * g + 2], s2); s3 = fmaf(v[4 * g + 3], v[4 * g + 3], s3); }
+        const float ss = sum_halves((s0 + s1) + (s2 + s3));
+        const float f = gs != 0.0f ? fabsf(gs) * __builtin_amdgcn_rsqf(fmaxf(ss, (is_anc ? 16e-24f : 1e-24f) * ws2)) : (is_anc ? 0.25f : 1.0f);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) v[r] *= f;
+        if (gs < 0.0f && half) v[15] = 1.0f;
+        if (is_anc) {
+            f16* o = (f16*)p.anc + (int64_t)(slot - p.nslots) * p.anc_plane_stride + m_anc * 32;
+            if (gs != 0.0f) store_slot<false>(o, v, half, anc_lane); else store_slot<true>(o, v, half, anc_lane);
+        } else {
+            f16* o = (f16*)p.out + (int64_t)slot * p.out_plane_stride + m_tok * 32;
+            if (gs != 0.0f) store_slot<false>(o, v, half); else store_slot<true>(o, v, half);
+        }
+    };
+    const float two_2e = two_e * two_e;
+    // The two split slots sa, sb go together (they share the token fragments).  The k loops are software-pipelined by hand: the fragments of k-step s + 1 (and, at the head of a 64-channel block, the
+    // block's fp8 operands) are requested before the MFMAs of step s, and a scheduling barrier keeps that order -- left alone the
+    // compiler issued reads and MFMAs in alternating batches with "s_waitcnt lgkmcnt(0)" in between (LDS latency exposed ~12
+    // times per slot pair, measured 4.2 k cycles for 1.9 k cycles of MFMA work).
+    auto do_pair = [&](const char* rowp, const char* row8, int64_t m_tok, int64_t m_anc) {
+        f32x16 acc0 = bias_init(sa, two_e), acc1 = bias_init(sb, two_e);
+        f16x8 bh = *(const f16x8*)(rowp), bl = *(const f16x8*)(rowp + QS_XT);
+        i32x8 x8, wa8, wb8;
+#pragma unroll
+        for (int s = 0; s < QR_KS; ++s) {
+            const int c = s >> 2, u = s & 3;
+            f16x8 nh = bh, nl = bl;
+            if (s + 1 < QR_KS) { nh = *(const f16x8*)(rowp + 32 * (s + 1)); nl = *(const f16x8*)(rowp + QS_XT + 32 * (s + 1)); }
+#ifndef QS_ABL_NOFP8
+            if (u == 0) {
+                x8 = ld32(row8 + 64 * c, row8 + 64 * c + 16);
+                wa8 = ld32(la + 64 * c + seg0, la + 64 * c + seg1);
+                wb8 = ld32(lb + 64 * c + seg0, lb + 64 * c + seg1);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            acc0 = mfma32_f16(A[0][s], bh, acc0);
+            acc1 = mfma32_f16(A[1][s], bh, acc1);
+#ifndef QS_ABL_NOLO
+            acc0 = mfma32_f16(A[0][s], bl, acc0);
+            acc1 = mfma32_f16(A[1][s], bl, acc1);
+#endif
+#ifndef QS_ABL_NOFP8
+            if (u == 3) {
+                acc0 = mfma64_fp8(wa8, x8, acc0);
+                acc1 = mfma64_fp8(wb8, x8, acc1);
+            }
+#endif
+            __builtin_amdgcn_sched_barrier(0);
+            bh = nh; bl = nl;
+        }
+#ifdef QS_DEBUG
+        asm volatile("s_nop 0" : "+v"(acc0), "+v"(acc1));   // the MFMA results have arrived
+#endif
+        QS_T(c2);
+        finish(acc0, sa, two_2e, m_tok, m_anc);
+        QS_T(c3);
+        finish(acc1, sb, two_2e, m_tok, m_anc);
+        QS_T(c4);
+        QS_ADD(2, c3 - c2);
+        QS_ADD(3, c4 - c3);
+    };
+    auto do_single = [&](const char* rowp, const char* row8, int64_t m_tok, int64_t m_anc) {
+        if (c_split) {
+            f32x16 acc = bias_init(sc, two_e);
+            f16x8 bh = *(const f16x8*)(rowp), bl = *(const f16x8*)(rowp + QS_XT);
+            i32x8 x8, wc8;
+#pragma unroll
+            for (int s = 0; s < QR_KS; ++s) {
+                const int c = s >> 2, u = s & 3;
+                f16x8 nh = bh, nl = bl;
+                if (s + 1 < QR_KS) { nh = *(const f16x8*)(rowp + 32 * (s + 1)); nl = *(const f16x8*)(rowp + QS_XT + 32 * (s + 1)); }
+#ifndef QS_ABL_NOFP8
+                if (u == 0) {
+                    x8 = ld32(row8 + 64 * c, row8 + 64 * c + 16);
+                    wc8 = ld32(lc + 64 * c + seg0, lc + 64 * c + seg1);
+                }
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma32_f16(A[2][s], bh, acc);
+#ifndef QS_ABL_NOLO
+                acc = mfma32_f16(A[2][s], bl, acc);
+#endif
+#ifndef QS_ABL_NOFP8
+                if (u == 3) acc = mfma64_fp8(wc8, x8, acc);
+#endif
+                __builtin_amdgcn_sched_barrier(0);
+                bh = nh; bl = nl;
+            }
+            finish(acc, sc, two_2e, m_tok, m_anc);
+        } else {
+            f32x16 acc = bias_init(sc, 1.0f);
+            f16x8 bh = *(const f16x8*)(rowp);
+#pragma unroll
+            for (int s = 0; s < QR_KS; ++s) {
+                f16x8 nh = bh;
+                if (s + 1 < QR_KS) nh = *(const f16x8*)(rowp + 32 * (s + 1));
+                __builtin_amdgcn_sched_barrier(0);
+                acc = mfma32_f16(A[2][s], bh, acc);
+                __builtin_amdgcn_sched_barrier(0);
+                bh = nh;
+            }
+            finish(acc, sc, 1.0f, m_tok, m_anc);
+        }
+    };
+#ifdef QS_ORDER
+    const bool single_first = wave_u >= 4;   // the two compute waves of a SIMD run their MFMA-heavy and VALU-heavy phases out of step
+#else
+    const bool single_first = false;
+#endif
+
+#pragma unroll 1
+    for (int it = 0; it < nsub; ++it) {
+        QS_T(c0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (not vmcnt: the stores of the previous tile need not have landed)
+        __builtin_amdgcn_s_barrier();   // tile `it` is complete in its buffer; everybody is done reading the other one
+        const char* xt = smem + (it & 1) * QS_XBUF;
+        int64_t cell0;
+        const int64_t origin = sub_origin(it, cell0);
+        const int64_t m_tok = origin + (int64_t)(j >> 4) * p.W + (j & 15);      // this lane's token
+        const int64_t m_anc = cell0 + ((j & 15) >> 1);                          // its pooling cell
+        const char* rowp = xt + j * QR_XROW + 16 * half;
+        const char* row8 = xt + 2 * QS_XT + j * QS_X8ROW + 32 * half;
+        QS_T(c1);
+        QS_ADD(0, c1 - c0);
+        if (single_first) {
+            do_single(rowp, row8, m_tok, m_anc);
+            do_pair(rowp, row8, m_tok, m_anc);
+        } else {
+            do_pair(rowp, row8, m_tok, m_anc);
+            QS_T(c5);
+            QS_ADD(1, c5 - c1);     // the whole pair phase (regions 2, 3 = its two epilogues)
+            do_single(rowp, row8, m_tok, m_anc);
+            QS_T(c6);
+            QS_ADD(4, c6 - c5);
+        }
+    }
+#ifdef QS_DEBUG
+    if (lane == 0) for (int i = 0; i < 8; ++i) atomicAdd(&qs_dbg[8 * wave_u + i], qs_acc[i]);
+#endif
+}
+
+#ifdef QS_DEBUG
+extern "C" int grl_qs_debug(unsigned long long* out64, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out64, HIP_SYMBOL(qs_dbg), sizeof(unsigned long long) * 64);
+    if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(qs_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
+int launch_qs(const GrlQkvAnchorArgs& p, hipStream_t st) {
+    const int ntiles = p.B * (p.H >> 1) * (p.W >> 6);
+    const int grid = ntiles < 256 ? ntiles : 256;   // persistent workgroups, one per CU
+    hipError_t e = hipFuncSetAttribute((const void*)qkv_split_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, QS_LDS);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(qkv_split_kernel, dim3(grid), dim3(QR_W * 64), QS_LDS, st, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
 int64_t qa_chunk_bytes(int Cpad) {
     switch (Cpad / 16) {
         case 4: return QaShape<4>::BUFP;
@@ -449,6 +860,11 @@ extern "C" int64_t grl_qkv_anchor_blob_bytes(int32_t Cpad, int32_t nslots, int32
     return (int64_t)((nslots + nanc + 1) / 2) * cb;
 }
 
+extern "C" int64_t grl_qkv_anchor_lo_blob_bytes(int32_t Cpad, int32_t nsplit) {
+    if (Cpad != 192 || nsplit != QS_NLO) return GRL_ERR_UNSUPPORTED;
+    return 16 + (int64_t)QS_NLO * QS_LSLOT;
+}
+
 extern "C" int grl_qkv_anchor_fwd(void* stream, const GrlQkvAnchorArgs* args) {
     const GrlQkvAnchorArgs& p = *args;
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return 0;
@@ -458,6 +874,10 @@ extern "C" int grl_qkv_anchor_fwd(void* stream, const GrlQkvAnchorArgs* args) {
     if (p.x == nullptr || p.blob == nullptr || p.out == nullptr || ((uintptr_t)p.blob & 15) != 0 || p.out_plane_stride < M * 32) return GRL_ERR_BAD_ARG;
     if (p.nanc > 0 && (p.anc == nullptr || p.anc_plane_stride < M / 4 * 32)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (p.lo_blob != nullptr) {   // split-precision variant: GRL-Base shape with the q,q,q,k,k,k,v,v,v x 2 + 3 anchor slot order only
+        if (p.Cpad != 192 || p.nslots != 18 || p.nanc != 3 || ((uintptr_t)p.lo_blob & 15) != 0) return GRL_ERR_UNSUPPORTED;
+        return launch_qs(p, st);
+    }
     static const bool regs_off = getenv("GRL_QKV_REGS") && atoi(getenv("GRL_QKV_REGS")) == 0;
     if (p.Cpad == 192 && p.nslots + p.nanc == QR_SLOTS && !regs_off) return launch_qr(p, st);
     switch (p.Cpad / 16) {

@@ -430,6 +430,8 @@ class GRL(nn.Module):
             pk["anc_w3"] = ops.split3_weight(Wap)
         if not hi and CP in (64, 128, 192):   # q/k/v + 2x2-pooled anchors in one pass over x (csrc/qkv_anchor.hip)
             pk.update(qa_blob=ops.pack_qkv_anchor(Wp, bp, gs, Wap, bap, pk["anc_gs"]), qa_slots=(G, nh_s))
+            if hiq and CP == 192 and (nh_w, nh_s) == (3, 3):   # the same pass on split operands (qkv_split_kernel, round 4)
+                pk["qa_lo"] = ops.pack_qkv_anchor_lo(torch.cat([Wp, Wap]), torch.cat([gs, pk["anc_gs"]]))
 
         # --- output projection over the slotted attention output + norm1 ---
         Wo = a.proj.weight.detach().float()
@@ -645,10 +647,13 @@ class GRL(nn.Module):
             return self._block_high(r, pk, geo, B, H, W)
         # q/k/v, anchors and the anchor-side values live as head planes [slot][token][32]: a key tile of 32
         # consecutive tokens is 2 KB contiguous for the attention kernel's staging loads
-        if pk.get("hiq"):
+        one_pass = "qa_blob" in pk and df == 2 and H % 2 == 0 and W % 64 == 0 and os.environ.get("GRL_QKV_ANCHOR", "1") != "0"
+        if pk.get("hiq") and one_pass and "qa_lo" in pk and os.environ.get("GRL_QKV_SPLIT", "1") != "0":
+            qkv, anc = ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W, lo_blob=pk["qa_lo"])
+        elif pk.get("hiq"):
             qkv = ops.linear(r, pk["qkv_w3"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3)
             anc = ops.linear(r, pk["anc_w3"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True, a_split=3)
-        elif "qa_blob" in pk and df == 2 and H % 2 == 0 and W % 64 == 0 and os.environ.get("GRL_QKV_ANCHOR", "1") != "0":
+        elif one_pass:
             qkv, anc = ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W)
         else:
             if "qkv_blob" in pk and os.environ.get("GRL_STREAM_QKV", "1") != "0":

@@ -266,17 +266,52 @@ def pack_qkv_anchor(w: torch.Tensor, bias: torch.Tensor, gscale: torch.Tensor, w
     return blob.contiguous()
 
 
-def qkv_anchor(x: torch.Tensor, blob: torch.Tensor, nslots: int, nanc: int, B: int, H: int, W: int):
+def pack_qkv_anchor_lo(w: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
+    """`lo_blob` of grl_qkv_anchor_fwd's split-precision variant (layout in include/grl_hip.h) from the slotted weight matrix
+    w [(nslots + nanc)*32, Cpad] (fp32, q/k/v slots then anchor slots) and the slots' gscale: for every normalised slot
+    (gscale != 0) the fp16 rounding error of its weights, scaled by 2^(e+4), as e4m3.  The kernel also multiplies W_hi by 2^e
+    (its split slots accumulate at that scale), so e <= 8 is lowered until 2^e max|W| stays inside fp16 and the scaled
+    rounding errors inside e4m3."""
+    dev = w.device
+    N, Cpad = w.shape
+    ns = N // 32
+    assert N % 32 == 0 and gscale.numel() == ns
+    w = w.detach().float()
+    lo = (w - w.to(GEMM_DTYPE).float()).view(ns, 32, Cpad)[gscale.detach().float().cpu() != 0]
+    nsplit = lo.shape[0]
+    total = L.lib().grl_qkv_anchor_lo_blob_bytes(Cpad, nsplit)
+    assert total > 0, "split-precision QKV: GRL-Base slot layout only"
+    amax = float(lo.abs().max())
+    wmax = float(w.view(ns, 32, Cpad)[gscale.detach().float().cpu() != 0].abs().max())
+    e = 8
+    while e > -8 and (amax * 2.0 ** (e + 4) > 448.0 or wmax * 2.0 ** e > 30000.0):
+        e -= 1
+    lo8 = (lo * 2.0 ** (e + 4)).clamp_(-448.0, 448.0).to(torch.float8_e4m3fn)
+    blob = torch.zeros(total, dtype=torch.uint8, device=dev)
+    blob[:8] = torch.tensor([2.0 ** -e, 2.0 ** e], dtype=torch.float32).view(torch.uint8).to(dev)
+    # row image: the 64-channel block c as [lane half h][k-step u of the block][8 channels] (k = 64 c + 16 u + 8 h + t): the 32
+    # bytes a lane half feeds to one 32x32x64 fp8 MFMA are contiguous (csrc/qkv_anchor.hip, mfma64_fp8)
+    img = lo8.view(torch.uint8).view(nsplit, 32, Cpad // 64, 4, 2, 8).permute(0, 1, 2, 4, 3, 5).reshape(nsplit, 32, Cpad // 16, 16)
+    # ... and the 16-byte segment s of row j at position s ^ ((j >> 2) & 3): the rows carry no pad (LDS budget), the swizzle
+    # keeps the kernel's 16-byte reads of 16 consecutive rows on distinct banks
+    seg = torch.arange(Cpad // 16, device=dev).view(1, -1) ^ ((torch.arange(32, device=dev) >> 2) & 3).view(-1, 1)   # [row][physical] -> logical
+    img = torch.gather(img, 2, seg.view(1, 32, Cpad // 16, 1).expand(nsplit, 32, Cpad // 16, 16))
+    blob[16:].view(nsplit, 32, Cpad)[:] = img.reshape(nsplit, 32, Cpad)
+    return blob
+
+
+def qkv_anchor(x: torch.Tensor, blob: torch.Tensor, nslots: int, nanc: int, B: int, H: int, W: int, lo_blob: Optional[torch.Tensor] = None):
     """(q/k/v head planes [nslots, M, 32], anchor head planes [nanc, M/4, 32]) (fp16) of the token matrix x [B*H*W, Cpad]
-    (fp32): slotted, normalised QKV projection + 2x2-pooled anchor projection in one pass (grl_qkv_anchor_fwd)."""
-    _dev_check(x, blob)
+    (fp32): slotted, normalised QKV projection + 2x2-pooled anchor projection in one pass (grl_qkv_anchor_fwd).  With `lo_blob`
+    (pack_qkv_anchor_lo) the normalised slots are computed on split operands."""
+    _dev_check(x, blob, lo_blob)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and blob.dtype == torch.uint8 and blob.is_contiguous()
     M, Cpad = x.shape
     assert M == B * H * W and H % 2 == 0 and W % 64 == 0
     out = torch.empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
     anc = torch.empty(max(nanc, 1), M // 4, 32, dtype=PLANE_DTYPE, device=x.device)
     args = L.GrlQkvAnchorArgs(x=_ptr(x), ldx=x.stride(0), B=B, H=H, W=W, Cpad=Cpad, blob=_ptr(blob), nslots=nslots, nanc=nanc,
-                              out=_ptr(out), out_plane_stride=M * 32, anc=_ptr(anc), anc_plane_stride=(M // 4) * 32)
+                              out=_ptr(out), out_plane_stride=M * 32, anc=_ptr(anc), anc_plane_stride=(M // 4) * 32, lo_blob=_ptr(lo_blob))
     with _timed("qkv_anchor"):
         L.check(L.lib().grl_qkv_anchor_fwd(L.stream_ptr(), C.byref(args)), "grl_qkv_anchor_fwd")
     return out, (anc if nanc > 0 else None)

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 15
+#define GRL_ABI_VERSION 16
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -187,6 +187,18 @@ int64_t grl_qkv_blob_bytes(int32_t Cpad, int32_t nslots);
  * Weight stream `blob`: chunks of 2 slots, padded to 1 KiB; a slot = 32 rows x (2*Cpad + 16) bytes fp16 (row n = output column
  * n of the slot, K in natural order) | 32 fp32 bias | 1 fp32 gscale (+12 B); slots 0..nslots-1 = q/k/v, then nanc anchor slots.
  * gscale as in grl_qkv_fwd.
+ *
+ * Split-precision variant (round 4; `lo_blob` != NULL, GRL-Base shape only: Cpad 192, 18 + 3 slots, otherwise
+ * GRL_ERR_UNSUPPORTED): for the normalised slots (gscale != 0: q, k, anchors) the projection is evaluated as
+ *     W_hi . x_hi  +  W_hi . x_lo  +  2^-e W_lo8 . x_8,
+ * W_hi = fp16(W) from `blob`, x_hi = fp16(x), x_lo = fp16(x - x_hi), W_lo8 = e4m3((W - W_hi) 2^(e+4)), x_8 = e4m3(clamp(x_hi / 16, +-448)):
+ * the fp16 rounding of BOTH operands is carried (~2^-15 relative instead of 2^-11) at the cost of one more fp16 MFMA term on
+ * register-resident weights and one fp8 MFMA term whose weights live in LDS.  Needed for checkpoints whose logit scales sit
+ * near the clamp (exp(min(logit_scale, ln 100)), mixed_attn_block_efficient.py:39): the q.k logits multiply the operand
+ * rounding by up to 144.  `lo_blob`: float 2^-e | float 2^e | 8 pad bytes | one image per normalised slot in slot order,
+ * 32 rows x 192 e4m3 bytes: byte 64 c + 32 h + 8 u + t of row j = channel 64 c + 16 u + 8 h + t (the order in which one
+ * 32x32x64 fp8 MFMA consumes a lane half's 32 bytes), and the 16-byte segments of a row are stored XOR-swizzled, segment s
+ * at position s ^ ((j >> 2) & 3) (the image is copied to LDS verbatim).  Pass-through slots (gscale == 0: v) are not split.
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlQkvAnchorArgs {
     const float* x;            /* [B*H*W, ldx] fp32 tokens                                            */
@@ -199,10 +211,12 @@ typedef struct GrlQkvAnchorArgs {
     int64_t out_plane_stride;  /* >= B*H*W*32                                                         */
     void* anc;                 /* fp16 planes of the anchors: (a, slot, c) at slot*anc_plane_stride + a*32 + c (nanc > 0) */
     int64_t anc_plane_stride;  /* >= B*(H/2)*(W/2)*32                                                 */
+    const void* lo_blob;       /* NULL: fp16 operands; else the fp8 low parts of the normalised slots' weights (see above), 16-B aligned */
 } GrlQkvAnchorArgs;
 
 int grl_qkv_anchor_fwd(void* stream, const GrlQkvAnchorArgs* args);
 int64_t grl_qkv_anchor_blob_bytes(int32_t Cpad, int32_t nslots, int32_t nanc);
+int64_t grl_qkv_anchor_lo_blob_bytes(int32_t Cpad, int32_t nsplit);   /* nsplit = number of slots with gscale != 0 */
 
 /* ---------------------------------------------------------------------------------------------
  * Cosine window / anchored-stripe attention (one call = one softmax(QK^T)V over all windows).

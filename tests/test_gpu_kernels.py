@@ -263,6 +263,88 @@ def test_qkv_anchor_one_pass(B, H, W, C, nslots, nanc):
         assert (anc.float() - old_a.float()).abs().max().item() < 4e-3   # (the old kernel rounds the POOLED token to fp16)
 
 
+@pytest.mark.parametrize("B,H,W", [(2, 4, 64), (1, 6, 128), (1, 66, 64)])
+def test_qkv_anchor_split_precision(B, H, W):
+    """grl_qkv_anchor_fwd with lo_blob (round 4): W_hi.x_hi + W_hi.x_lo + 2^-e W_lo8.x_8 for the normalised slots of the GRL-Base
+    layout.  (1) The kernel computes exactly that expression (fp64 emulation of every rounding point, one fp16 ulp of output
+    rounding allowed); (2) the expression is ~2^-15 away from the exact product where plain fp16 operands are 2^-11.5 away;
+    (3) the kernel's planes are measurably closer to the exact ones than the unsplit kernel's."""
+    from grl_image_restoration_amd import ops
+
+    C, CP, nslots, nanc = 180, 192, 18, 3
+    M = B * H * W
+    g = torch.Generator().manual_seed(77)
+    x = torch.zeros(M, CP)
+    x[:, :C] = torch.randn(M, C, generator=g) * 1.5
+    x[5, 7], x[9, 100], x[M - 1, 3] = 60.0, -400.0, 9000.0     # residual-stream outliers (9000 / 16 is clamped to the e4m3 maximum)
+    w = torch.zeros((nslots + nanc) * 32, CP)
+    w[:, :C] = torch.randn((nslots + nanc) * 32, C, generator=g) * 0.05
+    w.view(-1, 32, CP)[:, 30:, :] = 0                             # head_dim 30
+    w[40, 11] = 1.3                                               # one large weight: its rounding error sets the exponent e
+    b = 0.1 * torch.randn((nslots + nanc) * 32, generator=g)
+    b.view(-1, 32)[:, 30:] = 0
+    gs = torch.zeros(nslots + nanc)
+    for base in (0, 9):
+        gs[base : base + 3] = torch.tensor([144.27, 30.0, 1.4427])   # q: logit scale x log2(e)
+        gs[base + 3 : base + 6] = -1.0 if base == 0 else -100.0      # k (column 31 := 1.0)
+        b.view(-1, 32)[base + 6 : base + 9, 30] = 1.0                # v: constant-1 column
+    gs[nslots:] = -1.0
+    d = _dev()
+    blob = ops.pack_qkv_anchor(w[: nslots * 32].to(d), b[: nslots * 32].to(d), gs[:nslots].to(d), w[nslots * 32 :].to(d), b[nslots * 32 :].to(d),
+                               gs[nslots:].to(d))
+    lo_blob = ops.pack_qkv_anchor_lo(w.to(d), gs.to(d))
+    inv_e, two_e = lo_blob[:8].cpu().view(torch.float32).tolist()
+    assert inv_e * two_e == 1.0 and two_e <= 2.0 ** 8
+    out, anc = ops.qkv_anchor(x.to(d), blob, nslots, nanc, B, H, W, lo_blob=lo_blob)
+    out0, anc0 = ops.qkv_anchor(x.to(d), blob, nslots, nanc, B, H, W)
+    torch.cuda.synchronize()
+    out, anc, out0, anc0 = out.cpu(), anc.cpu(), out0.cpu(), anc0.cpu()
+    assert torch.isfinite(out.float()).all() and torch.isfinite(anc.float()).all()
+
+    f8 = lambda t: t.to(torch.float8_e4m3fn).double()
+    xh = x.to(torch.float16)
+    xl = (x - xh.float()).to(torch.float16).double()
+    x8 = f8((xh.float() / 16.0).clamp(-448.0, 448.0))
+    wh = w.to(torch.float16)
+    wl8 = f8(((w - wh.float()) * (two_e * 16.0)).clamp(-448.0, 448.0))
+    xh, wh = xh.double(), wh.double()
+    split = (gs != 0).repeat_interleave(32)
+    y_plain = xh @ wh.t() + b.double()
+    y_emul = y_plain + (xl @ wh.t() + (x8 @ wl8.t()) * inv_e) * split.double()
+    y_exact = x.double() @ w.double().t() + b.double()
+
+    def planes(y):
+        q = _groupnorm_ref(y[:, : nslots * 32].reshape(M, nslots, 32), gs[:nslots]).permute(1, 0, 2)
+        ya = y[:, nslots * 32 :].reshape(B, H, W, nanc * 32)
+        pooled = F.avg_pool2d(ya.permute(0, 3, 1, 2), 2, 2).permute(0, 2, 3, 1).reshape(-1, nanc, 32)
+        return q, _groupnorm_ref(pooled, gs[nslots:]).permute(1, 0, 2)
+
+    q_em, a_em = planes(y_emul)
+    q_ex, a_ex = planes(y_exact)
+    q_pl, a_pl = planes(y_plain)
+    # (1) the kernel is the emulated expression (+ fp32 accumulation order, + one fp16 output rounding)
+    for name, got, ref in (("planes", out, q_em), ("anchors", anc, a_em)):
+        gmax = (gs[:nslots] if name == "planes" else gs[nslots:]).abs().clamp_min(1.0).view(-1, 1, 1).double()
+        tol = 6e-4 * ref.abs() + 1e-6 * gmax          # one fp16 output rounding + fp32 accumulation noise relative to the slot's norm
+        bad = ((got.double() - ref).abs() > tol)
+        if bad.any():
+            i = tuple(int(v) for v in bad.nonzero()[0])
+            raise AssertionError(f"{name}: {int(bad.sum())} elements off, first {i}: got {float(got[i])} expected {float(ref[i])}")
+    assert (out[3:6, :, 31] == 1.0).all() and (out[12:15, :, 31] == 1.0).all() and (anc[:, :, 31] == 1.0).all()
+    # (2) the expression itself, before output rounding: relative rms error of the normalised slots against the exact product
+    nz = gs[:nslots] != 0
+    rel = lambda a, bb: float(((a - bb)[nz][..., :30].pow(2).mean() / bb[nz][..., :30].pow(2).mean()).sqrt())
+    r_em, r_pl = rel(q_em, q_ex), rel(q_pl, q_ex)
+    assert r_em < 3e-5 and r_pl > 5 * r_em, (r_em, r_pl)
+    # (3) the kernel outputs: the split planes are closer to the exact ones (unit-norm k slots: output rounding is the same in both)
+    ks = [3, 4, 5]
+    e1 = float((out[ks].double() - q_ex[ks])[..., :30].pow(2).mean().sqrt())
+    e0 = float((out0[ks].double() - q_ex[ks])[..., :30].pow(2).mean().sqrt())
+    assert e1 < 0.9 * e0, (e1, e0)
+    # pass-through slots are untouched by the split
+    assert torch.equal(out[6:9], out0[6:9]) and torch.equal(out[15:18], out0[15:18])
+
+
 def test_linear_pooled_anchor():
     """AnchorLinear: avg-pool df x df (mixed_attn_block.py:727-736) fused into the A load."""
     from grl_image_restoration_amd import _lib as L, ops

@@ -70,6 +70,8 @@ def main():
     kernels = {
         "qkv_anchor": (lambda: ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W), (6 * L_ * C * C + L_ * C * C // 2) * B,
                        M * (CP * 4 + 18 * 32 * 2 + 3 * 32 * 2 // 4)),
+        "qkv_split": (lambda: ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W, lo_blob=pk["qa_lo"]),
+                      (6 * L_ * C * C + L_ * C * C // 2) * B, M * (CP * 4 + 18 * 32 * 2 + 3 * 32 * 2 // 4)),   # needs --logit-scale > 50
         "qkv_stream": (lambda: ops.qkv(r, pk["qkv_blob"], pk["qkv_slots"], out=qkv), 6 * L_ * C * C * B, M * (CP * 4 + 18 * 32 * 2)),
         "qkv": (lambda: ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], out=qkv, planes=True),
                 6 * L_ * C * C * B, M * (CP * 4 + 576 * 2)),
@@ -107,6 +109,8 @@ def main():
     print(f"{'kernel':14s} {'us':>9s} {'GFLOP':>9s} {'TFLOP/s':>9s} {'MB':>9s} {'GB/s':>9s}")
     for name, (fn, flops, byts) in kernels.items():
         if only and name not in only:
+            continue
+        if name == "qkv_split" and "qa_lo" not in pk:
             continue
         for _ in range(2):
             fn()

@@ -7,8 +7,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from grl_image_restoration_amd import GRL, baseline_config, ops
 
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 4
+import math
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+B = int(args[0]) if args else 4
 m = GRL(**baseline_config(3)).eval().cuda()
+if "--trained" in sys.argv:   # logit scales around the clamp, the draw of bench.py's trained_scales leg
+    gs = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for n, p_ in m.named_parameters():
+            if n.endswith("logit_scale"):
+                p_.copy_((math.log(100.0) + 0.3 * torch.randn(p_.shape, generator=gs)).cuda())
 x = torch.rand(B, 3, 256, 256, device="cuda")
 with torch.no_grad():
     for _ in range(2):
