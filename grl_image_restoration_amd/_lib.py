@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 16
+ABI_VERSION = 17
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -21,6 +21,7 @@ EXPORTS = [
     "grl_mlp_blob_bytes",
     "grl_block_tail_fwd",
     "grl_proj_blob_bytes",
+    "grl_tail_regs_blob_bytes",
     "grl_qkv_fwd",
     "grl_qkv_blob_bytes",
     "grl_qkv_anchor_fwd",
@@ -136,6 +137,7 @@ class GrlTailArgs(_Strict):
         ("res_scale", C.c_float),
         ("out", C.c_void_p),
         ("ldo", C.c_int64),
+        ("rblob", C.c_void_p),
     ]
 
 
@@ -380,6 +382,8 @@ def lib():
     L.grl_block_tail_fwd.restype = C.c_int
     L.grl_proj_blob_bytes.argtypes = [C.c_int32]
     L.grl_proj_blob_bytes.restype = C.c_int64
+    L.grl_tail_regs_blob_bytes.argtypes = []
+    L.grl_tail_regs_blob_bytes.restype = C.c_int64
     L.grl_qkv_fwd.argtypes = [C.c_void_p, C.POINTER(GrlQkvArgs)]
     L.grl_qkv_fwd.restype = C.c_int
     L.grl_qkv_blob_bytes.argtypes = [C.c_int32, C.c_int32]

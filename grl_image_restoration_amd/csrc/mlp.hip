@@ -473,7 +473,7 @@ extern "C" int64_t grl_proj_blob_bytes(int32_t Cpad) {
     return (int64_t)(Cpad / 32) * proj_chunk_bytes(Cpad);
 }
 
-// csrc/tail_regs.hip: DRAFT of the weights-stationary tail, never run on hardware yet; only with GRL_TAIL_REGS=1
+// csrc/tail_regs.hip: the register-resident kernel for the GRL-Base shape (GrlTailArgs.rblob)
 int grl_tail_regs_launch(const GrlTailArgs& a, hipStream_t st);
 
 extern "C" int grl_block_tail_fwd(void* stream, const GrlTailArgs* args) {
@@ -484,8 +484,7 @@ extern "C" int grl_block_tail_fwd(void* stream, const GrlTailArgs* args) {
         (a.ldatt % 8) || a.ldatt < a.Cpad || (a.ldcab % 4) || a.ldcab < a.Cpad || a.pb == nullptr || a.n1_g == nullptr || a.n1_b == nullptr)
         return GRL_ERR_BAD_ARG;
     if (a.rows_per_image < 128) return GRL_ERR_UNSUPPORTED;   // a 128-token tile may touch at most two images
-    static const bool regs_draft = getenv("GRL_TAIL_REGS") && atoi(getenv("GRL_TAIL_REGS")) == 1;
-    if (regs_draft) {
+    if (a.rblob != nullptr) {
         const int rc = grl_tail_regs_launch(a, (hipStream_t)stream);
         if (rc != GRL_ERR_UNSUPPORTED) return rc;
     }

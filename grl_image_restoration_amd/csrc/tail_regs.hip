@@ -1,261 +1,394 @@
-// Block tail with the MLP weights stationary in registers (gfx950) -- DRAFT, NOT YET RUN ON HARDWARE.
+// Block tail with ALL weights stationary in registers (gfx950, round 4): the GRL-Base path of grl_block_tail_fwd.
 //
-// Status: written at the end of round 3 with no GPU minutes left.  It compiles (registers / LDS within budget, see
-// profiles/r03_kernel_resources.txt) but has never executed; it is reachable only through GRL_TAIL_REGS=1, is not part of any
-// parity or performance claim, and its test (tests/test_gpu_kernels.py::test_block_tail_regs_draft) is skipped unless that
-// variable is set.  First job of the next round: run that test, then time it against mlp_kernel<6,8,true> (257 us per 4 tiles).
+//     r1  = x + res_scale * LayerNorm1(att . Wp^T + bp) + cab * gate[image]
+//     out = r1 + res_scale * LayerNorm2(fc2(GELU(fc1(r1))))
+// (MixedAttention.proj + norm1 + residual + CAB gate + Mlp + norm2 + residual: mixed_attn_block_efficient.py:379,543-556,
+// swin_v1_block.py:37-43; contract in include/grl_hip.h.)  Shape: Cpad 192, Hpad 384, M and rows_per_image multiples of 32;
+// weights from GrlTailArgs.rblob (ops.pack_tail_regs).
 //
-// Same contract as grl_block_tail_fwd (include/grl_hip.h; MixedAttention.proj + norm1 + residual + CAB gate + Mlp + norm2 +
-// residual, mixed_attn_block_efficient.py:379,543-556, swin_v1_block.py:37-43), GRL-Base shape only (Cpad 192, Hpad 384,
-// M and rows_per_image multiples of 32), and the SAME weight blobs (ops.pack_proj / ops.pack_mlp): nothing new to pack.
-//
-// Why: mlp_kernel streams the 366 KB of proj + fc1 + fc2 weights through LDS for every 128 tokens (18 chunk barriers per tile,
-// 2 waves per SIMD, each wave re-reading the whole stream for its 16 tokens) and has no single bottleneck left to remove
-// (DESIGN section 4).  The layout that worked for QKV and CAB conv2 this round: weights stationary, activations streaming.
-//   * 12 waves (3 per SIMD, <= 168 VGPRs).  Wave w owns hidden channels 32w .. 32w+31 of fc1 (= weight chunk w of the MLP blob:
-//     2 groups x 6 k-steps of A fragments, 48 VGPRs) and output channels 16w .. 16w+15 of fc2 (its rows of all 12 chunks:
-//     12 k-steps, 48 VGPRs) and of the projection (A fragments read from LDS, where the 78 KB projection stream stays);
-//   * a tile is 32 tokens.  Activations meet the weights as MFMA B operands read from LDS tiles: the attention output (LDS-DMA,
-//     double buffered, natural channel order like the projection weights), r1 and the hidden activations (written by their
-//     producers in the k-slot order of ops.pack_mlp, so a consumer's operand is one 16-B read);
-//   * a wave sees only 16 of a token's channels, so the two LayerNorms combine per-wave (mean, M2) pairs through LDS with
-//     Chan's formula -- one exchange per norm, no cancellation for rows with |mean| >> std;
-//   * 5 barriers per 32 tokens; x (residual), cab and the SE gate are read straight from global memory by the lanes that own
-//     the channels; out is written by the same lanes.
+// Why: mlp_kernel<6,8,true> streams the 366 KB of proj + fc1 + fc2 weights through LDS for every 128 tokens -- 18 chunk
+// barriers per tile, every wave re-reading the whole stream for its 16 tokens: 254 us per 4 tiles, 2.4 TB/s.  Counting
+// instructions (s_memtime probes, round 4) both that kernel and the first register-resident versions are bound by instruction
+// ISSUE (~4.8 cycles per instruction and SIMD): 231 wave-instructions per token for the streaming kernel, 506 for a 12-wave
+// 16x16x32 version (a lane = 4 channels of 2 tokens: everything per-token is repeated 48 times; correct, 376 us -- recorded
+// under tools/attn_asm/dead_ends/).  So the layout is chosen for FEW INSTRUCTIONS:
+//   * 32x32x16 MFMAs: a lane = 16 channels of ONE token -- per-token work (norm statistics, row addresses) once per lane pair,
+//     epilogues amortised over 16 values, half the B-operand LDS reads of 16x16x32;
+//   * 8 waves.  The 24 row tiles of the three matrices (6 x proj, 12 x fc1, 6 x fc2 with K = 384) are A fragments in registers:
+//     wave w < 6 holds proj tile w, fc1 tile w, fc2 tile w (48 + 48 + 96 VGPRs: the channels 32 w .. 32 w + 31 of r1 and out
+//     belong to ONE wave and one lane per token, so the fp32 r1 simply overwrites the lane's x values in the LDS tile until
+//     the output epilogue needs it); waves 6, 7 hold fc1 tiles 6..8 / 9..11 (144 VGPRs);
+//   * NO weights in LDS: it holds the activations of a 32-token tile -- att, x (fp32) and cab arrive by LDS-DMA, double
+//     buffered, requested one tile ahead and awaited just before a tile's output stores (stores and DMA loads share vmcnt:
+//     waiting at the tile top would sit out the write acknowledgements); r1 and the hidden activations (fp16) are written by
+//     their producers in the natural K order of the consumers' B fragments;
+//   * a wave sees 32 of a token's 192 channels: the LayerNorms combine per-wave (mean, M2) pairs through LDS (Chan);
+//   * 192 of 256 VGPRs hold weights.  Everything else is written to keep few values alive: lane-derived offsets are recomputed
+//     at the head of every phase from an opaque lane id, epilogues run four channels at a time between scheduling barriers,
+//     k loops are software-pipelined by hand one step deep (left alone the compiler alternates read and MFMA batches with
+//     lgkmcnt(0) in between, csrc/qkv_anchor.hip).
 #include "common.h"
 #include "grl_hip_internal.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int TR_T = 32, TR_W = 12, TR_THREADS = TR_W * 64;
-constexpr int TR_CP = 192, TR_HP = 384, TR_KS1 = TR_CP / 32, TR_KS2 = TR_HP / 32;
-constexpr int TR_AROW = TR_CP * 2 + 16;            // 400: fp16 row of the att / r1 tiles (and of the W1 / projection rows in the blobs)
+constexpr int TR_T = 32, TR_W = 8, TR_THREADS = TR_W * 64;
+constexpr int TR_CP = 192, TR_HP = 384, TR_KS1 = TR_CP / 16, TR_KS2 = TR_HP / 16;   // k-steps of 16
+constexpr int TR_AROW = TR_CP * 2 + 16;            // 400: fp16 row of the att / cab / r1 tiles (16 B pad: conflict-free ds_read_b128)
 constexpr int TR_HROW = TR_HP * 2 + 16;            // 784: fp16 row of the hidden tile
-constexpr int TR_W2ROW = 80;                       // blob: fc2 rows of one chunk (32 k-slots + pad)
-constexpr int TR_PCH = (32 * TR_AROW + 1023) / 1024 * 1024;                          // 13312: projection chunk image
-constexpr int TR_MCH = (32 * TR_AROW + TR_CP * TR_W2ROW + 128 + 1023) / 1024 * 1024; // 28672: MLP chunk image (MlpShape<6>::BUFP)
-constexpr int TR_ATT_SEG = TR_AROW / 16;           // 25 16-B segments per tile row (24 + pad)
-constexpr int TR_ATT_PIECES = (TR_T * TR_AROW + 1023) / 1024;                        // 13 DMA pieces per att tile
-constexpr int TR_OFF_PW = 0;
-constexpr int TR_OFF_ATT = TR_OFF_PW + TR_KS1 * TR_PCH;                              // 79872
-constexpr int TR_OFF_R1 = TR_OFF_ATT + 2 * TR_ATT_PIECES * 1024;                     // + 26624
-constexpr int TR_OFF_H = TR_OFF_R1 + TR_T * TR_AROW;                                 // + 12800
-constexpr int TR_OFF_ST = TR_OFF_H + TR_T * TR_HROW;                                 // + 25088
-constexpr int TR_OFF_VEC = TR_OFF_ST + 2 * TR_W * TR_T * 8;                          // + 6144
-constexpr int TR_VECF = 6 * TR_CP + TR_HP;                                           // pb n1g n1b b2 n2g n2b | b1
-constexpr int TR_LDS = TR_OFF_VEC + TR_VECF * 4;                                     // 156672
+constexpr int TR_XROW = TR_CP * 4 + 16;            // 784: fp32 row of the x tile
+constexpr int TR_ASEG = TR_AROW / 16, TR_XSEG = TR_XROW / 16;
+constexpr int TR_APIECES = (TR_T * TR_AROW + 1023) / 1024;   // 13 DMA pieces (1 KiB) per att / cab tile
+constexpr int TR_XPIECES = (TR_T * TR_XROW + 1023) / 1024;   // 25 per x tile
+constexpr int TR_ABUF = TR_APIECES * 1024, TR_XBUF = TR_XPIECES * 1024;
+constexpr int TR_OFF_ATT = 0;                                 // [2][TR_ABUF]
+constexpr int TR_OFF_CAB = TR_OFF_ATT + 2 * TR_ABUF;          // [2][TR_ABUF]
+constexpr int TR_OFF_X = TR_OFF_CAB + 2 * TR_ABUF;            // [2][TR_XBUF]
+constexpr int TR_OFF_R1 = TR_OFF_X + 2 * TR_XBUF;
+constexpr int TR_OFF_H = TR_OFF_R1 + TR_T * TR_AROW;
+constexpr int TR_OFF_ST = TR_OFF_H + TR_T * TR_HROW;          // [2 norms][6 waves][32 tokens] float2
+constexpr int TR_OFF_VEC = TR_OFF_ST + 2 * 6 * TR_T * 8;
+constexpr int TR_VECF = 7 * TR_CP + TR_HP;                    // pb n1g n1b b2 n2g n2b gate | b1
+constexpr int TR_LDS = TR_OFF_VEC + TR_VECF * 4;              // 152 KB
+constexpr int TR_FRAGS = 48;                                  // A fragments (1 KiB each) per wave in the blob
+static_assert(TR_LDS <= 160 * 1024, "LDS budget");
 
-// per-wave (mean, M2) of a token over this wave's real channels -> LDS; after the barrier every lane combines the 12 pairs
-__device__ __forceinline__ void ln_local(const float (&v)[4], int nreal_lane, float n_w, float& mean_w, float& m2_w) {
-    float s = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) s += i < nreal_lane ? v[i] : 0.f;
-    s = sum_halves(sum_rows16(s));                 // over the 4 lanes (g4) that hold this token's 16 channels
-    mean_w = s / n_w;
-    float q = 0.f;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float d = v[i] - mean_w;
-        q = i < nreal_lane ? fmaf(d, d, q) : q;
-    }
-    m2_w = sum_halves(sum_rows16(q));
+#ifdef TR_DEBUG   // timing probes (s_memtime ticks): [wave][region], summed over workgroups and tiles
+__device__ unsigned long long tr_dbg[64];
+#define TR_TIME(x) const long long x = __builtin_amdgcn_s_memtime()
+#define TR_ADD(i, v) tr_acc[i] += (unsigned long long)(v)
+#else
+#define TR_TIME(x)
+#define TR_ADD(i, v)
+#endif
+
+#define TR_SB() __builtin_amdgcn_sched_barrier(0)
+
+// The lane id, recomputed (2 VALU) at the head of every phase instead of living in a VGPR -- together with everything derived
+// from it -- across the whole tile loop (volatile asm: a builtin would be hoisted out of the loop again).
+__device__ __forceinline__ int tr_lane() {
+    int x;
+    asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(x));
+    return x;
 }
 
-__device__ __forceinline__ void ln_combine(const float* st, int token, int n_real, float eps, float& mean, float& rstd) {
-    // st: [TR_W][TR_T][2]; wave w contributes n_w = clamp(n_real - 16 w, 0, 16) channels
-    float sum = 0.f;
-#pragma unroll 4
-    for (int w = 0; w < TR_W; ++w) sum = fmaf((float)min(16, max(0, n_real - 16 * w)), st[(w * TR_T + token) * 2], sum);
-    mean = sum / (float)n_real;
-    float m2 = 0.f;
-#pragma unroll 4
-    for (int w = 0; w < TR_W; ++w) {        // (the means are read a second time: 12 registers are worth more than 12 LDS reads here)
-        const float2 e = *(const float2*)(st + (w * TR_T + token) * 2);
-        const float d = e.x - mean;
-        m2 += e.y + (float)min(16, max(0, n_real - 16 * w)) * d * d;
+__device__ __forceinline__ void tr_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // (LDS only: the DMA / store counters are handled where they matter)
+    __builtin_amdgcn_s_barrier();
+}
+
+// acc += W_tile . B^T over KS k-steps: A fragments in registers, B fragments (32 tokens x 16 channels) from the LDS tile whose
+// row `brow` (this lane's token, + 16 B for the upper half-wave) is given.  Pipelined by hand, see the file header.
+template <int KS>
+__device__ __forceinline__ void tr_gemm(const f16x8* A, const char* brow, f32x16& acc) {
+    f16x8 b0 = *(const f16x8*)brow, b1 = *(const f16x8*)(brow + 32);   // two steps ahead: one accumulator chain cannot hide an LDS round trip
+#pragma unroll
+    for (int s = 0; s < KS; ++s) {
+        f16x8 nb = b0;
+        if (s + 2 < KS) nb = *(const f16x8*)(brow + 32 * (s + 2));
+        TR_SB();
+        acc = mfma32_f16(A[s], b0, acc);
+        TR_SB();
+        b0 = b1; b1 = nb;
     }
-    rstd = rsqrtf(m2 / (float)n_real + eps);
+}
+
+// accumulator <- per-channel fp32 vector in LDS (this lane's channels c0 + 8 g + [0..3])
+__device__ __forceinline__ void tr_bias(f32x16& acc, const float* v, int c0) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const float4 t = *(const float4*)(v + c0 + 8 * g);
+        acc[4 * g] = t.x; acc[4 * g + 1] = t.y; acc[4 * g + 2] = t.z; acc[4 * g + 3] = t.w;
+    }
+}
+
+// per-wave (mean, M2) of this lane's token over the wave's real channels -> st_wave[token].  MASKED: the wave holds pad channels
+// (wave 5: channels 160 + ...; pad values are exact zeros, so only M2 needs the mask: bit r of realmask = register r is real)
+template <bool MASKED>
+__device__ __forceinline__ void tr_ln_local(const f32x16& v, uint32_t realmask, float inv_n, float2* st_wave, int j, int half) {
+    float s0 = (v[0] + v[1]) + (v[2] + v[3]), s1 = (v[4] + v[5]) + (v[6] + v[7]);
+    float s2 = (v[8] + v[9]) + (v[10] + v[11]), s3 = (v[12] + v[13]) + (v[14] + v[15]);
+    const float mean_w = sum_halves((s0 + s1) + (s2 + s3)) * inv_n;
+    float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+        const float d0 = v[r] - mean_w, d1 = v[r + 1] - mean_w;
+        if (!MASKED || ((realmask >> r) & 1)) q0 = fmaf(d0, d0, q0);
+        if (!MASKED || ((realmask >> (r + 1)) & 1)) q1 = fmaf(d1, d1, q1);
+    }
+    const float q = sum_halves(q0 + q1);
+    if (half == 0) st_wave[j] = float2{mean_w, q};
+}
+
+// Chan's combination of the six per-wave pairs of token j (waves 0..4 hold 32 real channels, wave 5 n5 = n_real - 160)
+__device__ __forceinline__ void tr_ln_combine(const float2* st, int j, float n5, float inv_n, float eps, float& mean, float& rstd) {
+    const float2 e0 = st[j], e1 = st[TR_T + j], e2 = st[2 * TR_T + j], e3 = st[3 * TR_T + j], e4 = st[4 * TR_T + j], e5 = st[5 * TR_T + j];
+    mean = (32.f * ((e0.x + e1.x) + (e2.x + e3.x) + e4.x) + n5 * e5.x) * inv_n;
+    const float d0 = e0.x - mean, d1 = e1.x - mean, d2 = e2.x - mean, d3 = e3.x - mean, d4 = e4.x - mean, d5 = e5.x - mean;
+    const float m2 = ((e0.y + e1.y) + (e2.y + e3.y) + (e4.y + e5.y)) + 32.f * ((d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3) + d4 * d4) + n5 * d5 * d5;
+    rstd = rsqrtf(m2 * inv_n + eps);
 }
 
 __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
     extern __shared__ __attribute__((aligned(1024))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int r16 = lane & 15, g4 = lane >> 4;
+#ifdef TR_DEBUG
+    unsigned long long tr_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+    const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const bool cw = wave < 6;                      // channel wave: proj / fc2 tile `wave`, fc1 tile `wave`; else fc1 tiles 6 + 3 (wave - 6) ..
     const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)smem;
-    const char* blob = (const char*)p.blob;
     const int ntiles = p.M / TR_T;
     if ((int)blockIdx.x >= ntiles) return;
 
-    // ---- once per launch: projection stream -> LDS (DMA), fc1 / fc2 A fragments -> registers, vectors -> LDS ----
-    for (int q = wave; q < TR_KS1 * (TR_PCH / 1024); q += TR_W) {
-        const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + TR_OFF_PW + q * 1024);
-        const char* g = (const char*)p.pblob + (size_t)q * 1024 + lane * 16;
-        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
-    }
-    gemm_x8 A1[2][TR_KS1], A2[TR_KS2];
+    // ---- once per launch: A fragments -> registers, vectors -> LDS ----
+    f16x8 Wt[TR_FRAGS];
     {
-        const char* c1 = blob + (size_t)wave * TR_MCH + r16 * TR_AROW + 16 * g4;       // chunk `wave`: rows = hidden 32 wave + ..
+        const char* src = (const char*)p.rblob + ((size_t)wave * TR_FRAGS) * 1024 + tr_lane() * 16;
 #pragma unroll
-        for (int ga = 0; ga < 2; ++ga)
-#pragma unroll
-            for (int s = 0; s < TR_KS1; ++s) A1[ga][s] = *(const gemm_x8*)(c1 + ga * 16 * TR_AROW + 64 * s);
-        const char* c2 = blob + 32 * TR_AROW + (16 * wave + r16) * TR_W2ROW + 16 * g4; // fc2 rows 16 wave + r16 of every chunk
-#pragma unroll
-        for (int j = 0; j < TR_KS2; ++j) A2[j] = *(const gemm_x8*)(c2 + (size_t)j * TR_MCH);
+        for (int f = 0; f < TR_FRAGS; ++f)
+            if (f < 36 || cw) Wt[f] = *(const f16x8*)(src + (size_t)f * 1024);
     }
     float* vec = (float*)(smem + TR_OFF_VEC);
-    for (int i = tid; i < 6 * TR_CP; i += TR_THREADS) {
-        const int k = i / TR_CP, c = i - k * TR_CP;
-        const float* src = k == 0 ? p.pb : k == 1 ? p.n1_g : k == 2 ? p.n1_b : k == 3 ? p.b2 : k == 4 ? p.n2_g : p.n2_b;
-        vec[i] = c < p.n_real ? src[c] : 0.f;      // pad channels: zero bias / affine, so they stay exactly 0 all the way
+    {
+        const int tid = 64 * wave + tr_lane();
+        for (int i = tid; i < 6 * TR_CP; i += TR_THREADS) {
+            const int k = i / TR_CP, c = i - k * TR_CP;
+            const float* src = k == 0 ? p.pb : k == 1 ? p.n1_g : k == 2 ? p.n1_b : k == 3 ? p.b2 : k == 4 ? p.n2_g : p.n2_b;
+            vec[i] = c < p.n_real ? src[c] : 0.f;  // pad channels: zero bias / affine, so they stay exactly 0 all the way
+        }
+        for (int i = tid; i < TR_HP; i += TR_THREADS)
+            vec[7 * TR_CP + i] = ((const float*)((const char*)p.rblob + (size_t)TR_W * TR_FRAGS * 1024))[i];
     }
-    for (int i = tid; i < TR_HP; i += TR_THREADS)
-        vec[6 * TR_CP + i] = *(const float*)(blob + (size_t)(i >> 5) * TR_MCH + 32 * TR_AROW + TR_CP * TR_W2ROW + 4 * (i & 31));
+    float* gate_l = vec + 6 * TR_CP;
+    int gate_img = -1;
 
-    // att tile DMA: piece q (1 KiB) = LDS bytes [1024 q, 1024 q + 1024) of the tile image [32 rows][25 segments]
-    auto fetch_att = [&](int tile, int buf) {
-        for (int q = wave; q < TR_ATT_PIECES; q += TR_W) {
-            const int idx = q * 64 + lane;
-            int row = idx / TR_ATT_SEG, seg = idx - row * TR_ATT_SEG;
-            seg = seg < TR_ATT_SEG - 1 ? seg : TR_ATT_SEG - 2;     // the pad segment repeats the last real one
-            row = row < TR_T ? row : TR_T - 1;
-            const char* g = (const char*)p.att + ((int64_t)tile * TR_T + row) * p.ldatt * 2 + seg * 16;
-            const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + TR_OFF_ATT + buf * (TR_ATT_PIECES * 1024) + q * 1024);
-            asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(m0v), "v"(g) : "m0", "memory");
+    // tile DMA: att and cab pieces are [32 rows][25 x 16 B] images (24 real segments + the pad, which repeats the last one),
+    // the x piece [32 rows][49 x 16 B]; 51 pieces of 1 KiB per tile, dealt round-robin over the waves.  Buffer loads: the tensor
+    // base sits in a descriptor, the tile in the scalar offset, and a lane's 32-bit offset inside the tile costs ~8 instructions
+    // (with flat 64-bit addresses a piece cost 25, i.e. ~300 cycles of a wave's issue time: 3 k cycles per tile).
+    typedef __attribute__((__vector_size__(4 * sizeof(uint32_t)))) uint32_t u32x4;
+    auto srd = [](const void* ptr) {   // raw buffer descriptor: base, stride 0, all of memory, gfx950 data format word
+        const uint64_t a = (uint64_t)ptr;
+        u32x4 r;
+        r[0] = __builtin_amdgcn_readfirstlane((uint32_t)a);
+        r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32) & 0xffffu);
+        r[2] = 0xffffffffu;
+        r[3] = 0x00020000u;
+        return r;
+    };
+    const u32x4 att_srd = srd(p.att), cab_srd = srd(p.cab), x_srd = srd(p.x);
+    const uint32_t att_rb = (uint32_t)p.ldatt * 2u, cab_rb = (uint32_t)p.ldcab * 2u, x_rb = (uint32_t)p.ldx * 4u;   // bytes per row
+    // s_nop 4: SGPR operands may come straight from SALU / readfirstlane (5 wait states before a VMEM instruction reads them)
+#define TR_DMA(m0v, voff, rsrc, soff) \
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 4\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(m0v), "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+    auto fetch = [&](int tile, int buf) {
+        const int lane = tr_lane();
+        for (int q0 = (wave + 2) & 7; q0 < 2 * TR_APIECES + TR_XPIECES; q0 += TR_W) {   // (wave-uniform)
+            if (q0 < 2 * TR_APIECES) {
+                const bool is_cab = q0 >= TR_APIECES;
+                const int q = is_cab ? q0 - TR_APIECES : q0;
+                const int idx = q * 64 + lane;
+                int row = idx / TR_ASEG, seg = idx - row * TR_ASEG;
+                seg = min(seg, TR_ASEG - 2);
+                row = min(row, TR_T - 1);
+                const uint32_t rb = is_cab ? cab_rb : att_rb;
+                const uint32_t voff = (uint32_t)row * rb + (uint32_t)seg * 16u;
+                const uint32_t m0v = __builtin_amdgcn_readfirstlane(lds0 + (is_cab ? TR_OFF_CAB : TR_OFF_ATT) + buf * TR_ABUF + q * 1024);
+                const uint32_t soff = __builtin_amdgcn_readfirstlane((uint32_t)tile * (TR_T * rb));
+                if (is_cab) TR_DMA(m0v, voff, cab_srd, soff);
+                else TR_DMA(m0v, voff, att_srd, soff);
+            } else {
+                const int q = q0 - 2 * TR_APIECES;
+                const int idx = q * 64 + lane;
+                int row = idx / TR_XSEG, seg = idx - row * TR_XSEG;
+                seg = min(seg, TR_XSEG - 2);
+                row = min(row, TR_T - 1);
+                const uint32_t voff = (uint32_t)row * x_rb + (uint32_t)seg * 16u;
+                TR_DMA(__builtin_amdgcn_readfirstlane(lds0 + TR_OFF_X + buf * TR_XBUF + q * 1024), voff, x_srd, __builtin_amdgcn_readfirstlane((uint32_t)tile * (TR_T * x_rb)));
+            }
         }
     };
-    fetch_att(blockIdx.x, 0);
+    fetch(blockIdx.x, 0);
 
-    const int nreal_lane = min(4, max(0, p.n_real - 16 * wave - 4 * g4));    // real channels among this lane's 4
-    const float n_w = (float)min(16, max(1, p.n_real - 16 * wave));
-    const int ch0 = 16 * wave + 4 * g4;                                        // this lane's first output channel (proj, fc2)
-    float* st1 = (float*)(smem + TR_OFF_ST);
-    float* st2 = st1 + TR_W * TR_T * 2;
-    // A fragment rows of the projection: chunk wave >> 1, rows 16 (wave & 1) + r16
-    const char* pw = smem + TR_OFF_PW + (wave >> 1) * TR_PCH + (16 * (wave & 1) + r16) * TR_AROW + 16 * g4;
-    // where this lane's 4 channels go in a k-slot-ordered row: slots 8 g4 + 4 (group parity) of the 32-block
-    const int r1_col = (32 * (wave >> 1) + 8 * g4 + 4 * (wave & 1)) * 2;
+    const float n5 = (float)(p.n_real - 160);
+    const float inv_n = 1.0f / (float)p.n_real, inv_nw = wave < 5 ? 1.0f / 32.f : 1.0f / n5;
+    float2* st1 = (float2*)(smem + TR_OFF_ST);
+    float2* st2 = st1 + 6 * TR_T;
+    // per phase: j = token (MFMA column), half = upper / lower half-wave; ch0 = this lane's first channel (accumulator register r
+    // <-> channel ch0 + (r & 3) + 8 (r >> 2))
+#define TR_LANE() const int ln_ = tr_lane(), j = ln_ & 31, half = ln_ >> 5, ch0 = 32 * wave + 4 * half; (void)j; (void)ch0
+    auto realmask_of = [&](int ch0) {
+        uint32_t m = 0;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) m |= (uint32_t)(ch0 + (r & 3) + 8 * (r >> 2) < p.n_real) << r;
+        return m;
+    };
 
     int it = 0;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // own DMA pieces of this tile (and, first tile, of the projection stream)
-        __syncthreads();                                   // B0
-        const int next = tile + (int)gridDim.x;
-        if (next < ntiles) fetch_att(next, (it + 1) & 1);
-        const char* att = smem + TR_OFF_ATT + (it & 1) * (TR_ATT_PIECES * 1024);
+        TR_TIME(t0);
+        const int buf = it & 1;
         const int64_t m0 = (int64_t)tile * TR_T;
         const int img = (int)(m0 / p.rows_per_image);
-        float4 xr[2];
-        uint2 cb[2];
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            const int64_t m = m0 + 16 * tg + r16;
-            xr[tg] = *(const float4*)(p.x + m * p.ldx + ch0);
-            cb[tg] = *(const uint2*)((const gemm_t*)p.cab + m * p.ldcab + ch0);
+        if (img != gate_img) {   // SE gate row of the image (changes once per rows_per_image / 32 tiles of this workgroup)
+            tr_barrier();
+            const int i = 64 * wave + tr_lane();
+            if (i < TR_CP) gate_l[i] = i < p.n_real ? p.gate[(int64_t)img * TR_CP + i] : 0.f;
+            gate_img = img;
         }
-        const float4 gt = *(const float4*)(p.gate + (int64_t)img * TR_CP + ch0);
-
-        // ---- P1: projection, norm1, residual, CAB ----
-        float v[2][4];
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            f32x4 acc = *(const f32x4*)(vec + ch0);        // projection bias
-            const char* brow = att + (16 * tg + r16) * TR_AROW + 16 * g4;
-#pragma unroll
-            for (int s = 0; s < TR_KS1; ++s)
-                acc = mfma16_gemm(*(const gemm_x8*)(pw + 64 * s), *(const gemm_x8*)(brow + 64 * s), acc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[tg][i] = acc[i];
-            float mw, m2;
-            ln_local(v[tg], nreal_lane, n_w, mw, m2);
-            if (g4 == 0) *(float2*)(st1 + (wave * TR_T + 16 * tg + r16) * 2) = float2{mw, m2};
-            __builtin_amdgcn_sched_barrier(0);   // (keeps the two token groups from being interleaved: the register budget is 168)
+        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first tile's DMA pieces (later ones: awaited before the stores)
+        tr_barrier();                                      // B0: tile `it` landed for everybody; the other buffers are free
+        TR_TIME(t1);
+        TR_ADD(0, t1 - t0);
+        const int next = tile + (int)gridDim.x;
+        if (next < ntiles) fetch(next, buf ^ 1);
+        f32x16 acc;
+        if (cw) {
+            // ---- P1: projection + per-wave norm statistics ----
+            TR_LANE();
+            tr_bias(acc, vec, ch0);
+            tr_gemm<TR_KS1>(Wt, smem + TR_OFF_ATT + buf * TR_ABUF + j * TR_AROW + 16 * half, acc);
+            if (wave < 5) tr_ln_local<false>(acc, 0, inv_nw, st1 + wave * TR_T, j, half);
+            else tr_ln_local<true>(acc, realmask_of(ch0), inv_nw, st1 + wave * TR_T, j, half);
         }
-        __syncthreads();                                   // B1
-        float r1[2][4];
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
+        TR_TIME(t2);
+        TR_ADD(1, t2 - t1);
+        tr_barrier();                                      // B1
+        if (cw) {
+            TR_LANE();
             float mean, rstd;
-            ln_combine(st1, 16 * tg + r16, p.n_real, p.ln_eps, mean, rstd);
-            const f32x4 g1 = *(const f32x4*)(vec + TR_CP + ch0), b1n = *(const f32x4*)(vec + 2 * TR_CP + ch0);
-            const float xs[4] = {xr[tg].x, xr[tg].y, xr[tg].z, xr[tg].w};
-            const f16x2 c01 = __builtin_bit_cast(f16x2, cb[tg].x), c23 = __builtin_bit_cast(f16x2, cb[tg].y);
-            const float cs[4] = {(float)c01[0], (float)c01[1], (float)c23[0], (float)c23[1]};
-            const float gs[4] = {gt.x, gt.y, gt.z, gt.w};
+            tr_ln_combine(st1, j, n5, inv_n, p.ln_eps, mean, rstd);
+            rstd *= p.res_scale;
+            char* xrow = smem + TR_OFF_X + buf * TR_XBUF + j * TR_XROW + ch0 * 4;
+            const char* crow = smem + TR_OFF_CAB + buf * TR_ABUF + j * TR_AROW + ch0 * 2;
+            char* r1row = smem + TR_OFF_R1 + j * TR_AROW + ch0 * 2;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                r1[tg][i] = xs[i] + p.res_scale * ((v[tg][i] - mean) * rstd * g1[i] + b1n[i]) + cs[i] * gs[i];
-            uint2 o;
-            o.x = pack_f16(r1[tg][0], r1[tg][1]);
-            o.y = pack_f16(r1[tg][2], r1[tg][3]);
-            *(uint2*)(smem + TR_OFF_R1 + (16 * tg + r16) * TR_AROW + r1_col) = o;
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        __syncthreads();                                   // B2
-
-        // ---- P2: fc1 + GELU -> hidden tile (k-slot order) ----
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            f32x4 h0 = *(const f32x4*)(vec + 6 * TR_CP + 32 * wave + 4 * g4);
-            f32x4 h1 = *(const f32x4*)(vec + 6 * TR_CP + 32 * wave + 16 + 4 * g4);
-            const char* brow = smem + TR_OFF_R1 + (16 * tg + r16) * TR_AROW + 16 * g4;
-#pragma unroll
-            for (int s = 0; s < TR_KS1; ++s) {
-                const gemm_x8 b = *(const gemm_x8*)(brow + 64 * s);
-                h0 = mfma16_gemm(A1[0][s], b, h0);
-                h1 = mfma16_gemm(A1[1][s], b, h1);
+            for (int g = 0; g < 4; ++g) {   // channels ch0 + 8 g + [0..3]
+                const float4 xs = *(const float4*)(xrow + 32 * g);
+                const uint2 cb = *(const uint2*)(crow + 16 * g);
+                const float4 g1 = *(const float4*)(vec + TR_CP + ch0 + 8 * g), b1n = *(const float4*)(vec + 2 * TR_CP + ch0 + 8 * g);
+                const float4 gt = *(const float4*)(gate_l + ch0 + 8 * g);
+                const f16x2 c01 = __builtin_bit_cast(f16x2, cb.x), c23 = __builtin_bit_cast(f16x2, cb.y);
+                float4 r1;   // x + res_scale ((v - mean) rstd g + b) + cab gate
+                r1.x = fmaf((float)c01[0], gt.x, fmaf(p.res_scale, b1n.x, fmaf((acc[4 * g] - mean) * rstd, g1.x, xs.x)));
+                r1.y = fmaf((float)c01[1], gt.y, fmaf(p.res_scale, b1n.y, fmaf((acc[4 * g + 1] - mean) * rstd, g1.y, xs.y)));
+                r1.z = fmaf((float)c23[0], gt.z, fmaf(p.res_scale, b1n.z, fmaf((acc[4 * g + 2] - mean) * rstd, g1.z, xs.z)));
+                r1.w = fmaf((float)c23[1], gt.w, fmaf(p.res_scale, b1n.w, fmaf((acc[4 * g + 3] - mean) * rstd, g1.w, xs.w)));
+                *(float4*)(xrow + 32 * g) = r1;              // fp32 r1 in place of x (this lane's own 16 bytes), for the output epilogue
+                uint2 o;
+                o.x = pack_f16(r1.x, r1.y);
+                o.y = pack_f16(r1.z, r1.w);
+                *(uint2*)(r1row + 16 * g) = o;
+                TR_SB();   // (bounds the live range of the per-channel vectors: the register budget is 256 - 192)
             }
-            const f32x2v a01 = gelu_erf2(f32x2v{h0[0], h0[1]}), a23 = gelu_erf2(f32x2v{h0[2], h0[3]});
-            const f32x2v b01 = gelu_erf2(f32x2v{h1[0], h1[1]}), b23 = gelu_erf2(f32x2v{h1[2], h1[3]});
-            uint4 o;   // slots 8 g4 + [0..3] = group 0's channels 4 g4 + i, slots 8 g4 + [4..7] = group 1's (hidden 16 + 4 g4 + i)
-            o.x = pack_f16(a01[0], a01[1]);
-            o.y = pack_f16(a23[0], a23[1]);
-            o.z = pack_f16(b01[0], b01[1]);
-            o.w = pack_f16(b23[0], b23[1]);
-            *(uint4*)(smem + TR_OFF_H + (16 * tg + r16) * TR_HROW + (32 * wave + 8 * g4) * 2) = o;
-            __builtin_amdgcn_sched_barrier(0);
         }
-        __syncthreads();                                   // B3
-
-        // ---- P3: fc2, norm2, residual ----
+        TR_TIME(t3);
+        TR_ADD(2, t3 - t2);
+        tr_barrier();                                      // B2: r1 tile complete
+        // ---- P2: fc1 + GELU -> hidden tile ----
+        {
+            TR_LANE();
+            const char* rb = smem + TR_OFF_R1 + j * TR_AROW + 16 * half;
+            auto fc1_tile = [&](const f16x8* A, int ht) {  // hidden channels 32 ht ..
+                f32x16 h;
+                tr_bias(h, vec + 7 * TR_CP, 32 * ht + 4 * half);
+                tr_gemm<TR_KS1>(A, rb, h);
+                char* hr = smem + TR_OFF_H + j * TR_HROW + (32 * ht + 4 * half) * 2;
 #pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
-            f32x4 acc = *(const f32x4*)(vec + 3 * TR_CP + ch0);   // fc2 bias
-            const char* brow = smem + TR_OFF_H + (16 * tg + r16) * TR_HROW + 16 * g4;
-#pragma unroll
-            for (int j = 0; j < TR_KS2; ++j) acc = mfma16_gemm(A2[j], *(const gemm_x8*)(brow + 64 * j), acc);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) v[tg][i] = acc[i];
-            float mw, m2;
-            ln_local(v[tg], nreal_lane, n_w, mw, m2);
-            if (g4 == 0) *(float2*)(st2 + (wave * TR_T + 16 * tg + r16) * 2) = float2{mw, m2};
-            __builtin_amdgcn_sched_barrier(0);
+                for (int g = 0; g < 4; ++g) {
+                    const f32x2v a = gelu_erf2(f32x2v{h[4 * g], h[4 * g + 1]}), b = gelu_erf2(f32x2v{h[4 * g + 2], h[4 * g + 3]});
+                    uint2 o;
+                    o.x = pack_f16(a[0], a[1]);
+                    o.y = pack_f16(b[0], b[1]);
+                    *(uint2*)(hr + 16 * g) = o;
+                    TR_SB();   // (one group of four at a time: interleaving all sixteen GELUs costs ~40 registers)
+                }
+            };
+            // The fc1-only waves have three tiles where the channel waves have one: a barrier after the first lets the channel
+            // waves start fc2 on the hidden channels they produced themselves (k-steps 0..11 = hidden 0..191) meanwhile.
+            if (cw) {
+                fc1_tile(Wt + 12, wave);
+                TR_TIME(t4);
+                TR_ADD(3, t4 - t3);
+                tr_barrier();                              // B3a: hidden channels 0..191 (+ 192.., 288.. of waves 6, 7) complete
+                // ---- P3: fc2 + per-wave norm statistics ----
+                tr_bias(acc, vec + 3 * TR_CP, ch0);
+                const char* hb = smem + TR_OFF_H + j * TR_HROW + 16 * half;
+                tr_gemm<TR_KS2 / 2>(Wt + 24, hb, acc);
+                TR_TIME(t4b);
+                TR_ADD(7, t4b - t4);
+                tr_barrier();                              // B3b: hidden tile complete
+                tr_gemm<TR_KS2 / 2>(Wt + 36, hb + 32 * (TR_KS2 / 2), acc);
+                if (wave < 5) tr_ln_local<false>(acc, 0, inv_nw, st2 + wave * TR_T, j, half);
+                else tr_ln_local<true>(acc, realmask_of(ch0), inv_nw, st2 + wave * TR_T, j, half);
+            } else {
+                const int t0h = 6 + 3 * (wave - 6);
+                fc1_tile(Wt, t0h);
+                TR_TIME(t4);
+                TR_ADD(3, t4 - t3);
+                tr_barrier();                              // B3a
+                fc1_tile(Wt + 12, t0h + 1);
+                TR_SB();
+                fc1_tile(Wt + 24, t0h + 2);
+                TR_TIME(t4b);
+                TR_ADD(7, t4b - t4);
+                tr_barrier();                              // B3b
+            }
         }
-        __syncthreads();                                   // B4
-#pragma unroll
-        for (int tg = 0; tg < 2; ++tg) {
+        TR_TIME(t5);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (a whole tile old); nothing else is pending yet
+        tr_barrier();                                      // B4
+        TR_TIME(t6);
+        TR_ADD(5, t6 - t5);
+        if (cw) {
+            TR_LANE();
             float mean, rstd;
-            ln_combine(st2, 16 * tg + r16, p.n_real, p.ln_eps, mean, rstd);
-            const f32x4 g2 = *(const f32x4*)(vec + 4 * TR_CP + ch0), b2n = *(const f32x4*)(vec + 5 * TR_CP + ch0);
-            float4 o;
-            o.x = r1[tg][0] + p.res_scale * ((v[tg][0] - mean) * rstd * g2[0] + b2n[0]);
-            o.y = r1[tg][1] + p.res_scale * ((v[tg][1] - mean) * rstd * g2[1] + b2n[1]);
-            o.z = r1[tg][2] + p.res_scale * ((v[tg][2] - mean) * rstd * g2[2] + b2n[2]);
-            o.w = r1[tg][3] + p.res_scale * ((v[tg][3] - mean) * rstd * g2[3] + b2n[3]);
-            *(float4*)(p.out + (m0 + 16 * tg + r16) * p.ldo + ch0) = o;
+            tr_ln_combine(st2, j, n5, inv_n, p.ln_eps, mean, rstd);
+            rstd *= p.res_scale;
+            float* orow = p.out + (m0 + j) * p.ldo + ch0;
+            const char* xrow = smem + TR_OFF_X + buf * TR_XBUF + j * TR_XROW + ch0 * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 g2 = *(const float4*)(vec + 4 * TR_CP + ch0 + 8 * g), b2n = *(const float4*)(vec + 5 * TR_CP + ch0 + 8 * g);
+                const float4 r1 = *(const float4*)(xrow + 32 * g);
+                float4 o;   // r1 + res_scale ((v - mean) rstd g + b)
+                o.x = fmaf(p.res_scale, b2n.x, fmaf((acc[4 * g] - mean) * rstd, g2.x, r1.x));
+                o.y = fmaf(p.res_scale, b2n.y, fmaf((acc[4 * g + 1] - mean) * rstd, g2.y, r1.y));
+                o.z = fmaf(p.res_scale, b2n.z, fmaf((acc[4 * g + 2] - mean) * rstd, g2.z, r1.z));
+                o.w = fmaf(p.res_scale, b2n.w, fmaf((acc[4 * g + 3] - mean) * rstd, g2.w, r1.w));
+                *(float4*)(orow + 8 * g) = o;
+                TR_SB();
+            }
         }
+        TR_TIME(t7);
+        TR_ADD(6, t7 - t6);
     }
+#ifdef TR_DEBUG
+    if (tr_lane() == 0) for (int i = 0; i < 8; ++i) atomicAdd(&tr_dbg[8 * wave + i], tr_acc[i]);
+#endif
 }
 
 }  // namespace
 
-// draft path of grl_block_tail_fwd (GRL_TAIL_REGS=1); GRL_ERR_UNSUPPORTED for every other shape
+#ifdef TR_DEBUG
+extern "C" int grl_tr_debug(unsigned long long* out64, int reset) {
+    hipDeviceSynchronize();
+    hipMemcpyFromSymbol(out64, HIP_SYMBOL(tr_dbg), sizeof(unsigned long long) * 64);
+    if (reset) { unsigned long long z[64] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(tr_dbg), z, sizeof(z)); }
+    return 0;
+}
+#endif
+
+extern "C" int64_t grl_tail_regs_blob_bytes(void) { return (int64_t)TR_W * TR_FRAGS * 1024 + TR_HP * 4; }
+
+// register-resident path of grl_block_tail_fwd; GRL_ERR_UNSUPPORTED for every other shape (the caller falls back to the streaming kernel)
 int grl_tail_regs_launch(const GrlTailArgs& a, hipStream_t st) {
-    if (a.Cpad != TR_CP || a.Hpad != TR_HP || (a.M % TR_T) || a.M <= 0 || (a.rows_per_image % TR_T) || a.n_real <= TR_CP - 16 ||
-        a.n_real > TR_CP || (a.ldatt % 8) || (a.ldcab % 4) || (a.ldx % 4) || (a.ldo % 4))
+    if (a.rblob == nullptr || a.Cpad != TR_CP || a.Hpad != TR_HP || (a.M % TR_T) || a.M <= 0 || (a.rows_per_image % TR_T) || a.n_real <= 160 ||
+        a.n_real > TR_CP || (a.ldatt % 8) || (a.ldcab % 8) || (a.ldx % 4) || (a.ldo % 4) || ((uintptr_t)a.rblob & 15))
         return GRL_ERR_UNSUPPORTED;
+    const int64_t rowb = a.ldx * 4 > a.ldatt * 2 ? (a.ldx * 4 > a.ldcab * 2 ? a.ldx * 4 : a.ldcab * 2) : (a.ldatt * 2 > a.ldcab * 2 ? a.ldatt * 2 : a.ldcab * 2);
+    if ((int64_t)a.M * rowb >= (1ll << 32)) return GRL_ERR_UNSUPPORTED;   // the tile DMA addresses rows by 32-bit buffer offsets
     const int ntiles = a.M / TR_T;
     const int grid = ntiles < 256 ? ntiles : 256;
     hipError_t e = hipFuncSetAttribute((const void*)tail_regs_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TR_LDS);

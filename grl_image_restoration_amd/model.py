@@ -462,6 +462,10 @@ class GRL(nn.Module):
                   fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
         if not hi and CP in (64, 128, 192) and KA == CP and self.local_connection:   # + proj/norm1/CAB in front: one kernel per block tail
             pk["proj_blob"] = ops.pack_proj(Wop)
+            # weights stationary in registers (csrc/tail_regs.hip, round 4): correct and tested, but measured at parity with the
+            # streaming kernel (296 vs 293 us per 4 tiles) -- opt-in until it is faster
+            if CP == 192 and HP == 384 and C > 160 and os.environ.get("GRL_TAIL_REGS", "0") == "1":
+                pk["tail_rblob"] = ops.pack_tail_regs(Wop, blk.mlp.fc1.weight.to(dev), blk.mlp.fc1.bias.to(dev), blk.mlp.fc2.weight.to(dev))
         if not hi and CP in (64, 128, 192):  # fused fc1 -> GELU -> fc2 -> norm2 -> residual kernel (csrc/mlp.hip)
             pk.update(mlp_blob=ops.pack_mlp(blk.mlp.fc1.weight.to(dev), blk.mlp.fc1.bias.to(dev), blk.mlp.fc2.weight.to(dev), CP, HP),
                       mlp_hp=HP)
@@ -666,7 +670,8 @@ class GRL(nn.Module):
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         if "proj_blob" in pk and "mlp_blob" in pk and H * W >= 128 and os.environ.get("GRL_FUSED_TAIL", "1") != "0":
             return ops.block_tail(att, r, cab, gate, H * W, pk["proj_blob"], pk["proj_b"], pk["n1_g"], pk["n1_b"], pk["mlp_blob"],
-                                  pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C, res_scale=self.res_scale)
+                                  pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C, res_scale=self.res_scale,
+                                  rblob=pk.get("tail_rblob"))
         # x = x + res_scale * norm1(proj(attn)) + cab(x)   (efficient.py:543-548)
         r1 = ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=pk["n1_g"],
                         ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab, add2_scale=gate,

@@ -332,12 +332,46 @@ def pack_proj(w: torch.Tensor) -> torch.Tensor:
     return blob.contiguous()
 
 
+def pack_tail_regs(proj_w: torch.Tensor, fc1_w: torch.Tensor, fc1_b: torch.Tensor, fc2_w: torch.Tensor) -> torch.Tensor:
+    """`rblob` of grl_block_tail_fwd's register-resident kernel (layout in include/grl_hip.h; GRL-Base shape): the MFMA A
+    fragments of proj_w [192, 192] (rows = output channels, columns = the slotted attention output), fc1_w [Hd <= 384, C <= 192]
+    and fc2_w [C, Hd] (swin_v1_block.py:29-33), padded with zeros, wave by wave, followed by the padded fc1 bias."""
+    dev = proj_w.device
+    CP, HP = 192, 384
+    Hd, Cin = fc1_w.shape
+    assert proj_w.shape == (CP, CP) and fc2_w.shape == (Cin, Hd) and Cin <= CP and Hd <= HP and fc1_b.numel() == Hd
+    W1 = torch.zeros(HP, CP, dtype=torch.float32, device=dev)
+    W1[:Hd, :Cin] = fc1_w.detach().float()
+    W2 = torch.zeros(CP, HP, dtype=torch.float32, device=dev)
+    W2[:Cin, :Hd] = fc2_w.detach().float()
+
+    def frags(w):   # [rows, K] -> [rows / 32 tiles][K / 16 k-steps][64 lanes][8]: lane = 32 * (column half) + row
+        R, K = w.shape
+        return w.to(GEMM_DTYPE).view(R // 32, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(R // 32, K // 16, 64, 8)
+
+    fp, f1, f2 = frags(proj_w.detach().float()), frags(W1), frags(W2)      # [6][12], [12][12], [6][24]
+    img = torch.zeros(8, 48, 64, 8, dtype=GEMM_DTYPE, device=dev)
+    for w in range(6):
+        img[w, 0:12], img[w, 12:24], img[w, 24:48] = fp[w], f1[w], f2[w]
+    for w in (6, 7):
+        for t in range(3):
+            img[w, 12 * t : 12 * t + 12] = f1[6 + 3 * (w - 6) + t]
+    total = L.lib().grl_tail_regs_blob_bytes()
+    blob = torch.zeros(total, dtype=torch.uint8, device=dev)
+    blob[: 8 * 48 * 1024] = img.view(torch.uint8).reshape(-1)
+    b1 = torch.zeros(HP, dtype=torch.float32, device=dev)
+    b1[:Hd] = fc1_b.detach().float()
+    blob[8 * 48 * 1024 :] = b1.view(torch.uint8)
+    return blob
+
+
 def block_tail(att: torch.Tensor, x: torch.Tensor, cab: torch.Tensor, gate: torch.Tensor, rows_per_image: int,
                pblob: torch.Tensor, pb: torch.Tensor, n1_g: torch.Tensor, n1_b: torch.Tensor,
                blob: torch.Tensor, b2: torch.Tensor, n2_g: torch.Tensor, n2_b: torch.Tensor, *, Hpad: int, n_real: int,
-               ln_eps: float = 1e-5, res_scale: float = 1.0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """proj + norm1 + residual + gated CAB + MLP + norm2 + residual of a block in one kernel (grl_block_tail_fwd)."""
-    _dev_check(att, x, cab, gate, pblob, pb, n1_g, n1_b, blob, b2, n2_g, n2_b, out)
+               ln_eps: float = 1e-5, res_scale: float = 1.0, out: Optional[torch.Tensor] = None, rblob: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """proj + norm1 + residual + gated CAB + MLP + norm2 + residual of a block in one kernel (grl_block_tail_fwd); with `rblob`
+    (pack_tail_regs) the register-resident kernel where the shape qualifies."""
+    _dev_check(att, x, cab, gate, pblob, pb, n1_g, n1_b, blob, b2, n2_g, n2_b, out, rblob)
     M, Cpad = x.shape
     assert x.dtype == torch.float32 and x.stride(1) == 1 and att.dtype == GEMM_DTYPE and att.stride(1) == 1 and att.shape[0] == M
     assert cab.dtype == GEMM_DTYPE and cab.stride(1) == 1 and cab.shape[0] == M and gate.dtype == torch.float32 and gate.is_contiguous()
@@ -348,7 +382,7 @@ def block_tail(att: torch.Tensor, x: torch.Tensor, cab: torch.Tensor, gate: torc
     args = L.GrlTailArgs(att=_ptr(att), ldatt=att.stride(0), x=_ptr(x), ldx=x.stride(0), cab=_ptr(cab), ldcab=cab.stride(0),
                          gate=_ptr(gate), rows_per_image=rows_per_image, pblob=_ptr(pblob), pb=_ptr(pb), n1_g=_ptr(n1_g),
                          n1_b=_ptr(n1_b), blob=_ptr(blob), M=M, Cpad=Cpad, Hpad=Hpad, b2=_ptr(b2), n2_g=_ptr(n2_g), n2_b=_ptr(n2_b),
-                         n_real=n_real, ln_eps=ln_eps, res_scale=res_scale, out=_ptr(out), ldo=out.stride(0))
+                         n_real=n_real, ln_eps=ln_eps, res_scale=res_scale, out=_ptr(out), ldo=out.stride(0), rblob=_ptr(rblob))
     with _timed("block_tail"):
         L.check(L.lib().grl_block_tail_fwd(L.stream_ptr(), C.byref(args)), "grl_block_tail_fwd")
     return out

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 16
+#define GRL_ABI_VERSION 17
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -124,6 +124,14 @@ int64_t grl_mlp_blob_bytes(int32_t Cpad, int32_t Hpad);
  * gate: [images, Cpad] SE gate (grl_se_scale_fwd); pblob: projection weight stream = Cpad/32 chunks, each 32 rows
  * (output channels) x (2*Cpad + 16) bytes fp16 padded to 1024 bytes (grl_proj_blob_bytes); blob as in GrlMlpArgs.
  * rows_per_image must be >= 128 (GRL_ERR_UNSUPPORTED otherwise).
+ *
+ * Register-resident variant (round 4, csrc/tail_regs.hip; GRL-Base shape: Cpad 192, Hpad 384, M and rows_per_image multiples
+ * of 32, 160 < n_real <= 192): when `rblob` is given and the shape qualifies, the three weight matrices stay in the register
+ * file of a persistent 8-wave workgroup as MFMA A fragments and only activations move (`blob` / `pblob` are then unused but
+ * still have to be valid: other shapes fall back to the streaming kernel).  `rblob` (grl_tail_regs_blob_bytes() bytes, 16-B
+ * aligned): 8 waves x 48 fragments x 1 KiB -- fragment f of wave w = 64 lanes x 16 B, lane l = 8 fp16 of row 32 t + (l & 31),
+ * columns 16 s + 8 (l >> 5) + [0..8) of tile t, k-step s of a matrix: wave w < 6: f 0..11 proj tile w, 12..23 fc1 tile w,
+ * 24..47 fc2 tile w (K = Hpad, natural order); waves 6, 7: f 0..35 = fc1 tiles 6..8 / 9..11 -- followed by the Hpad fp32 of fc1.bias.
  * ------------------------------------------------------------------------------------------- */
 typedef struct GrlTailArgs {
     const void* att;
@@ -148,9 +156,11 @@ typedef struct GrlTailArgs {
     float res_scale;
     float* out;             /* [M, ldo] fp32; must not alias x                                      */
     int64_t ldo;
+    const void* rblob;      /* NULL or the register-resident weight image (see above)               */
 } GrlTailArgs;
 
 int grl_block_tail_fwd(void* stream, const GrlTailArgs* args);
+int64_t grl_tail_regs_blob_bytes(void);
 int64_t grl_proj_blob_bytes(int32_t Cpad);
 
 /* ---------------------------------------------------------------------------------------------

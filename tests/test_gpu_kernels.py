@@ -158,9 +158,10 @@ def test_streaming_qkv(M, C, nslots):
 
 
 @pytest.mark.parametrize("M,C,Hd,rpi", [(1000, 180, 360, 500), (4099, 180, 360, 4099), (1300, 128, 256, 650)])
-def test_fused_block_tail(M, C, Hd, rpi):
+def test_fused_block_tail(M, C, Hd, rpi, regs=False):
     """grl_block_tail_fwd (proj + norm1 + residual + gated CAB + MLP + norm2 + residual) against the separate kernels
-    (LN_RES linear with add2, then the fused MLP) and against fp64 torch on fp16-rounded operands."""
+    (LN_RES linear with add2, then the fused MLP) and against fp64 torch on fp16-rounded operands.  regs: through the
+    register-resident kernel (rblob)."""
     from grl_image_restoration_amd import _lib as L, ops
 
     CP, HP = (C + 31) // 32 * 32, (Hd + 31) // 32 * 32
@@ -181,8 +182,9 @@ def test_fused_block_tail(M, C, Hd, rpi):
     g2, b2n = pad(1 + 0.1 * torch.randn(C, generator=g), CP), pad(0.1 * torch.randn(C, generator=g), CP)
     d = _dev()
     blob = ops.pack_mlp(w1.to(d), b1.to(d), w2.to(d), CP, HP)
+    rblob = ops.pack_tail_regs(wp.to(d), w1.to(d), b1.to(d), w2.to(d)) if regs else None
     out = ops.block_tail(att.to(d), x.to(d), cab.to(d), gate.to(d), rpi, ops.pack_proj(wp.to(d)), bp.to(d), g1.to(d), b1n.to(d),
-                         blob, b2.to(d), g2.to(d), b2n.to(d), Hpad=HP, n_real=C, res_scale=0.5).cpu()
+                         blob, b2.to(d), g2.to(d), b2n.to(d), Hpad=HP, n_real=C, res_scale=0.5, rblob=rblob).cpu()
     # separate kernels
     r1 = ops.linear(att.to(d), wp.to(torch.float16).to(d), bp.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, ln_g=g1.to(d),
                     ln_b=b1n.to(d), n_real=C, res_scale=0.5, resid=x.to(d), add2=cab.to(d), add2_scale=gate.to(d), rows_per_image=rpi)
@@ -201,13 +203,31 @@ def test_fused_block_tail(M, C, Hd, rpi):
         assert out[:, C:].abs().max().item() == 0.0
 
 
-@pytest.mark.skipif(__import__("os").environ.get("GRL_TAIL_REGS") != "1",
-                    reason="csrc/tail_regs.hip is a draft that has not run on hardware yet: GRL_TAIL_REGS=1 pytest -k tail_regs_draft")
-@pytest.mark.parametrize("M,rpi", [(2048, 1024), (4096, 4096), (8192, 256)])
-def test_block_tail_regs_draft(M, rpi):
-    """The weights-stationary block tail (GRL_TAIL_REGS=1 routes grl_block_tail_fwd to it for Cpad 192 / Hpad 384 / M % 32 == 0):
-    same checks as the shipped kernel's test."""
-    test_fused_block_tail(M, 180, 360, rpi)
+@pytest.mark.parametrize("M,rpi", [(2048, 1024), (4096, 4096), (8192, 256), (32 * 513, 32 * 19), (128, 128)])
+def test_block_tail_register_resident(M, rpi):
+    """The register-resident block tail (csrc/tail_regs.hip: GrlTailArgs.rblob, Cpad 192 / Hpad 384 / M, rows_per_image
+    multiples of 32): the checks of the streaming kernel's test -- against the separate kernels and fp64 torch, pad channels 0 --
+    with more tiles than workgroups (513 x 32 tokens: the persistent loop, both DMA buffers) and several images per workgroup."""
+    test_fused_block_tail(M, 180, 360, rpi, regs=True)
+
+
+def test_block_tail_rblob_layout():
+    """ops.pack_tail_regs against the fragment layout include/grl_hip.h describes."""
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(5)
+    d = _dev()
+    wp = torch.randn(192, 192, generator=g)
+    w1, b1, w2 = torch.randn(360, 180, generator=g), torch.randn(360, generator=g), torch.randn(180, 360, generator=g)
+    blob = ops.pack_tail_regs(wp.to(d), w1.to(d), b1.to(d), w2.to(d)).cpu()
+    fr = blob[: 8 * 48 * 1024].view(torch.float16).view(8, 48, 64, 8)
+    W1 = torch.zeros(384, 192); W1[:360, :180] = w1
+    W2 = torch.zeros(192, 384); W2[:180, :360] = w2
+    for (w, f, lane, mat, tile, s) in [(0, 0, 0, wp, 0, 0), (3, 7, 45, wp, 3, 7), (5, 12, 63, W1, 5, 0), (2, 30, 17, W2, 2, 6), (5, 47, 40, W2, 5, 23),
+                                       (6, 0, 1, W1, 6, 0), (6, 35, 33, W1, 8, 11), (7, 13, 62, W1, 10, 1)]:
+        row, c0 = 32 * tile + (lane & 31), 16 * s + 8 * (lane >> 5)
+        assert torch.equal(fr[w, f, lane], mat[row, c0 : c0 + 8].to(torch.float16)), (w, f, lane)
+    assert torch.equal(blob[8 * 48 * 1024 :].view(torch.float32)[:360], b1) and blob[8 * 48 * 1024 :].view(torch.float32)[360:].abs().max() == 0
 
 
 @pytest.mark.parametrize("B,H,W,C,nslots,nanc", [(2, 4, 64, 180, 18, 3), (1, 6, 128, 180, 18, 3), (3, 2, 64, 128, 12, 2), (1, 8, 64, 64, 12, 2),

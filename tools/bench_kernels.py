@@ -63,6 +63,8 @@ def main():
     cab = torch.zeros(M, CP, dtype=torch.float16, device="cuda")
     pool = torch.zeros(L.lib().grl_conv3x3_num_workgroups(B, H, W), CP, device="cuda")
     gate = torch.ones(B, CP, device="cuda")
+    blk0 = m.layers[0].blocks[a.block]
+    rblob = ops.pack_tail_regs(pk["proj_w"].float(), blk0.mlp.fc1.weight, blk0.mlp.fc1.bias, blk0.mlp.fc2.weight)   # register-resident tail (opt-in kernel)
     L_, Nw, N2 = H * W, ws[0] * ws[1], ast[0] * ast[1]
     fl_att = 2 * L_ * Nw * C * B
     fl_s = 2 * L_ * N2 * C * B
@@ -96,6 +98,9 @@ def main():
         "block_tail": (lambda: ops.block_tail(att, r, cab, gate, H * W, pk["proj_blob"], pk["proj_b"], pk["n1_g"], pk["n1_b"], pk["mlp_blob"],
                                               pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C),
                        10 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4)),
+        "block_tail_regs": (lambda: ops.block_tail(att, r, cab, gate, H * W, pk["proj_blob"], pk["proj_b"], pk["n1_g"], pk["n1_b"], pk["mlp_blob"],
+                                                   pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C, rblob=rblob),
+                            10 * L_ * C * C * B, M * (192 * 2 + CP * 4 + CP * 2 + CP * 4)),
         "fc1_gelu": (lambda: ops.linear(r, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out=h), 4 * L_ * C * C * B, M * (CP * 4 + 384 * 2)),
         "mlp_fused": (lambda: ops.mlp(r, pk["mlp_blob"], pk["fc2_b"], pk["n2_g"], pk["n2_b"], Hpad=pk["mlp_hp"], n_real=C),
                       8 * L_ * C * C * B, M * (CP * 4 * 2)),
