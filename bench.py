@@ -100,9 +100,8 @@ def cpu_baseline(cfg):
     torch.set_num_threads(best)
     side = 128
     c128, _ = make(side)
-    run(c128, sd, side)                                     # warm-up
-    times = sorted(run(c128, sd, side) for _ in range(2))
-    dt = 0.5 * (times[0] + times[1])
+    times = sorted(run(c128, sd, side) for _ in range(3))   # (the thread sweep above has paged everything in)
+    dt = times[1]
     return {
         "value": round(side * side / dt / 1e6, 6),
         "unit": "LQ megapixels/s",
@@ -111,7 +110,7 @@ def cpu_baseline(cfg):
         "kind": "port",
         "thread_sweep_s_per_64x64_tile": {str(k): round(v, 2) for k, v in sweep.items()},
         "sample": f"one 128x128 LQ tile (1/4 of the pixels of a bench tile, same network / window / stripe geometry), fp32 torch CPU, "
-                  f"1 warm-up + median of 2: {dt:.1f} s per forward on {best} threads.  `value` is that tile's own pixels per second; "
+                  f"median of 3: {dt:.1f} s per forward on {best} threads.  `value` is that tile's own pixels per second; "
                   f"a 256x256 tile costs 4x the pixel-wise work at the same per-pixel attention cost (window 32, stripe 64x64 "
                   f"divide both sizes), i.e. ~{4 * dt:.0f} s per bench tile at the same rate (SURVEY 8(d) measured 99 s on 8 threads)",
     }
@@ -321,7 +320,10 @@ def run(args, rank, world, local_rank):
             "data": "synthetic",
             "config": conf,
             "roofline": {
-                "kernel": "attn_rows_kernel (cosine window / anchored-stripe attention, csrc/attention_rows.hip)",
+                # the row-streaming kernel serves the 32-aligned geometry of config 3; the window-12 / -16 geometries of configs 2 and 4
+                # run the generic kernel (grl_attention_fwd's dispatch, csrc/attention.hip)
+                "kernel": "attn_rows_kernel (cosine window / anchored-stripe attention, csrc/attention_rows.hip)" if args.config == 3 else
+                          "attn_kernel (generic cosine window / anchored-stripe attention, csrc/attention.hip)",
                 "bound": "mfma",
                 "achieved": round(ach, 2),
                 "peak": PEAK_F16_TFLOPS,
@@ -335,6 +337,8 @@ def run(args, rank, world, local_rank):
                 "flops_per_launch": fl,
                 "probe_pass_ms_per_step": round(dt_probe / args.steps * 1e3, 3),
                 "time_share_of_step": round(sum(att) / (dt_probe * 1e3), 3) if att else None,
+                "time_share_note": "sum of the launches' own durations / step time; the tile groups run on concurrent streams, so launches overlap "
+                                   "and the shares of all kernels add up to more than 1" if groups > 1 else None,
                 "concurrent_streams": groups,
                 "tiles_per_launch": args.tiles // groups,
                 **excl,

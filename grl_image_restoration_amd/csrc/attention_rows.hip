@@ -18,7 +18,13 @@
 //     of the whole per-workgroup slice (27 KB for anchor->window, which forced one workgroup per CU);
 //   * a weight that reaches 2^14 leaves the statement BEFORE the row's PV product; the offsets of the queries
 //     concerned are raised from the exact row maximum (compiler-generated cold code), O is rescaled and the row is
-//     redone.  The offsets start at the logit floor, so the first row of every query tile takes this path once.
+//     redone; the maxima are taken over the rest of the chunk (round 4), so a chunk trips at most once.  The offsets start at
+//     the logit floor: the first chunk of a wave goes through the same code before its first row ("prime").
+// Timing-ablation switches of this file compute WRONG results by construction (they remove work to see what it costs).  They only
+// build together with -DGRL_ABLATION, which tools/attn_asm/build_variants_generic.sh passes for its throw-away variant libraries.
+#if !defined(GRL_ABLATION) && (defined(ROWS_ABL_NOBARRIER) || defined(ROWS_ABL_NODMA) || defined(ROWS_ABL_REPEAT))
+#error "timing-ablation switch without -DGRL_ABLATION: the results of such a build are wrong"
+#endif
 #include "common.h"
 #include "grl_hip_internal.h"
 #include "attn_common.h"
@@ -253,10 +259,15 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
 #endif
         DBG_T(t_c3);
         DBG_ADD(3, t_c3 - t_c2);
+        // The offsets start at the logit floor, so the very first row of a wave always "tripped": half a row of wasted work, the exit
+        // from the statement and the repair -- 2.5 rows of 32 (measured).  The first chunk now enters the repair code directly
+        // (`prime`): its exact maxima set the offsets before any exponential is taken.
+        bool prime = ch == 0;
         while (true) {
-            int done;
+            int done = 0;
             const int rs_u = __builtin_amdgcn_readfirstlane(rs), nochk_u = __builtin_amdgcn_readfirstlane(nochk);
-            if constexpr (BORDER) {
+            if (prime) {
+            } else if constexpr (BORDER) {
                 uint32_t t0, t1, t2;
                 asm volatile(ATTN_ROWS4_MASK1
                              : [o0] "+v"(O0), [o1] "+v"(O1), [sb] "+s"(sb), [done] "=s"(done), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)
@@ -270,10 +281,10 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
                                [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par), [nochk] "s"(nochk_u)
                              : ATTN_ROWS_CLOBBER);
             }
-            if (done == RROWS) { DBG_T(t_c4); DBG_ADD(4, t_c4 - t_c3); break; }
+            if (!prime && done == RROWS) { DBG_T(t_c4); DBG_ADD(4, t_c4 - t_c3); break; }
             DBG_ADD(6, 1);
             // ---- cold: a weight of key row `done` reached 2^14.  Exact row maxima -> raise the offsets, rescale O, redo the row ----
-            if (done == last_trip) {
+            if (!prime && done == last_trip) {
                 // the row tripped again right after its offsets were raised: only non-finite logits do that.  Poison the
                 // outputs (the reference yields NaN as well) and move on.
                 poison = 1;
@@ -282,38 +293,45 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
                 if (rs == RROWS) break;
                 continue;
             }
-            last_trip = done;
+            last_trip = prime ? -1 : done;
+            prime = false;
             {
                 const int ln = lane_id();
                 const int half = ln >> 5, l31 = ln & 31, sw = (l31 >> 2) & 3;
-                const char* Kc = smem + par;
-                const int kk = 32 * done + l31;
-                const f16x8 kf0 = *(const f16x8*)(Kc + kk * 64 + (((0 + half) ^ sw) << 4));
-                const f16x8 kf1 = *(const f16x8*)(Kc + kk * 64 + (((2 + half) ^ sw) << 4));
+                const char* Kc = smem + __builtin_amdgcn_readfirstlane((int)((ch & 1) * KBUF));   // (recomputed: `par` as a VGPR across the statement was a spill slot)
                 // (Nothing the repair path needs may be kept in a spill slot across the statement: a scratch reload here is "pending" at
                 // the head of the loop on every path, and the compiler then puts s_waitcnt vmcnt(0) in front of the statement -- which
                 // also waits for the DMA of the next chunk, issued a few instructions earlier.  Hence the opaque copy of bl, which keeps
                 // bl - lds0 from being hoisted out of the chunk loop, and msafe as an integer in an SGPR.)
                 uint32_t blx = bl;
                 asm volatile("" : "+v"(blx));
-                const float* t0p = (const float*)(smem + (blx + sb - lds0));   // tile 0's fragment of this row; tile 1's is one table row below
-                f32x16 S0, S1;
+                // Exact maxima of the tripping row AND of the rows of the chunk still to come (round 4): at checkpoint-like logit
+                // scales 20 of a wave's 32 key rows tripped and a trip costs 2.5 rows (measured, tools/attn_asm/dbg_rows.py); the
+                // chunk's K rows and table window are in LDS anyway, so one repair now covers the whole chunk.
+                float mx0 = NEG_BIG, mx1 = NEG_BIG;
+#pragma unroll 1
+                for (int rr = done; rr < RROWS; ++rr) {
+                    const int kk = 32 * rr + l31;
+                    const f16x8 kf0 = *(const f16x8*)(Kc + kk * 64 + (((0 + half) ^ sw) << 4));
+                    const f16x8 kf1 = *(const f16x8*)(Kc + kk * 64 + (((2 + half) ^ sw) << 4));
+                    const float* t0p = (const float*)(smem + (blx + sb - lds0)) + (rr - done) * D;   // tile 0's fragment of row rr; tile 1's is one table row below
+                    f32x16 S0, S1;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) { S0[r] = t0p[(r & 3) + 8 * (r >> 2)]; S1[r] = t0p[(r & 3) + 8 * (r >> 2) - D]; }
-                S0 = mfma32_f16(kf0, q00, S0);
-                S1 = mfma32_f16(kf0, q10, S1);
-                S0 = mfma32_f16(kf1, q01, S0);
-                S1 = mfma32_f16(kf1, q11, S1);
-                if constexpr (BORDER) {
-                    const int id_lo = (ids >> (8 * done)) & 15, id_hi = (ids >> (8 * done + 4)) & 15;
-                    const float a_lo = id_lo != idq0 ? MASK_L2 : 0.f, a_hi = id_hi != idq0 ? MASK_L2 : 0.f;
-                    const float b_lo = id_lo != idq1 ? MASK_L2 : 0.f, b_hi = id_hi != idq1 ? MASK_L2 : 0.f;
+                    for (int r = 0; r < 16; ++r) { S0[r] = t0p[(r & 3) + 8 * (r >> 2)]; S1[r] = t0p[(r & 3) + 8 * (r >> 2) - D]; }
+                    S0 = mfma32_f16(kf0, q00, S0);
+                    S1 = mfma32_f16(kf0, q10, S1);
+                    S0 = mfma32_f16(kf1, q01, S0);
+                    S1 = mfma32_f16(kf1, q11, S1);
+                    if constexpr (BORDER) {
+                        const int id_lo = (ids >> (8 * rr)) & 15, id_hi = (ids >> (8 * rr + 4)) & 15;
+                        const float a_lo = id_lo != idq0 ? MASK_L2 : 0.f, a_hi = id_hi != idq0 ? MASK_L2 : 0.f;
+                        const float b_lo = id_lo != idq1 ? MASK_L2 : 0.f, b_hi = id_hi != idq1 ? MASK_L2 : 0.f;
 #pragma unroll
-                    for (int r = 0; r < 8; ++r) { S0[r] += a_lo; S0[8 + r] += a_hi; S1[r] += b_lo; S1[8 + r] += b_hi; }
+                        for (int r = 0; r < 8; ++r) { S0[r] += a_lo; S0[8 + r] += a_hi; S1[r] += b_lo; S1[8 + r] += b_hi; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) { mx0 = fmaxf(mx0, S0[r]); mx1 = fmaxf(mx1, S1[r]); }
                 }
-                float mx0 = S0[0], mx1 = S1[0];
-#pragma unroll
-                for (int r = 1; r < 16; ++r) { mx0 = fmaxf(mx0, S0[r]); mx1 = fmaxf(mx1, S1[r]); }
                 mx0 = fmaxf(mx0, xhalf(mx0));
                 mx1 = fmaxf(mx1, xhalf(mx1));
                 float d0 = fmaxf(0.f, __builtin_ceilf(mx0) - ROWS_REST), d1 = fmaxf(0.f, __builtin_ceilf(mx1) - ROWS_REST);

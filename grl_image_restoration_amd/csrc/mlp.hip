@@ -19,6 +19,11 @@
 //     through a double-buffered LDS ring, one 32-channel chunk (W1 rows, W2 columns, b1) per step; the
 //     chunk sequence is cyclic, so the ring keeps running across the token tiles of the persistent
 //     workgroup.  One barrier per chunk.
+// Timing-ablation switches of this file compute WRONG results by construction (they remove work to see what it costs).  They only
+// build together with -DGRL_ABLATION, which tools/attn_asm/build_variants_generic.sh passes for its throw-away variant libraries.
+#if !defined(GRL_ABLATION) && (defined(MLP_ABL_NOATT) || defined(MLP_ABL_NOXDMA) || defined(MLP_ABL_NOGELU) || defined(MLP_ABL_NOFC2) || defined(MLP_ABL_NOSTORE))
+#error "timing-ablation switch without -DGRL_ABLATION: the results of such a build are wrong"
+#endif
 #include "common.h"
 #include <stdlib.h>
 

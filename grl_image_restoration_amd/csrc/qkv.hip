@@ -14,6 +14,11 @@
 //     2*SPC n-tiles x K/32 MFMAs, the per-slot L2 normalisation needs two cross-lane adds, and the store of a slot
 //     is 1 KiB contiguous per wave (head-plane layout).
 // DMA ordering is by hand (inline asm, counted s_waitcnt before the publishing barrier) as in csrc/mlp.hip.
+// Timing-ablation switches of this file compute WRONG results by construction (they remove work to see what it costs).  They only
+// build together with -DGRL_ABLATION, which tools/attn_asm/build_variants_generic.sh passes for its throw-away variant libraries.
+#if !defined(GRL_ABLATION) && (defined(QKV_ABL_NOXDMA) || defined(QKV_ABL_NOMFMA) || defined(QKV_ABL_NOSTORE))
+#error "timing-ablation switch without -DGRL_ABLATION: the results of such a build are wrong"
+#endif
 #include "common.h"
 #include <stdlib.h>
 

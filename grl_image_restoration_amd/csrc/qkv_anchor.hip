@@ -17,6 +17,11 @@
 //   * tiles are 2 image rows x 64 columns (128 tokens), token pieces and weight chunks arrive by LDS-DMA as in round 2;
 //     DMA completion is awaited right before a chunk's stores (vmcnt also counts stores: a wait at the chunk top would sit out
 //     the write acknowledgements of the previous chunk every time).
+// Timing-ablation switches of this file compute WRONG results by construction (they remove work to see what it costs).  They only
+// build together with -DGRL_ABLATION, which tools/attn_asm/build_variants_generic.sh passes for its throw-away variant libraries.
+#if !defined(GRL_ABLATION) && (defined(QA_ABL_NOXDMA) || defined(QA_ABL_NOSTORE) || defined(QA_TOKEN_MAJOR) || defined(QS_ABL_NOLO) || defined(QS_ABL_NOFP8))
+#error "timing-ablation switch without -DGRL_ABLATION: the results of such a build are wrong"
+#endif
 #include "common.h"
 #include "grl_hip_internal.h"
 #include <stdlib.h>
@@ -445,7 +450,7 @@ int launch_qr(const GrlQkvAnchorArgs& p, hipStream_t st) {
 //     for the whole launch, multiplied with x_8 = e4m3(x_hi / 16) -- converted in registers from the fp16 B operand, the fp8
 //     32x32x16 MFMA has the same lane <-> k layout -- at twice the fp16 MFMA rate;
 //   * the split slots are all normalised per token (q, k, anchors), so a common factor is free: W_hi and the bias are scaled by
-//     2^e in registers once per launch (exact; e <= 8 chosen by the host so that nothing overflows) and the main term
+//     2^e in registers once per launch (exact; e <= 14 chosen by the host so that nothing overflows) and the main term
 //     accumulates at the scale 2^e of the two low terms -- ONE accumulator per slot, no fold; v slots (gscale 0, not
 //     normalised, not multiplied by a logit scale) are not split.
 // LDS: 96 KB of W_lo8 leave room for 32-token tiles (hi + lo, double buffered: 51 KB), so a tile is one token group of the

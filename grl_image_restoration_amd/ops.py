@@ -270,7 +270,7 @@ def pack_qkv_anchor_lo(w: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
     """`lo_blob` of grl_qkv_anchor_fwd's split-precision variant (layout in include/grl_hip.h) from the slotted weight matrix
     w [(nslots + nanc)*32, Cpad] (fp32, q/k/v slots then anchor slots) and the slots' gscale: for every normalised slot
     (gscale != 0) the fp16 rounding error of its weights, scaled by 2^(e+4), as e4m3.  The kernel also multiplies W_hi by 2^e
-    (its split slots accumulate at that scale), so e <= 8 is lowered until 2^e max|W| stays inside fp16 and the scaled
+    (its split slots accumulate at that scale), so e <= 14 is lowered until 2^e max|W| stays inside fp16 and the scaled
     rounding errors inside e4m3."""
     dev = w.device
     N, Cpad = w.shape
@@ -283,7 +283,7 @@ def pack_qkv_anchor_lo(w: torch.Tensor, gscale: torch.Tensor) -> torch.Tensor:
     assert total > 0, "split-precision QKV: GRL-Base slot layout only"
     amax = float(lo.abs().max())
     wmax = float(w.view(ns, 32, Cpad)[gscale.detach().float().cpu() != 0].abs().max())
-    e = 8
+    e = 14   # as large as both ranges allow: the scaled rounding errors should sit in e4m3's normal range (3 significant bits)
     while e > -8 and (amax * 2.0 ** (e + 4) > 448.0 or wmax * 2.0 ** e > 30000.0):
         e -= 1
     lo8 = (lo * 2.0 ** (e + 4)).clamp_(-448.0, 448.0).to(torch.float8_e4m3fn)

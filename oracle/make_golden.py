@@ -40,11 +40,25 @@ FIXTURES = [
     ("tiny_sr2_ckpt_64_hiscale", "tiny", "sr_ckpt_df4", 2, 64, (64, 64), "sr", dict(sd=dict(logit_scale_mean=LN100))),
     # the bench shape itself: two 256x256 LQ tiles (4x4 stripes, 8x8 windows per tile, both tile groups of the 2-stream split)
     ("base_sr4_ckpt_256", "base", "sr_ckpt_df2", 4, 256, (256, 256), "sr", dict(batch=2, quantise=True, sub2=4)),
-    # the bench shape with checkpoint-like logit scales (around ln 100: about half of the heads at the clamp) -- the headline is
-    # measured on this kernel path, so its parity is pinned at the benchmarked shape, not only at 64x64
+    # the bench shape with checkpoint-like logit scales (around ln 100: about half of the heads at the clamp) -- the
+    # bench's trained_scales leg runs on this kernel path, so its parity is pinned at the benchmarked shape
     ("base_sr4_ckpt_256_hiscale", "base", "sr_ckpt_df2", 4, 256, (256, 256), "sr", dict(batch=1, quantise=True, sd=dict(logit_scale_mean=LN100))),
     # BASELINE config 4 at a real tile: 384x384 (2 x 4 tiles of the 1280x720 frame), window 12, stripes 48x96, anchors /4
     ("base_deblur_384", "base", "deblur", 1, 384, (384, 384), "deblur", dict(frame=(720, 1280), tile=384, overlap=48, tiles=(0, 5))),
+    # round 4 (VERDICT r3 #1a): checkpoint-like logit scales for BASELINE configs 2 and 4 as well (around ln 100: about half of the
+    # heads at the clamp), and the regime in between -- scales around 30, above anything random init draws and below the
+    # threshold (GRL_HIQ_SCALE) at which the q / k / anchor projection switches to split operands
+    # `conditioning`: the fixture also records how far the REFERENCE's own fp32 output moves when the input is multiplied by
+    # 1 + 2^-20 N(0,1) (250 x below 8-bit image quantisation).  With these seeded random weights GRL-Small at the clamp is
+    # a chaotic amplifier: 2.9e-3 -- its output is not defined to the 1e-3 parity bar, whatever the arithmetic (the others: ~1e-5).
+    # The test reads the number and only asserts that fixture against gross errors; small_dn_128_midscale (scales around 40, still
+    # above what random init draws and above the level at which `auto` moves the narrow models to split operands) is the
+    # well-conditioned config-2 fixture for that regime.
+    ("small_dn_128_hiscale", "small", "dn_df4", 1, 128, (128, 128), "dn", dict(sd=dict(logit_scale_mean=LN100), conditioning=True)),
+    ("small_dn_128_midscale", "small", "dn_df4", 1, 128, (128, 128), "dn", dict(sd=dict(logit_scale_mean=math.log(40.0)), conditioning=True)),
+    ("base_deblur_384_hiscale", "base", "deblur", 1, 384, (384, 384), "deblur",
+     dict(frame=(720, 1280), tile=384, overlap=48, tiles=(5,), sd=dict(logit_scale_mean=LN100), conditioning=True)),
+    ("base_sr4_ckpt_64_midscale", "base", "sr_ckpt_df2", 4, 64, (64, 64), "sr", dict(sd=dict(logit_scale_mean=math.log(30.0)), conditioning=True)),
 ]
 
 
@@ -89,6 +103,10 @@ def main(only=None):
             y = ref(lq)
             yo = O.grl_forward(lq, cfg, sd)
         err = (y - yo).abs().max().item()
+        if ex.get("conditioning"):
+            with torch.no_grad():
+                yp = ref(lq * (1 + 2.0**-20 * torch.randn(lq.shape, generator=torch.Generator().manual_seed(3))))
+            extra_meta["conditioning_2e-20"] = (yp - y).abs().max().item()
         meta = dict(name=name, cfg=cfg, weight_seed=0, sd_kwargs=sd_kw, task=task, oracle_vs_reference_maxabs=err, **extra_meta)
         arrays = dict(input=lq.numpy())
         if ex.get("quantise"):

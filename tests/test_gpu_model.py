@@ -40,7 +40,11 @@ def test_hip_forward_matches_reference_golden(name):
     err = (y - z["output"]).abs().max().item()
     rms = (y - z["output"]).pow(2).mean().sqrt().item()
     print(f"{name} [{m.precision}]: max|hip - reference| = {err:.3e}  rms = {rms:.3e}")
-    assert err < TOL_MAXABS, err
+    # An ill-conditioned fixture (the reference's own fp32 output moves by more than a quarter of the bar when the input is
+    # perturbed by 1e-6 relative, recorded by oracle/make_golden.py) is asserted against gross errors only: 4 x that movement.
+    cond = meta.get("conditioning_2e-20", 0.0)
+    tol = TOL_MAXABS if cond < 0.25 * TOL_MAXABS else 4.0 * cond
+    assert err < tol, (err, tol)
 
 
 def test_hip_forward_at_the_bench_shape():

@@ -6,8 +6,8 @@ ROOT=$(cd $(dirname $0)/../.. && pwd)
 CS=$ROOT/grl_image_restoration_amd/csrc
 OUT=$ROOT/tools/attn_asm/variants
 mkdir -p $OUT
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
-OBJS="linear.o linear_k576.o linear_k1152.o mlp.o qkv.o attention.o attention_bwd.o conv.o misc.o grad.o"
+FLAGS="-DGRL_ABLATION --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
+OBJS="linear.o linear_k576.o linear_k1152.o mlp.o qkv.o qkv_anchor.o attention.o attention_bwd.o conv.o cab_conv2.o tail_regs.o misc.o grad.o"
 build() {  # name, generator --abl, extra -D flags
   T=$(mktemp -d)
   cp $CS/attention_rows.hip $CS/common.h $CS/attn_common.h $CS/grl_hip_internal.h $T/

@@ -7,7 +7,7 @@ OUT=$ROOT/tools/attn_asm/variants
 mkdir -p $OUT
 SRC=$1; shift
 OBJ=${SRC%.hip}.o
-FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
+FLAGS="-DGRL_ABLATION --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=fast -Wno-unused-result -Wno-unused-value -Wno-inline-asm"
 ALL="linear.o linear_k576.o linear_k1152.o mlp.o qkv.o qkv_anchor.o attention.o attention_rows.o attention_bwd.o conv.o cab_conv2.o tail_regs.o misc.o grad.o"
 REST=$(echo $ALL | sed "s/\b$OBJ\b//")
 for spec in "$@"; do
