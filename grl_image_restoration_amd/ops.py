@@ -585,7 +585,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             out_dtype=_KIND[out.dtype], ldo=out.stride(0),
             shuffle_r=shuffle_r, shuffle_cg=shuffle_cg, shuffle_ij0=(c0 // shuffle_cg if shuffle_r > 1 else 0),
         )
-        with _timed("conv3x3"):
+        with _timed(f"conv3x3 {CinP}->{CoutP} {H}x{W}" if _PROFILE is not None else "conv3x3"):
             L.check(lib.grl_conv3x3_fwd(L.stream_ptr(), C.byref(args)), "grl_conv3x3_fwd")
     return (out, pool) if want_pool else out
 
@@ -631,7 +631,7 @@ def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H
         args.gate, args.se_counter = _ptr(gate), _ptr(cnt)
         args.se_w1, args.se_b1, args.se_w2, args.se_b2 = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
         args.se_c, args.se_mid, args.inv_hw = C_, w1.shape[0], 1.0 / (H * W)
-    with _timed("conv3x3"):
+    with _timed("cab_conv2"):
         L.check(L.lib().grl_cab_conv2_fwd(L.stream_ptr(), C.byref(args)), "grl_cab_conv2_fwd")
     return out, (gate if se is not None else pool)
 

@@ -34,7 +34,7 @@ us = e0.elapsed_time(e1) * 1e3 / N
 print(f"kernel wall {us:.1f} us per launch = {us / 32:.2f} us per 32-token tile and CU")
 lib.grl_tr_debug(buf, 1)
 tiles = N * (M // 32)
-names = ["B0 wait", "fetch|P1 proj+stats", "LN1+r1", "fc1 tile", "-", "vmcnt+B4", "LN2+out", "fc2 half | fc1 x2"]
+names = ["B0 wait", "P1 | load r0", "LN1+r1 | store r0, load r1", "fc1 tile", "-", "B4 wait", "LN2+out", "fc2 half | fc1 x2"]
 for w in range(8):
     v = [buf[8 * w + i] / tiles for i in range(8)]
     print(f"wave {w:2d}: " + "  ".join(f"{n} {x:.0f}" for n, x in zip(names, v)) + f"   sum {sum(v):.0f} ticks")
