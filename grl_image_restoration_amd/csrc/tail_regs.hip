@@ -141,13 +141,7 @@ __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
     if ((int)blockIdx.x >= ntiles) return;
 
     // ---- once per launch: A fragments -> registers, vectors -> LDS ----
-    f16x8 Wt[TR_FRAGS];
-    {
-        const char* src = (const char*)p.rblob + ((size_t)wave * TR_FRAGS) * 1024 + tr_lane() * 16;
-#pragma unroll
-        for (int f = 0; f < TR_FRAGS; ++f)
-            if (f < 36 || cw) Wt[f] = *(const f16x8*)(src + (size_t)f * 1024);
-    }
+    f16x8 Wt[TR_FRAGS];   // (loaded at the head of each role's loop below: a common load is a common live range across the branch)
     float* vec = (float*)(smem + TR_OFF_VEC);
     {
         const int tid = 64 * wave + tr_lane();
@@ -313,6 +307,11 @@ __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
     // B4): the register allocator works per program point, so in one shared loop the 48 fragment registers the fc1-only waves do
     // not use and the 48 registers of data their loader keeps in flight both counted against the channel waves' code.
     if (cw) {
+        {
+            const char* src = (const char*)p.rblob + ((size_t)wave * TR_FRAGS) * 1024 + tr_lane() * 16;
+#pragma unroll
+            for (int f = 0; f < TR_FRAGS; ++f) Wt[f] = *(const f16x8*)(src + (size_t)f * 1024);
+        }
         int it = 0;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
             TR_TIME(t0);
@@ -412,6 +411,11 @@ __global__ __launch_bounds__(TR_THREADS) void tail_regs_kernel(GrlTailArgs p) {
             TR_ADD(6, t7 - t6);
         }
     } else {
+        {
+            const char* src = (const char*)p.rblob + ((size_t)wave * TR_FRAGS) * 1024 + tr_lane() * 16;
+#pragma unroll
+            for (int f = 0; f < 36; ++f) Wt[f] = *(const f16x8*)(src + (size_t)f * 1024);
+        }
         int it = 0;
         for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
             TR_TIME(t0);
