@@ -225,6 +225,7 @@ def run(args, rank, world, local_rank):
             y = model(x)
     dt, y = timed_steps(model, x, args.steps, world)
     assert torch.isfinite(y).all()
+    precision_mode = model.precision   # (of the timed leg: `auto` is resolved per weight set, the trained-scale leg may differ)
 
     # ---- untimed passes (rank 0 measures; every rank runs the same launches so that the barriers match) ----
     groups = model.stream_groups(args.tiles)   # tile groups advancing on separate HIP streams (one launch = one group)
@@ -261,7 +262,7 @@ def run(args, rank, world, local_rank):
                 yt = model(x)
         dt_t, yt = timed_steps(model, x, args.steps, world)
         assert torch.isfinite(yt).all()
-        trained = {"ms_per_step": round(dt_t / args.steps * 1e3, 3), "ratio_to_random_init": round(dt_t / dt, 4),
+        trained = {"ms_per_step": round(dt_t / args.steps * 1e3, 3), "ratio_to_random_init": round(dt_t / dt, 4), "precision_mode": model.precision,
                    "logit_scales": "exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at the clamp"}
 
     # strong-scaling leg: one fixed tile list sharded over the ranks, stitched through the RCCL all-gather
@@ -278,7 +279,6 @@ def run(args, rank, world, local_rank):
                  "value": round(n_t * side * side * 3 / dt_s / 1e6, 4), "unit": "LQ megapixels/s", "scaling": "strong",
                  "collective": f"all_gather_into_tensor of {n_t // world} x (3, {side * scale}, {side * scale}) fp32 tiles per rank (RCCL)"}
 
-    precision_mode = model.precision
     training = None
     if not args.no_train and args.config == 3:
         del model, x, y

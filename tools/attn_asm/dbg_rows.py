@@ -8,7 +8,7 @@ shutil.copy(lib, lib + ".orig")
 shutil.copy(os.path.join(root, "tools", "attn_asm", "libgrl_hip_dbg.so"), lib)
 try:
     sys.path.insert(0, root)
-    sys.argv = ["bench_kernels.py", "--tiles", "4", "--iters", "1", "--only", sys.argv[1] if len(sys.argv) > 1 else "attn_window"] + sys.argv[2:]
+    sys.argv = ["bench_kernels.py", "--tiles", "4", "--iters", "10", "--only", sys.argv[1] if len(sys.argv) > 1 else "attn_window"] + sys.argv[2:]
     from grl_image_restoration_amd import _lib as L
     import runpy
     h = L.lib()

@@ -16,7 +16,7 @@ DB=$(find /tmp/prof_kt -name "*.db" | head -1)
 echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-trained-scales" > $OUT/kernel_stats.txt
 tail -1 $OUT/prof_bench_stdout.txt >> $OUT/kernel_stats.txt
 python $ROOT/tools/rocprof_summary.py "$DB" 30 >> $OUT/kernel_stats.txt 2>&1
-KERN=attn_window,attn_a2w,attn_w2a,qkv_anchor,block_tail,cab_conv1,cab_conv2_regs,se,stage_conv
+KERN=attn_window,attn_a2w,attn_w2a,qkv_anchor,block_tail_regs,cab_conv1,cab_conv2_regs,se,stage_conv
 : > $OUT/pmc_hbm.txt
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/prof_$c
@@ -31,7 +31,7 @@ cd $ROOT
 tools/pmc_kernels.sh gpurun_out/prof/pmc_sq_all.txt --tiles 4 --iters 3 --only $KERN > /dev/null 2>&1
 grep -v "at6native\|rocclr" gpurun_out/prof/pmc_sq_all.txt > $OUT/pmc_sq.txt; rm -f gpurun_out/prof/pmc_sq_all.txt
 python tools/bench_kernels.py --tiles 4 2>&1 | grep -v amdgpu.ids > $OUT/bench_kernels.txt
-python tools/bench_kernels.py --tiles 4 --logit-scale 100 --only attn_window,attn_a2w,attn_w2a 2>&1 | grep -v amdgpu.ids > $OUT/bench_kernels_scale100.txt
+python tools/bench_kernels.py --tiles 4 --logit-scale 100 --only attn_window,attn_a2w,attn_w2a,qkv_anchor,qkv_split 2>&1 | grep -v amdgpu.ids > $OUT/bench_kernels_scale100.txt
 python bench.py --config 2 --tiles 16 --no-cpu-baseline > $OUT/bench_config2.json 2> $OUT/bench_config2.err
 python bench.py --config 4 --tiles 4 --no-cpu-baseline > $OUT/bench_config4.json 2> $OUT/bench_config4.err
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
