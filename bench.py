@@ -54,6 +54,11 @@ WORKLOADS = {
 }
 
 
+def attention_launches(prof):
+    """durations of the forward attention launches of an ops.profile_end() record (labelled per geometry: 'attention q.. k..')"""
+    return [t for k, v in prof.items() if k.startswith("attention ") or k == "attention" for t in v]
+
+
 def attention_flops_per_launch(cfg, tiles, hw):
     """each of the three attention launches of a block (window, anchors->
     stripe, stripe->anchors) does 2 * L * N_keys * C FLOPs per tile (QK^T + PV over C/2 channels)."""
@@ -242,7 +247,7 @@ def run(args, rank, world, local_rank):
             model(x)
             p1 = ops.profile_end()
             del os.environ["GRL_SPLIT_STREAMS"]
-            a1 = p1.get("attention", [])
+            a1 = attention_launches(p1)
             if a1:
                 ms1 = sum(a1) / len(a1)
                 fl1 = attention_flops_per_launch(cfg, args.tiles, (side, side))
@@ -287,7 +292,7 @@ def run(args, rank, world, local_rank):
 
     if rank == 0:
         mp = world * args.tiles * side * side * args.steps / dt / 1e6
-        att = prof.get("attention", [])
+        att = attention_launches(prof)
         att_ms = sum(att) / max(len(att), 1)
         fl = attention_flops_per_launch(cfg, args.tiles // groups, (side, side))
         ach = fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 17
+ABI_VERSION = 18
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -30,6 +30,7 @@ EXPORTS = [
     "grl_cab_conv2_fwd",
     "grl_cab_conv2_blob_bytes",
     "grl_attention_fwd",
+    "grl_attention_rows_geometry_ok",
     "grl_layernorm_fwd",
     "grl_layernorm_res_fwd",
     "grl_conv3x3_fwd",
@@ -211,6 +212,7 @@ class GrlTokenGrid(_Strict):
         ("ww", C.c_int32),
         ("shy", C.c_int32),
         ("shx", C.c_int32),
+        ("transposed", C.c_int32),
     ]
 
 
@@ -400,6 +402,8 @@ def lib():
     L.grl_cab_conv2_blob_bytes.restype = C.c_int64
     L.grl_attention_fwd.argtypes = [C.c_void_p, C.POINTER(GrlAttnArgs)]
     L.grl_attention_fwd.restype = C.c_int
+    L.grl_attention_rows_geometry_ok.argtypes = [C.POINTER(GrlAttnArgs)]
+    L.grl_attention_rows_geometry_ok.restype = C.c_int
     L.grl_layernorm_fwd.argtypes = [
         C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,
         C.c_int32, C.c_int32, C.c_int32, C.c_float,

@@ -736,6 +736,8 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
 bool grl_attn_rows_supported(const GrlAttnArgs& p);
 int grl_attn_rows_launch(const GrlAttnArgs& p, hipStream_t st);
 
+extern "C" int grl_attention_rows_geometry_ok(const GrlAttnArgs* args) { return grl_attn_rows_supported(*args) ? 1 : 0; }
+
 extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     const GrlAttnArgs& p = *args;
     const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
@@ -749,6 +751,7 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
         (p.v.col0 % 8) || (p.o.col0 % 4) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 4))
         return GRL_ERR_BAD_ARG;
     if (p.lse != nullptr && p.lse_stride <= 0) return GRL_ERR_BAD_ARG;
+    if (p.q.transposed != p.k.transposed || p.q.transposed != p.v.transposed || p.q.transposed != p.o.transposed) return GRL_ERR_BAD_ARG;
     if (p.out_dtype == GRL_DT_F16 && ((p.o.ld % 8) || (p.o.col0 % 8) || (p.o.hstride % 8))) return GRL_ERR_BAD_ARG;   // 16-B stores
     hipStream_t st = (hipStream_t)stream;
     // fast path: 32-aligned geometry with the ones column and the lazy running offset (needs the spare head-dim slot 31:
@@ -757,8 +760,10 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (p.o_lo != nullptr && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
     const bool lazy_ok = !split && p.k_one31 && p.head_dim <= 30 && p.ones_col != 31 && p.lazy_floor != nullptr;
     static const int rows_off = getenv("GRL_ATTN_ROWS") ? atoi(getenv("GRL_ATTN_ROWS")) == 0 : 0;   // 0: round-2 fast kernels (A/B)
-    if (lazy_ok && !rows_off && !getenv("GRL_ATTN_GENERIC") && grl_attn_rows_supported(p)) return grl_attn_rows_launch(p, st);
-    if (lazy_ok && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
+    // head_dim 32 (GRL-Small): no spare slot; the row-streaming kernel carries offset and denominator on the VALU instead
+    const bool d32_ok = !split && p.head_dim == 32 && p.ones_col < 0 && p.lazy_floor != nullptr;
+    if ((lazy_ok || d32_ok) && !rows_off && !getenv("GRL_ATTN_GENERIC") && grl_attn_rows_supported(p)) return grl_attn_rows_launch(p, st);
+    if (lazy_ok && !p.q.transposed && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
         (p.k.wh % 8) == 0 && fast_lds_bytes(p, 1) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
         return launch_fast(p, st);
     const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));

@@ -520,6 +520,7 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
     const int Nq = p.q.wh * p.q.ww, Nk = p.k.wh * p.k.ww;
     if (Nq <= 0 || Nk <= 0 || p.B <= 0 || p.nh <= 0) return GRL_ERR_BAD_ARG;
     if (p.q.Himg != p.nwy * p.q.wh || p.q.Wimg != p.nwx * p.q.ww || p.k.Himg != p.nwy * p.k.wh || p.k.Wimg != p.nwx * p.k.ww) return GRL_ERR_BAD_ARG;
+    if (p.q.transposed || p.k.transposed || p.v.transposed || p.o.transposed) return GRL_ERR_UNSUPPORTED;   // (GrlTokenGrid.transposed: forward only)
     if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1) || p.tstride < p.trows || (p.tstride & 3)) return GRL_ERR_BAD_ARG;
     if (p.head_dim > 32 || p.out_dtype != GRL_DT_F32 || p.lse == nullptr || p.lse_stride <= 0) return GRL_ERR_BAD_ARG;
     if (!a.d_o || !a.d_q || !a.d_k || !a.d_v || !a.d_table || !(a.g_scale > 0.f)) return GRL_ERR_BAD_ARG;

@@ -39,7 +39,9 @@ constexpr int RROWS = 4;              // key rows per chunk
 constexpr int RKC = RROWS * 32;       // keys per chunk
 constexpr int KBUF = RKC * 64;        // bytes of one K (or V) chunk buffer
 constexpr int TBUF = 4096;            // bytes of one table-window buffer
-constexpr int ROWS_LDS = 4 * KBUF + 2 * TBUF;
+constexpr int TBUF_D32 = 8192;        // ... of the head_dim-32 instance (dn geometry: 16x32 anchors against 64x128 stripes need 6.6 KB)
+constexpr int rows_tbuf(bool d32) { return d32 ? TBUF_D32 : TBUF; }
+constexpr int rows_lds(bool d32) { return 4 * KBUF + 2 * rows_tbuf(d32); }
 constexpr float ROWS_REST = 4.0f;     // after an offset move the row maximum sits in (2^3, 2^4]
 constexpr float ROWS_EXTRA = 3.0f;    // ... unless up to this much more reaches the level where the overflow test can go (msafe)
 
@@ -74,7 +76,12 @@ __device__ unsigned long long rows_dbg[8];
 #define DBG_FLUSH()
 #endif
 
-__global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
+// D32: head_dim 32 (GRL-Small).  All 32 head-dim slots of Q / K / V are data, so the running offset lives in two VGPRs
+// (nm0 / nm1 = -m of the lane's query in tile 0 / 1) that the statement adds to the logits, and the softmax denominator is
+// summed from the packed fp16 weights (l0 / l1, one partial sum per half-wave); 48 KB of LDS -> 3 workgroups per CU.
+template <bool D32>
+__global__ __launch_bounds__(RW * 64, D32 ? 3 : 4) void attn_rows_kernel(GrlAttnArgs p) {
+    constexpr int TB = rows_tbuf(D32);
     extern __shared__ __attribute__((aligned(1024))) char smem[];
 #ifdef ROWS_DEBUG
     unsigned long long dbg_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -132,8 +139,9 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         // offsets start at the floor of the head's logits (every weight >= 1): the first row raises them
         // (integer valued, |m| < 2048: exact in fp16 -- slot 31 of the upper half-wave IS the running offset, no second copy)
         const float mq = p.lazy_floor[head];
-        if (half) { q01[7] = (f16)(-mq); q11[7] = (f16)(-mq); }   // head-dim slot 31 (K holds 1.0 there)
+        if (!D32 && half) { q01[7] = (f16)(-mq); q11[7] = (f16)(-mq); }   // head-dim slot 31 (K holds 1.0 there)
     }
+    float nm0 = -p.lazy_floor[head], nm1 = nm0, l0 = 0.f, l1 = 0.f;   // (D32 only)
     f32x16 O0, O1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { O0[r] = 0.f; O1[r] = 0.f; }
@@ -156,7 +164,9 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
     const u32x4 ksrd = srd((const f16*)p.k.ptr + (int64_t)b * p.k.Himg * p.k.Wimg * p.k.ld + p.k.col0 + head * p.k.hstride, 0xffffffffu);
     const u32x4 vsrd = srd((const f16*)p.v.ptr + (int64_t)b * p.v.Himg * p.v.Wimg * p.v.ld + p.v.col0 + head * p.v.hstride, 0xffffffffu);
     const u32x4 tsrd = srd(p.table + (int64_t)head * p.tstride, (uint32_t)p.tstride * 4u);   // reads past the head's table return 0
-    const uint32_t krb = (uint32_t)(p.k.Wimg * (int)p.k.ld * 2), vrb = (uint32_t)(p.v.Wimg * (int)p.v.ld * 2);   // bytes per image row
+    // bytes per image row / per image column step (transposed view: a row step is one token, a column step Himg tokens)
+    const int ktx = p.k.transposed ? p.k.Himg : 1;
+    const uint32_t krb = (uint32_t)((p.k.transposed ? 1 : p.k.Wimg) * (int)p.k.ld * 2), vrb = (uint32_t)((p.k.transposed ? 1 : p.k.Wimg) * (int)p.v.ld * 2);
     const int kcol = wave_u & 1, krow = wave_u >> 1;     // this wave's DMA pieces: key rows krow and krow + 2 of a chunk, column half kcol
     // s_nop 4: SGPR operands may come straight from SALU / readfirstlane (5 wait states before a VMEM instruction reads them)
 #define ROWS_DMA(m0v, voff, rsrc, soff) \
@@ -172,8 +182,8 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         const int ln = lane_id();
         const int kx = 16 * kcol + (ln >> 2), s3 = ln & 3;                        // key column inside the 32-wide strip, 16-B segment
         int ox = wx * p.k.ww + 32 * sk + kx + p.k.shx; if (ox >= p.k.Wimg) ox -= p.k.Wimg;
-        const uint32_t vk = (uint32_t)((ox * (int)p.k.ld + (s3 ^ ((kx >> 2) & 3)) * 8) * 2);    // XOR swizzle on the source side
-        const uint32_t vv = (uint32_t)((ox * (int)p.v.ld + s3 * 8) * 2);
+        const uint32_t vk = (uint32_t)((ox * ktx * (int)p.k.ld + (s3 ^ ((kx >> 2) & 3)) * 8) * 2);    // XOR swizzle on the source side
+        const uint32_t vv = (uint32_t)((ox * ktx * (int)p.v.ld + s3 * 8) * 2);
 #pragma unroll
         for (int j = 0; j < KBUF / (RW * 1024); ++j) {
             const int q = wave_u + j * RW;                                           // piece: keys 16*q .. 16*q+15 = row q >> 1, half q & 1
@@ -182,10 +192,14 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
             ROWS_DMA(mk, vk, ksrd, (uint32_t)oy * krb);
             ROWS_DMA(mv, vv, vsrd, (uint32_t)oy * vrb);
         }
-        if (wave_u * 64 < win_n4) {
-            const uint32_t vt = (uint32_t)ln * 16u;
-            const uint32_t mt = lds0 + TOFF + (uint32_t)par * TBUF + wave_u * 1024;
-            ROWS_DMA(mt, vt, tsrd, (uint32_t)(window_lo(sk, hk0) * 4 + wave_u * 1024));
+#pragma unroll
+        for (int j = 0; j < TB / (RW * 1024); ++j) {
+            const int piece = wave_u + j * RW;
+            if (piece * 64 < win_n4) {
+                const uint32_t vt = (uint32_t)ln * 16u;
+                const uint32_t mt = lds0 + TOFF + (uint32_t)par * TB + piece * 1024;
+                ROWS_DMA(mt, vt, tsrd, (uint32_t)(window_lo(sk, hk0) * 4 + piece * 1024));
+            }
         }
     };
 #ifdef ROWS_STAGGER
@@ -238,7 +252,7 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         if (!active) continue;
         const uint32_t par = (uint32_t)(ch & 1) * KBUF;
         // scalar part of the bias address of (tile 0, key row hk_c), advanced by the statement row by row
-        uint32_t sb = (uint32_t)(ch & 1) * TBUF + 4 * (R0 + (hk_c - hq0) * D + 32 * (sk_c - sg) - window_lo(sk_c, hk_c));
+        uint32_t sb = (uint32_t)(ch & 1) * TB + 4 * (R0 + (hk_c - hq0) * D + 32 * (sk_c - sg) - window_lo(sk_c, hk_c));
         // region labels of the 2 x 16-key bands of the chunk's key rows (ops.py:76-157; bands are aligned to 16 on this path)
         uint32_t ids = 0;
         if constexpr (BORDER) {
@@ -255,7 +269,7 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
 #ifdef ROWS_ABL_REPEAT   // timing experiment: the rows of chunk 0 ROWS_ABL_REPEAT times, no other chunks (results are wrong)
         if (ch > 0) continue;
         for (int rep_ = 0; rep_ < ROWS_ABL_REPEAT; ++rep_) {
-        rs = 0; sb = (uint32_t)(ch & 1) * TBUF + 4 * (R0 + (hk_c - hq0) * D + 32 * (sk_c - sg) - window_lo(sk_c, hk_c));
+        rs = 0; sb = (uint32_t)(ch & 1) * TB + 4 * (R0 + (hk_c - hq0) * D + 32 * (sk_c - sg) - window_lo(sk_c, hk_c));
 #endif
         DBG_T(t_c3);
         DBG_ADD(3, t_c3 - t_c2);
@@ -267,6 +281,19 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
             int done = 0;
             const int rs_u = __builtin_amdgcn_readfirstlane(rs), nochk_u = __builtin_amdgcn_readfirstlane(nochk);
             if (prime) {
+            } else if constexpr (BORDER && D32) {
+                uint32_t t0, t1, t2;
+                asm volatile(ATTN_ROWS4_MASK1_D32
+                             : [o0] "+v"(O0), [o1] "+v"(O1), [l0] "+v"(l0), [l1] "+v"(l1), [sb] "+s"(sb), [done] "=s"(done), [t0] "=&s"(t0), [t1] "=&s"(t1), [t2] "=&s"(t2)
+                             : [ka0] "v"(ka0), [va] "v"(va), [bl] "v"(bl), [q00] "v"(q00), [q01] "v"(q01), [q10] "v"(q10), [q11] "v"(q11), [nm0] "v"(nm0), [nm1] "v"(nm1),
+                               [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par), [nochk] "s"(nochk_u), [ids] "s"(ids), [idq0] "v"(idq0), [idq1] "v"(idq1)
+                             : ATTN_ROWS_CLOBBER);
+            } else if constexpr (D32) {
+                asm volatile(ATTN_ROWS4_MASK0_D32
+                             : [o0] "+v"(O0), [o1] "+v"(O1), [l0] "+v"(l0), [l1] "+v"(l1), [sb] "+s"(sb), [done] "=s"(done)
+                             : [ka0] "v"(ka0), [va] "v"(va), [bl] "v"(bl), [q00] "v"(q00), [q01] "v"(q01), [q10] "v"(q10), [q11] "v"(q11), [nm0] "v"(nm0), [nm1] "v"(nm1),
+                               [d4] "s"(d4), [rs] "s"(rs_u), [par] "s"(par), [nochk] "s"(nochk_u)
+                             : ATTN_ROWS_CLOBBER);
             } else if constexpr (BORDER) {
                 uint32_t t0, t1, t2;
                 asm volatile(ATTN_ROWS4_MASK1
@@ -332,6 +359,7 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r) { mx0 = fmaxf(mx0, S0[r]); mx1 = fmaxf(mx1, S1[r]); }
                 }
+                if constexpr (D32) { mx0 += nm0; mx1 += nm1; }   // (the fragments carry no offset slot: relative to the current offsets)
                 mx0 = fmaxf(mx0, xhalf(mx0));
                 mx1 = fmaxf(mx1, xhalf(mx1));
                 float d0 = fmaxf(0.f, __builtin_ceilf(mx0) - ROWS_REST), d1 = fmaxf(0.f, __builtin_ceilf(mx1) - ROWS_REST);
@@ -339,16 +367,23 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
                     // offsets within ROWS_EXTRA of the level where the overflow test becomes unnecessary go there right away
                     // (the row maximum then rests at 2^(ROWS_REST - ROWS_EXTRA) at worst: ample for fp16 weights)
                     const float msafe = (float)msafe_i;
-                    const float t0 = (float)q01[7], t1 = (float)q11[7], u0 = xhalf(t0), u1 = xhalf(t1);
-                    float m0 = d0 - (half ? t0 : u0), m1 = d1 - (half ? t1 : u1);   // the new offsets
+                    float m0, m1;   // the new offsets
+                    if constexpr (D32) {
+                        m0 = d0 - nm0; m1 = d1 - nm1;
+                    } else {
+                        const float t0 = (float)q01[7], t1 = (float)q11[7], u0 = xhalf(t0), u1 = xhalf(t1);
+                        m0 = d0 - (half ? t0 : u0); m1 = d1 - (half ? t1 : u1);
+                    }
                     if (m0 < msafe && m0 >= msafe - ROWS_EXTRA) { d0 += msafe - m0; m0 = msafe; }
                     if (m1 < msafe && m1 >= msafe - ROWS_EXTRA) { d1 += msafe - m1; m1 = msafe; }
                     nochk = __builtin_amdgcn_ballot_w64(!(m0 >= msafe && m1 >= msafe)) == 0;
                 }
-                if (half) { q01[7] = (f16)((float)q01[7] - d0); q11[7] = (f16)((float)q11[7] - d1); }   // slot 31 holds -m
+                if constexpr (D32) { nm0 -= d0; nm1 -= d1; }
+                else if (half) { q01[7] = (f16)((float)q01[7] - d0); q11[7] = (f16)((float)q11[7] - d1); }   // slot 31 holds -m
                 const float f0 = __builtin_amdgcn_exp2f(-d0), f1 = __builtin_amdgcn_exp2f(-d1);
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { O0[r] *= f0; O1[r] *= f1; }
+                if constexpr (D32) { l0 *= f0; l1 *= f1; }
             }
             rs = done;
         }
@@ -371,14 +406,14 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
         int rid;
         const int lane = lane_id(), half = lane >> 5, l31 = lane & 31;
         const int wq = 32 * sg + l31;
-        const float mq0 = -xhalf((float)q01[7]), mq1 = -xhalf((float)q11[7]);   // lower half-wave <- the upper one's slot 31
+        const float mq0 = D32 ? -nm0 : -xhalf((float)q01[7]), mq1 = D32 ? -nm1 : -xhalf((float)q11[7]);   // lower half-wave <- the upper one's slot 31
         locate(p.q, b, wy, wx, hq0 * p.q.ww + wq, row, rid);
-        float l = ones_row(O0, p.ones_col, half);
+        float l = D32 ? l0 + xhalf(l0) : ones_row(O0, p.ones_col, half);
         if (poison) l = __builtin_nanf("");
         store_o(p, O0, 1.0f / l, row, head, half);
         if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + row] = mq0 + __builtin_amdgcn_logf(l);
         locate(p.q, b, wy, wx, (hq0 + 1) * p.q.ww + wq, row, rid);
-        l = ones_row(O1, p.ones_col, half);
+        l = D32 ? l1 + xhalf(l1) : ones_row(O1, p.ones_col, half);
         if (poison) l = __builtin_nanf("");
         store_o(p, O1, 1.0f / l, row, head, half);
         if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + row] = mq1 + __builtin_amdgcn_logf(l);
@@ -389,7 +424,8 @@ __global__ __launch_bounds__(RW * 64, 4) void attn_rows_kernel(GrlAttnArgs p) {
 
 // 1 when the geometry is served by the row-streaming kernel (the caller has already checked the lazy-offset preconditions)
 bool grl_attn_rows_supported(const GrlAttnArgs& p) {
-    if ((p.q.ww % 32) || (p.k.ww % 32) || (p.q.wh % 2) || (p.k.wh % RROWS) || p.ones_col < 0) return false;
+    const bool d32 = p.head_dim == 32;   // no spare slot: offset and denominator on the VALU (attn_rows_kernel<true>)
+    if ((p.q.ww % 32) || (p.k.ww % 32) || (p.q.wh % 2) || (p.k.wh % RROWS) || (p.ones_col < 0) != d32) return false;
     if (p.masked && ((p.k.shx & 15) || (p.q.shx & 15))) return false;
     const RowsGeom g = rows_geom(p);
     const int D = p.q.ww + p.k.ww - 1;
@@ -397,7 +433,7 @@ bool grl_attn_rows_supported(const GrlAttnArgs& p) {
         int hqa, hqb, sga, sgb;
         rows_span(g, qs, hqa, hqb, sga, sgb);
         const int n = (hqb - hqa + RROWS - 1) * D + 32 * (sgb - sga) + 63 + 3;
-        if (n > TBUF / 4) return false;
+        if (n > rows_tbuf(d32) / 4) return false;
     }
     return true;
 }
@@ -415,10 +451,11 @@ int grl_attn_rows_launch(const GrlAttnArgs& p, hipStream_t st) {
     const RowsGeom g = rows_geom(p);
     const int64_t grid = (int64_t)g.nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
-    auto kfn = attn_rows_kernel;
-    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, ROWS_LDS);
+    const bool d32 = p.head_dim == 32;
+    auto kfn = d32 ? attn_rows_kernel<true> : attn_rows_kernel<false>;
+    hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, rows_lds(d32));
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(RW * 64), ROWS_LDS, st, p);
+    hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(RW * 64), rows_lds(d32), st, p);
     GRL_CHECK_LAUNCH();
     return 0;
 }

@@ -44,7 +44,7 @@ __device__ __forceinline__ void locate(const GrlTokenGrid& g, int b, int wy, int
     const int ry = wy * g.wh + hq, rx = wx * g.ww + wq;
     int oy = ry + g.shy; if (oy >= g.Himg) oy -= g.Himg;
     int ox = rx + g.shx; if (ox >= g.Wimg) ox -= g.Wimg;
-    row = ((int64_t)b * g.Himg + oy) * g.Wimg + ox;
+    row = g.transposed ? ((int64_t)b * g.Wimg + ox) * g.Himg + oy : ((int64_t)b * g.Himg + oy) * g.Wimg + ox;
     rid = 3 * region1d(ry, g.Himg, g.wh, g.shy) + region1d(rx, g.Wimg, g.ww, g.shx);
 }
 

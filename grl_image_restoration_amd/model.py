@@ -473,14 +473,26 @@ class GRL(nn.Module):
                       mlp_hp=HP)
 
         # --- relative-position bias tables in the kernel's exp2 domain ---
-        def table(m: _Affine, win, df):
+        # A (query window, key window) pair that is not 32-aligned as it stands but is so with the image axes swapped -- the
+        # 128x64 stripes / 32x16 anchors of every other block of the dn geometry -- is launched on the transposed view of its
+        # grids (GrlTokenGrid.transposed) with the transposed table: row-streaming kernel instead of the generic one.
+        def table(m: _Affine, win, df, q_win, k_win, q_sh, k_sh, masked, d):
             coords = tables.coords_table(win, df, device=dev)
             bias = tables.bias_rows(m.cpb_mlp[0].weight.to(dev), m.cpb_mlp[0].bias.to(dev), m.cpb_mlp[2].weight.to(dev), coords)
-            return tables.kernel_table(bias)
+            sw = lambda t: (t[1], t[0])
+            tr = (not hi and os.environ.get("GRL_ATTN_TRANSPOSE", "1") != "0"
+                  and not ops.attention_rows_ok(q_win, k_win, q_sh, k_sh, masked, d)
+                  and ops.attention_rows_ok(sw(q_win), sw(k_win), sw(q_sh), sw(k_sh), masked, d))
+            if tr:
+                bias = ops.transpose_table(bias, q_win, k_win)
+            return tables.kernel_table(bias), tr
 
-        pk["tab_w"] = table(a.window_attn.attn_transform, geo.window, 1)
-        pk["tab_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df)
-        pk["tab_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df)
+        wsh = (geo.window_shift, geo.window_shift)
+        pk["tab_w"], pk["tr_w"] = table(a.window_attn.attn_transform, geo.window, 1, geo.window, geo.window, wsh, wsh, geo.window_shift > 0, d_w)
+        pk["tab_a2w"], pk["tr_a2w"] = table(a.stripe_attn.attn_transform1, geo.stripe, geo.df, geo.anchor_stripe, geo.stripe,
+                                            geo.anchor_shift_size, geo.stripe_shift_size, geo.stripe_shift, d_s)
+        pk["tab_w2a"], pk["tr_w2a"] = table(a.stripe_attn.attn_transform2, geo.stripe, geo.df, geo.stripe, geo.anchor_stripe,
+                                            geo.stripe_shift_size, geo.anchor_shift_size, geo.stripe_shift, d_s)
         pk.update(ceil_w=tables.lazy_ceil(sc_w, pk["tab_w"]), ceil_a2w=tables.lazy_ceil(sc_1, pk["tab_a2w"]),
                   ceil_w2a=tables.lazy_ceil(sc_2, pk["tab_w2a"]))
         assert pk["tab_w"].shape[1] == (table_rows(geo.window, geo.window) + 3) // 4 * 4
@@ -644,9 +656,10 @@ class GRL(nn.Module):
         ws, sh = geo.window, geo.window_shift
         TG = ops.TokenGrid
         ls = lse if lse is not None else (None, None, None)
+        tr = lambda key, *gs: tuple(g.T() for g in gs) if pk.get(key) else gs    # transposed view where the plan chose it
         ops.attention(
-            TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w, H, W, ws[0], ws[1], sh, sh),
-            TG(qkv, 2 * nh_w, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh),
+            *tr("tr_w", TG(qkv, 0, H, W, ws[0], ws[1], sh, sh), TG(qkv, nh_w, H, W, ws[0], ws[1], sh, sh),
+                TG(qkv, 2 * nh_w, H, W, ws[0], ws[1], sh, sh), TG(att, 0, H, W, ws[0], ws[1], sh, sh)),
             B=B, nh=nh_w, table=pk["tab_w"], masked=sh > 0,
             ones_col=d_w if d_w < 32 else -1, head_dim=d_w, k_one31=pk["one_w"], lazy_floor=pk["floor_w"], lse=ls[0], lazy_ceil=pk.get("ceil_w"),
             q_lo=qkv_lo, k_lo=qkv_lo, v_lo=qkv_lo,
@@ -660,10 +673,10 @@ class GRL(nn.Module):
         g_a = TG(anc, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         g_y = TG(y, 0, Ha, Wa, ast[0], ast[1], ass[0], ass[1])
         oc = d_s if d_s < 32 else -1
-        ops.attention(g_a, g_k, g_v, g_y, B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
+        ops.attention(*tr("tr_a2w", g_a, g_k, g_v, g_y), B=B, nh=nh_s, table=pk["tab_a2w"], masked=geo.stripe_shift,
                       ones_col=oc, head_dim=d_s, k_one31=pk["one_s"], lazy_floor=pk["floor_a2w"], lse=ls[1], lazy_ceil=pk.get("ceil_a2w"),
                       q_lo=anc_lo, k_lo=qkv_lo, v_lo=qkv_lo, o_lo=y_lo)
-        ops.attention(g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1]), B=B, nh=nh_s, table=pk["tab_w2a"],
+        ops.attention(*tr("tr_w2a", g_q, g_a, g_y, TG(att, nh_w, H, W, st[0], st[1], ss[0], ss[1])), B=B, nh=nh_s, table=pk["tab_w2a"],
                       masked=geo.stripe_shift, ones_col=oc, head_dim=d_s, k_one31=pk["one_s"],
                       lazy_floor=pk["floor_w2a"], lse=ls[2], q_lo=qkv_lo, k_lo=anc_lo, v_lo=y_lo, lazy_ceil=pk.get("ceil_w2a"))
         return y

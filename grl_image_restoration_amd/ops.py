@@ -420,6 +420,11 @@ class TokenGrid:
     ww: int
     shy: int = 0
     shx: int = 0
+    transposed: bool = False   # the grid is the transposed view of a (Wimg x Himg) row-major image (GrlTokenGrid.transposed)
+
+    def T(self) -> "TokenGrid":
+        """The same tokens seen through the transposed image: attention commutes with it (bias table transposed by the caller)."""
+        return TokenGrid(self.t, self.slot, self.Wimg, self.Himg, self.ww, self.wh, self.shx, self.shy, not self.transposed)
 
     def c(self) -> L.GrlTokenGrid:
         t = self.t
@@ -427,14 +432,35 @@ class TokenGrid:
         if t.dim() == 3:  # head planes
             assert t.shape[2] == 32 and t.is_contiguous()
             return L.GrlTokenGrid(ptr=C.c_void_p(t.data_ptr() + self.slot * t.stride(0) * t.element_size()), ld=32, hstride=t.stride(0),
-                                  col0=0, Himg=self.Himg, Wimg=self.Wimg, wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx)
+                                  col0=0, Himg=self.Himg, Wimg=self.Wimg, wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx,
+                                  transposed=int(self.transposed))
         assert t.dim() == 2
         return L.GrlTokenGrid(ptr=_ptr(t), ld=t.stride(0), hstride=32, col0=self.slot * 32, Himg=self.Himg, Wimg=self.Wimg,
-                              wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx)
+                              wh=self.wh, ww=self.ww, shy=self.shy, shx=self.shx, transposed=int(self.transposed))
 
     @property
     def tokens(self) -> int:
         return self.t.shape[-2] if self.t.dim() == 3 else self.t.shape[0]
+
+
+def attention_rows_ok(q_win, k_win, q_shift, k_shift, masked: bool, head_dim: int) -> bool:
+    """Would grl_attention_fwd serve this (query window, key window) geometry with the row-streaming kernel
+    (grl_attention_rows_geometry_ok)?  Plan-time question: a geometry that is not 32-aligned may be so transposed."""
+    def grid(win, sh):
+        return L.GrlTokenGrid(ptr=None, ld=32, hstride=32, col0=0, Himg=win[0], Wimg=win[1], wh=win[0], ww=win[1], shy=sh[0], shx=sh[1], transposed=0)
+    gq, gk = grid(q_win, q_shift), grid(k_win, k_shift)
+    args = L.GrlAttnArgs(q=gq, k=gk, v=gk, o=gq, B=1, nh=1, nwy=1, nwx=1, table=None,
+                         trows=(q_win[0] + k_win[0] - 1) * (q_win[1] + k_win[1] - 1), tstride=0, masked=int(masked),
+                         ones_col=head_dim if head_dim < 32 else -1, head_dim=head_dim, out_dtype=L.DT_F16, k_one31=0)
+    return bool(L.lib().grl_attention_rows_geometry_ok(C.byref(args)))
+
+
+def transpose_table(bias: torch.Tensor, q_win, k_win) -> torch.Tensor:
+    """(rows, nh) relative-position bias of a (query window, key window) pair -> the rows of the transposed pair:
+    row (dy, dx) of the (q_wh + k_wh - 1) x (q_ww + k_ww - 1) offset grid becomes row (dx, dy)."""
+    Dy, Dx = q_win[0] + k_win[0] - 1, q_win[1] + k_win[1] - 1
+    assert bias.shape[0] == Dy * Dx
+    return bias.view(Dy, Dx, -1).transpose(0, 1).reshape(Dy * Dx, -1).contiguous()
 
 
 def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int, nh: int, table: torch.Tensor,
@@ -469,7 +495,7 @@ def attention(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, *, B: int,
                          head_dim=head_dim, out_dtype=_KIND[o.t.dtype], k_one31=int(k_one31), lazy_floor=_ptr(lazy_floor),
                          lse=_ptr(lse), lse_stride=lse.stride(0) if lse is not None else 0,
                          q_lo=twin(q, q_lo), k_lo=twin(k, k_lo), v_lo=twin(v, v_lo), o_lo=twin(o, o_lo), lazy_ceil=_ptr(lazy_ceil))
-    with _timed("attention"):
+    with _timed(f"attention q{q.wh}x{q.ww} k{k.wh}x{k.ww}" if _PROFILE is not None else "attention"):
         L.check(L.lib().grl_attention_fwd(L.stream_ptr(), C.byref(args)), "grl_attention_fwd")
     return o.t
 

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 17
+#define GRL_ABI_VERSION 18
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -257,6 +257,13 @@ typedef struct GrlTokenGrid {
     int32_t Himg, Wimg;   /* token image size                                                       */
     int32_t wh, ww;       /* window (stripe) size on this grid                                      */
     int32_t shy, shx;     /* cyclic shift (rolled[y] = orig[(y+sh) % H]); 0 = none                  */
+    int32_t transposed;   /* 0: token (y, x) of image b is row (b*Himg + y)*Wimg + x of the matrix.  */
+                          /* 1: the grid is the TRANSPOSED VIEW of a (Wimg x Himg) row-major image:  */
+                          /* token (y, x) is row (b*Wimg + x)*Himg + y.  Attention is invariant under */
+                          /* a joint transposition of the image axes (with wh/ww, shy/shx swapped and */
+                          /* the bias table transposed by the caller), which brings a 128x64 stripe   */
+                          /* with 32x16 anchors onto the 32-aligned fast path as 64x128 / 16x32.      */
+                          /* All four grids of a launch must agree.  Forward only.                    */
 } GrlTokenGrid;
 
 typedef struct GrlAttnArgs {
@@ -286,6 +293,11 @@ typedef struct GrlAttnArgs {
 } GrlAttnArgs;
 
 int grl_attention_fwd(void* stream, const GrlAttnArgs* args);
+
+/* 1 when grl_attention_fwd would serve these arguments with the row-streaming kernel (csrc/attention_rows.hip): 32-aligned
+ * window widths, table window within its LDS buffer, 16-aligned shifts.  Reads the geometry fields, head_dim, ones_col and
+ * masked only (pointers may be NULL): lets the host choose between a grid and its transposed view at plan time. */
+int grl_attention_rows_geometry_ok(const GrlAttnArgs* args);
 
 /* ---------------------------------------------------------------------------------------------
  * 3x3 convolution (stride 1, zero pad 1) on channels-last token matrices, fused epilogue.

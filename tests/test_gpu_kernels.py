@@ -437,10 +437,19 @@ CASES = [
     ("a2w_48x96_df4", "a2w", (96, 96), (48, 96), (24, 48), 4, 3, 30),
     ("w2a_48x96_df4", "w2a", (96, 96), (48, 96), (24, 48), 4, 3, 30),
     ("w2a_groups_shift_one_axis", "w2a", (32, 32), (8, 32), (4, 0), 4, 3, 30),
+    # head_dim 32 (GRL-Small) on 32-aligned shapes: row-streaming kernel with offset / denominator on the VALU
+    ("win32_shift_d32", "w", (64, 64), (32, 32), (16, 16), 1, 2, 32),
+    ("a2w_dn_d32", "a2w", (128, 128), (64, 128), (32, 64), 4, 2, 32),     # dn geometry: 16x32 anchors, 64x128 stripes
+    ("w2a_dn_d32", "w2a", (128, 128), (64, 128), (32, 64), 4, 2, 32),
+    ("a2w_64_df2_d32_noshift", "a2w", (64, 128), (64, 64), (0, 0), 2, 2, 32),
+    # tall stripes (every other block of the dn geometry): 32-aligned only on the transposed view of the grids
+    ("a2w_dn_tall_d32", "a2w", (128, 128), (128, 64), (64, 32), 4, 2, 32),
+    ("w2a_dn_tall_d32", "w2a", (128, 128), (128, 64), (64, 32), 4, 2, 32),
+    ("w2a_tall_d30", "w2a", (128, 64), (128, 32), (64, 16), 2, 3, 30),
 ]
 
 
-def _attention_case(case, offset, planes, scale_hi, out_dtype=torch.float16, want_lse=False):
+def _attention_case(case, offset, planes, scale_hi, out_dtype=torch.float16, want_lse=False, transposed=False):
     """offset: 'lazy'   -- running offset in head-dim slot 31 (k carries 1.0 there), fast kernel for 32-aligned shapes;
                'online' -- no slot-31 contract: generic kernel, ordinary online softmax."""
     from grl_image_restoration_amd import ops, tables
@@ -471,6 +480,8 @@ def _attention_case(case, offset, planes, scale_hi, out_dtype=torch.float16, wan
     bias = torch.rand(rows, nh, generator=g) * 16
     tab_k = tables.kernel_table(bias)                             # what the kernel receives (reversed, padded)
     tab = torch.flip(tab_k[:, : tab_k.shape[1] - (-rows) % 4], dims=(1,))  # forward order for the reference
+    if transposed:   # the launch sees the transposed view of every grid and the transposed table; the reference does not change
+        tab_k = tables.kernel_table(ops.transpose_table(bias, qg[2], kg[2]))
     masked = shift[0] > 0 or shift[1] > 0
     if mode == "w":
         index = O.rel_index(win)
@@ -512,11 +523,14 @@ def _attention_case(case, offset, planes, scale_hi, out_dtype=torch.float16, wan
     qd, kd, vd = lay(qs), lay(ks), lay(vs)
     out = lay(torch.zeros(B * qg[0] * qg[1], nh * 32, dtype=out_dtype))
     lse = torch.zeros(nh, B * qg[0] * qg[1], dtype=torch.float32, device=dev) if want_lse else None
+    grids = (TG(qd, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
+             TG(kd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
+             TG(vd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
+             TG(out, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]))
+    if transposed:
+        grids = tuple(g_.T() for g_ in grids)
     ops.attention(
-        TG(qd, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
-        TG(kd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
-        TG(vd, 0, kg[0], kg[1], kg[2][0], kg[2][1], kg[3][0], kg[3][1]),
-        TG(out, 0, qg[0], qg[1], qg[2][0], qg[2][1], qg[3][0], qg[3][1]),
+        *grids,
         B=B, nh=nh, table=tab_k.to(dev), masked=masked, ones_col=d if ones else -1, head_dim=d,
         k_one31=one31, lazy_floor=tables.lazy_floor(scale).to(dev) if offset == "lazy" else None, lse=lse,
         lazy_ceil=tables.lazy_ceil(scale, tab_k).to(dev) if offset == "lazy" else None,
@@ -542,7 +556,7 @@ def test_attention_vs_oracle_indexing(case, offset, planes):
 
 @pytest.mark.parametrize("offset", ["lazy", "online"])
 @pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("win32_shift", "win8_shift", "a2w_64_df2", "w2a_64_df2", "a2w_64_df4_tiny",
-                                                               "w2a_64x128_df2", "a2w_48x96_df4", "w2a_8x16_df4")],
+                                                               "w2a_64x128_df2", "a2w_48x96_df4", "w2a_8x16_df4", "win32_shift_d32", "a2w_dn_d32", "w2a_dn_d32")],
                          ids=lambda c: c[0])
 def test_attention_logit_scale_at_clamp(case, offset):
     """logit scales 40 .. 100 (the clamp exp(min(., ln 100)), efficient.py:39): logits span +-144 in the log2 domain, the
@@ -550,7 +564,24 @@ def test_attention_logit_scale_at_clamp(case, offset):
     _attention_case(case, offset, True, scale_hi=True)
 
 
-@pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("win32_shift", "w2a_64_df2", "a2w_48x96_df4", "win12_ragged")], ids=lambda c: c[0])
+@pytest.mark.parametrize("planes", [False, True])
+@pytest.mark.parametrize("offset", ["lazy", "online"])
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("a2w_dn_tall_d32", "w2a_dn_tall_d32", "w2a_tall_d30", "win12_ragged", "win32_shift",
+                                                               "a2w_48x96_df4", "w2a_8x16_df4")], ids=lambda c: c[0])
+def test_attention_transposed_view(case, offset, planes):
+    """GrlTokenGrid.transposed: the same attention launched on the transposed view of its grids with the transposed bias
+    table (row-streaming kernel for the tall stripes, generic kernel for the ragged shapes) equals the reference."""
+    from grl_image_restoration_amd import ops
+    name, mode, _, win, shift, df, nh, d = case
+    if name.endswith("tall_d32") and offset == "lazy":   # the point of the flag: these are only 32-aligned when transposed
+        awin, ash = (win[0] // df, win[1] // df), (shift[0] // df, shift[1] // df)
+        qw, kw, qs_, ks_ = (awin, win, ash, shift) if mode == "a2w" else (win, awin, shift, ash)
+        sw = lambda t: (t[1], t[0])
+        assert not ops.attention_rows_ok(qw, kw, qs_, ks_, True, d) and ops.attention_rows_ok(sw(qw), sw(kw), sw(qs_), sw(ks_), True, d)
+    _attention_case(case, offset, planes, scale_hi=False, transposed=True, want_lse=True, out_dtype=torch.float32 if name == "win12_ragged" else torch.float16)
+
+
+@pytest.mark.parametrize("case", [c for c in CASES if c[0] in ("win32_shift", "w2a_64_df2", "a2w_48x96_df4", "win12_ragged", "w2a_dn_d32")], ids=lambda c: c[0])
 def test_attention_fp32_output_and_lse(case):
     """fp32 output (split-precision path) and the log2-sum-exp2 side output (what the backward kernel re-normalises with)."""
     _attention_case(case, "lazy", True, scale_hi=False, out_dtype=torch.float32, want_lse=True)

@@ -35,7 +35,7 @@ def f32bits(x):
     return struct.unpack("<I", struct.pack("<f", x))[0]
 
 
-def gen(rows, mask, kstride=2048, abl=()):
+def gen(rows, mask, kstride=2048, abl=(), d32=False):
     """Two copies of the row loop in one statement: with the overflow test, and -- entered when %[nochk] != 0: the offsets of
     all the wave's queries are within 13.5 of the head's logit bound, nothing can trip -- without it (a per-row skip would be
     a taken branch per row)."""
@@ -44,10 +44,10 @@ def gen(rows, mask, kstride=2048, abl=()):
         L.append(f"s_mov_b32 %[t2], 0x{f32bits(-MASK_L2):08x}")    # +144.27: multiplied by -|id_k - id_q|
     L.append("s_cmp_lg_u32 %[nochk], 0")
     L.append("s_cbranch_scc1 200f")
-    L += body(rows, mask, kstride, abl, True, 0)
+    L += body(rows, mask, kstride, abl, True, 0, d32)
     L.append("s_branch 99f")
     L.append("200:")
-    L += body(rows, mask, kstride, abl + ("nocheck",), False, 100)
+    L += body(rows, mask, kstride, abl + ("nocheck",), False, 100, d32)
     if "nocheck" not in abl:
         L.append("s_branch 99f")
         for r in range(rows):
@@ -60,7 +60,12 @@ def gen(rows, mask, kstride=2048, abl=()):
     return L
 
 
-def body(rows, mask, kstride, abl, check, lb):
+def body(rows, mask, kstride, abl, check, lb, d32=False):
+    """d32: head_dim 32 fills all 32 slots of the Q / K fragments and of V, so the two things the spare slot 31 carries for
+    free elsewhere are done on the VALU: the running offset (-m per query, operands %[nm0] / %[nm1]) is added to the logits
+    (folded into the mask value where there is one), and the softmax denominator is summed from the packed fp16 weights
+    with v_dot2c_f32_f16 (exactly the values the PV product multiplies) into %[l0] / %[l1] after the row has passed the
+    overflow test."""
     L = []
     e = L.append
     lab = lambda n: str(lb + n)
@@ -120,14 +125,24 @@ def body(rows, mask, kstride, abl, check, lb):
                 for k in ks:
                     e(f"v_cvt_f32_i32 {v(KF + 2 * k)}, {v(KF + 2 * k)}")
                 for k in ks:
-                    e(f"v_mul_f32_e64 {v(KF + 2 * k)}, -|{v(KF + 2 * k)}|, %[t2]")
+                    if d32:
+                        e(f"v_fma_f32 {v(KF + 2 * k)}, -|{v(KF + 2 * k)}|, %[t2], %[nm{k // 2}]")
+                    else:
+                        e(f"v_mul_f32_e64 {v(KF + 2 * k)}, -|{v(KF + 2 * k)}|, %[t2]")
             e("s_nop 0")     # 12 VALU + this >= 12 states behind tile 0's last MFMA (one MFMA in between)
+        elif d32:
+            e(f"v_mov_b32 {v(KF)}, %[nm0]")
+            e(f"v_mov_b32 {v(KF + 2)}, %[nm1]")
+            e("s_nop 8")
         else:
             e("s_nop 10")
         for ti, S in enumerate((Z, Y)):
             if mask:
                 for i in range(8):
                     e(f"v_pk_add_f32 {v(S + 2 * i, 2)}, {v(S + 2 * i, 2)}, {v(KF + 4 * ti + (2 if i >= 4 else 0), 2)} op_sel_hi:[1,0]")
+            elif d32:
+                for i in range(8):
+                    e(f"v_pk_add_f32 {v(S + 2 * i, 2)}, {v(S + 2 * i, 2)}, {v(KF + 2 * ti, 2)} op_sel_hi:[1,0]")
             for i in range(16):
                 if "noexp" in abl:
                     e(f"v_mov_b32 {v(S + i)}, {v(S + i)}")
@@ -164,6 +179,10 @@ def body(rows, mask, kstride, abl, check, lb):
             e(f"v_mfma_f32_32x32x16_f16 %[o1], {v(VF + 4, 4)}, {v(Y + 4, 4)}, %[o1]")
         if "prio" in abl or "priopv" in abl:
             e("s_setprio 0")
+        if d32:
+            for j in range(8):
+                e(f"v_dot2c_f32_f16 %[l0], 0x3c003c00, {v(Z + j)}")
+                e(f"v_dot2c_f32_f16 %[l1], 0x3c003c00, {v(Y + j)}")
         e("s_add_u32 %[sb], %[sb], %[d4]")
     e(f"s_mov_b32 %[done], {rows}")
     return L
@@ -177,9 +196,10 @@ def main():
     abl = tuple(x for x in a.abl.split(",") if x)
     with open(a.out, "w") as f:
         f.write("// generated by tools/attn_asm/gen_attn_loop.py -- do not edit (regenerate: python3 tools/attn_asm/gen_attn_loop.py --out <this file>)\n")
-        for mask in (0, 1):
-            f.write(f"#define ATTN_ROWS4_MASK{mask} \\\n")
-            f.write(" \\\n".join('    "' + ln + '\\n"' for ln in gen(4, mask, abl=abl)) + "\n\n")
+        for d32 in (False, True):
+            for mask in (0, 1):
+                f.write(f"#define ATTN_ROWS4_MASK{mask}{'_D32' if d32 else ''} \\\n")
+                f.write(" \\\n".join('    "' + ln + '\\n"' for ln in gen(4, mask, abl=abl, d32=d32)) + "\n\n")
         f.write("#define ATTN_ROWS_CLOBBER " + ", ".join(f'"v{i}"' for i in range(64)) + ', "vcc", "scc", "memory"\n')
 
 

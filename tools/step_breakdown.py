@@ -10,14 +10,16 @@ from grl_image_restoration_amd import GRL, baseline_config, ops
 import math
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 B = int(args[0]) if args else 4
-m = GRL(**baseline_config(3)).eval().cuda()
+cfg_i = int(args[1]) if len(args) > 1 else 3          # BASELINE config (2: Small denoise 128^2, 3: Base x4 256^2, 4: Base deblur 384^2)
+side = {2: 128, 4: 384}.get(cfg_i, 256)
+m = GRL(**baseline_config(cfg_i)).eval().cuda()
 if "--trained" in sys.argv:   # logit scales around the clamp, the draw of bench.py's trained_scales leg
     gs = torch.Generator().manual_seed(7)
     with torch.no_grad():
         for n, p_ in m.named_parameters():
             if n.endswith("logit_scale"):
                 p_.copy_((math.log(100.0) + 0.3 * torch.randn(p_.shape, generator=gs)).cuda())
-x = torch.rand(B, 3, 256, 256, device="cuda")
+x = torch.rand(B, 3, side, side, device="cuda")
 with torch.no_grad():
     for _ in range(2):
         m(x)
@@ -29,7 +31,7 @@ with torch.no_grad():
     e1.record()
     prof = ops.profile_end()
 tot = e0.elapsed_time(e1)
-print(f"B={B}: forward {tot:.2f} ms (single stream)")
+print(f"config {cfg_i}, B={B} x {side}^2, precision {m.precision}: forward {tot:.2f} ms (single stream)")
 acc = 0.0
 for k, v in sorted(prof.items(), key=lambda kv: -sum(kv[1])):
     s = sum(v)
