@@ -39,7 +39,7 @@ namespace {
 
 constexpr int QT = 2;            // query tiles per wave
 constexpr int KC = 256;          // keys per LDS chunk
-constexpr int VROW = KC * 2 + 8; // V^T row stride in bytes (pad: conflict-free ds_read_b64)
+constexpr int VROW = KC * 2 + 8; // V^T row stride in bytes of the round-2 fast kernel's transposed staging (pad: conflict-free ds_read_b64)
 constexpr float P_TOP = 14.0f;           // log2 of the largest fp16 weight the kernels produce (fp16 max is 2^16)
 constexpr float LAZY_REST = 4.0f;        // lazy offset: after a rescale the tile maximum sits in (2^3, 2^4]
                                          // (measured: 6 -> 4 costs nothing in parity and saves 9 % at logit scale 100; 2 loses parity margin)
@@ -51,6 +51,21 @@ constexpr unsigned short F16_INF = 0x7C00;
 // ------------------------------------------------------------------------------------------------
 // SPLIT: split-precision operands (precision "high"): S = q_hi k_hi + q_lo k_hi + q_hi k_lo, O = P v_hi + P v_lo with the fp16
 // residual planes q_lo / k_lo / v_lo (3 + 2 MFMA terms instead of 1 + 1: ~22-bit operands; P stays fp16).
+typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
+typedef __fp16 tr_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+// V^T fragments of a 32-key tile staged row major (64 B per key) through the LDS transpose read (same lane map as
+// csrc/attention_rows.hip): rows = head dim l31; k-slot e of step s <-> key 16*s + 8*(e>>2) + 4*half + (e&3)
+__device__ __forceinline__ void vt_frags(const char* tile, int lane, f16x8 (&vf)[2]) {
+    const int half = lane >> 5;
+    const char* a = tile + (4 * half + ((lane & 15) >> 2)) * 64 + (16 * ((lane >> 4) & 1) + 4 * (lane & 3)) * 2;
+    typedef __attribute__((address_space(3))) tr_h4* lp;
+    const tr_h4 r0 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(a)), r1 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(a + 512));
+    const tr_h4 r2 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(a + 1024)), r3 = __builtin_amdgcn_ds_read_tr16_b64_v4f16((lp)(a + 1536));
+    vf[0] = __builtin_bit_cast(f16x8, __builtin_shufflevector(r0, r1, 0, 1, 2, 3, 4, 5, 6, 7));
+    vf[1] = __builtin_bit_cast(f16x8, __builtin_shufflevector(r2, r3, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
 template <bool ONES, bool KW4, bool SPLIT>
 __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -69,18 +84,18 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
 
     // ---- LDS carve ----
     float* tab = (float*)smem;                                   // trows
-    char* Ks = smem + (((size_t)p.trows * 4 + 15) & ~(size_t)15); // KC x 64 B
-    char* Vt = Ks + KC * 64;                                     // 32 x VROW
-    int* koff = (int*)(Vt + 32 * VROW);                          // KC
-    unsigned char* kreg = (unsigned char*)(koff + KC);           // KC
-    char* Ks2 = (char*)(kreg + KC);                              // SPLIT: residual planes, same layouts
-    char* Vt2 = Ks2 + KC * 64;
+    const int kcap = min(KC, (Nk + 31) & ~31);                   // key slots staged at a time (small windows: more workgroups per CU)
+    char* Ks = smem + (((size_t)p.trows * 4 + 15) & ~(size_t)15); // kcap x 64 B (16-B slots XOR-swizzled)
+    char* Vs = Ks + kcap * 64;                                   // kcap x 64 B row major: V^T fragments come out of ds_read_b64_tr_b16
+    int* koff = (int*)(Vs + kcap * 64);                          // kcap
+    unsigned char* kreg = (unsigned char*)(koff + kcap);         // kcap
+    char* Ks2 = (char*)(kreg + kcap);                            // SPLIT: residual planes, same layouts
+    char* Vs2 = Ks2 + kcap * 64;
 
     load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
 
     // does this window need the mask path at all?  (window touches the wrapped border, or ragged keys)
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
-    const bool need_mask = border || (Nk & 31) != 0;
 
     // ---- per-lane query state ----
     int U[QT], idq[QT];
@@ -121,34 +136,46 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
         const int ntiles = (klen + 31) >> 5;
         __syncthreads();
         // ---- stage K rows (swizzled 16-B slots) and V^T; per-key table offset + region id ----
-        for (int i = tid; i < ntiles * 32 * 4; i += nthreads) {
-            const int kk = i >> 2, seg = i & 3;
+        // (one thread per key: a single locate() -- two integer divisions -- per key instead of per 16-B piece; V goes in row
+        // major like K, one 16-B write per piece: the transposed copy cost eight 2-byte LDS writes per piece)
+        for (int kk = tid; kk < ntiles * 32; kk += nthreads) {
             const int n = k0 + kk;
             const bool valid = n < Nk;
             int64_t row; int rid;
             locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
-            f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = {0, 0, 0, 0, 0, 0, 0, 0};
-            if (valid) {
-                kv = *(const f16x8*)((const f16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
-                vv = *(const f16x8*)((const f16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
-            }
-            *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
+            const f16* ksrc = (const f16*)p.k.ptr + row * p.k.ld + p.k.col0 + head * p.k.hstride;
+            const f16* vsrc = (const f16*)p.v.ptr + row * p.v.ld + p.v.col0 + head * p.v.hstride;
+            // (a dead key slot -- past the window's last key -- holds key 0's data: its logit is masked to -1e30 through kreg,
+            // its weight is exactly 0, so any finite K / V will do and the loads need no predicate)
+            f16x8 kv[4], vv[4];
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *(f16*)(Vt + (seg * 8 + e) * VROW + kk * 2) = vv[e];
+            for (int seg = 0; seg < 4; ++seg) {
+                kv[seg] = *(const f16x8*)(ksrc + seg * 8);
+                vv[seg] = *(const f16x8*)(vsrc + seg * 8);
+            }
+#pragma unroll
+            for (int seg = 0; seg < 4; ++seg) {
+                *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv[seg];
+                *(f16x8*)(Vs + kk * 64 + seg * 16) = vv[seg];
+            }
             if constexpr (SPLIT) {
-                f16x8 k2 = {0, 0, 0, 0, 0, 0, 0, 0}, v2 = k2;
-                if (valid && p.k_lo != nullptr) k2 = *(const f16x8*)((const f16*)p.k_lo + row * p.k.ld + p.k.col0 + head * p.k.hstride + seg * 8);
-                if (valid && p.v_lo != nullptr) v2 = *(const f16x8*)((const f16*)p.v_lo + row * p.v.ld + p.v.col0 + head * p.v.hstride + seg * 8);
-                *(f16x8*)(Ks2 + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = k2;
+                const int64_t ko = row * p.k.ld + p.k.col0 + head * p.k.hstride, vo = row * p.v.ld + p.v.col0 + head * p.v.hstride;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) *(f16*)(Vt2 + (seg * 8 + e) * VROW + kk * 2) = v2[e];
+                for (int seg = 0; seg < 4; ++seg) {
+                    const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+                    kv[seg] = p.k_lo != nullptr ? *(const f16x8*)((const f16*)p.k_lo + ko + seg * 8) : zero;
+                    vv[seg] = p.v_lo != nullptr ? *(const f16x8*)((const f16*)p.v_lo + vo + seg * 8) : zero;
+                }
+#pragma unroll
+                for (int seg = 0; seg < 4; ++seg) {
+                    *(f16x8*)(Ks2 + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv[seg];
+                    *(f16x8*)(Vs2 + kk * 64 + seg * 16) = vv[seg];
+                }
             }
-            if (seg == 0) {
-                const int nn = valid ? n : 0;
-                const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
-                koff[kk] = hk * D + wk;
-                kreg[kk] = valid ? (unsigned char)rid : (unsigned char)255;
-            }
+            const int nn = valid ? n : 0;
+            const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
+            koff[kk] = hk * D + wk;
+            kreg[kk] = valid ? (unsigned char)rid : (unsigned char)255;
         }
         __syncthreads();
 
@@ -202,7 +229,8 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                     S[t] = mfma32_f16(k2[1], qf[t][1], S[t]);
                 }
             }
-            if (need_mask) {
+            // (wave-uniform: only a border window needs the region mask, only the window's last tile has dead key slots)
+            if (border || k0 + kb + 32 > Nk) {
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
                     const uint32_t ids = *(const uint32_t*)(kreg + kb + 8 * g + 4 * half);
@@ -228,30 +256,35 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                 for (int r = 1; r < 16; ++r) mx = fmaxf(mx, S[t][r]);
                 mx = fmaxf(mx, xhalf(mx));
                 const float mnew = fmaxf(mrun[t], mx);
-                const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
-                mrun[t] = mnew;
+                if (__builtin_amdgcn_ballot_w64(mnew > mrun[t]) != 0) {   // (wave-uniform) some query's running maximum moved: rescale
+                    const float alpha = __builtin_amdgcn_exp2f(mrun[t] - mnew);
+                    const f32x2v a2 = {alpha, alpha};
 #pragma unroll
-                for (int r = 0; r < 16; ++r) O[t][r] *= alpha;
-                lrun[t] *= alpha;
-                float ps = 0.f;
-                const float sub = mnew - P_TOP;   // weights <= 2^14: 28 binades of fp16 normals below the row maximum
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const float pr = __builtin_amdgcn_exp2f(S[t][r] - sub);
-                    if constexpr (!ONES) ps += pr;
-                    pb[t][r >> 3][r & 7] = (f16)pr;
+                    for (int r = 0; r < 16; r += 2) {
+                        const f32x2v o2 = f32x2v{O[t][r], O[t][r + 1]} * a2;
+                        O[t][r] = o2[0]; O[t][r + 1] = o2[1];
+                    }
+                    lrun[t] *= alpha;
+                    mrun[t] = mnew;
                 }
+                float ps = 0.f;
+                const float nsub = P_TOP - mnew;   // weights <= 2^14: 28 binades of fp16 normals below the row maximum
+                const f32x2v ns2 = {nsub, nsub};
+                uint32_t pw[8];
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const f32x2v e2 = f32x2v{S[t][r], S[t][r + 1]} + ns2;
+                    const float p0 = __builtin_amdgcn_exp2f(e2[0]), p1 = __builtin_amdgcn_exp2f(e2[1]);
+                    if constexpr (!ONES) ps += p0 + p1;
+                    pw[r >> 1] = pack_f16_raw(p0, p1);
+                }
+                pb[t][0] = __builtin_bit_cast(f16x8, u32x4v{pw[0], pw[1], pw[2], pw[3]});
+                pb[t][1] = __builtin_bit_cast(f16x8, u32x4v{pw[4], pw[5], pw[6], pw[7]});
                 if constexpr (!ONES) lrun[t] += ps;
             }
             // V^T fragments: rows = head dim l31; k-slot e <-> key kb + 16*s + 8*(e>>2) + 4*half + (e&3)
             f16x8 vf[2];
-#pragma unroll
-            for (int s = 0; s < 2; ++s) {
-                const char* vp = Vt + l31 * VROW + (kb + 16 * s + 4 * half) * 2;
-                const f16x4 lo = *(const f16x4*)(vp);
-                const f16x4 hi = *(const f16x4*)(vp + 16);
-                vf[s] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-            }
+            vt_frags(Vs + kb * 64, lane, vf);
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 O[t] = mfma32_f16(vf[0], pb[t][0], O[t]);
@@ -259,13 +292,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             }
             if constexpr (SPLIT) {
                 f16x8 v2[2];
-#pragma unroll
-                for (int s2 = 0; s2 < 2; ++s2) {
-                    const char* vp = Vt2 + l31 * VROW + (kb + 16 * s2 + 4 * half) * 2;
-                    const f16x4 lo = *(const f16x4*)(vp);
-                    const f16x4 hi = *(const f16x4*)(vp + 16);
-                    v2[s2] = f16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
-                }
+                vt_frags(Vs2 + kb * 64, lane, v2);
 #pragma unroll
                 for (int t = 0; t < QT; ++t) {
                     O[t] = mfma32_f16(v2[0], pb[t][0], O[t]);
@@ -766,13 +793,16 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     if (lazy_ok && !p.q.transposed && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
         (p.k.wh % 8) == 0 && fast_lds_bytes(p, 1) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
         return launch_fast(p, st);
-    const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
+    // query blocks of equal size: 288 anchors are 2 x 3 waves (192 + 96 queries), not 4 waves + a workgroup that stages every
+    // key chunk for 32 queries
+    const int units = (Nq + QT * 32 - 1) / (QT * 32);
+    const int waves = (units + (units + 3) / 4 - 1) / ((units + 3) / 4);
     const int qblk = waves * QT * 32;
     const int nqs = (Nq + qblk - 1) / qblk;
     const int64_t grid = (int64_t)nqs * p.nh * p.nwx * p.nwy * p.B;
     if (grid > 0x7fffffff) return GRL_ERR_BAD_ARG;
-    const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + (size_t)KC * 64 + 32 * (size_t)VROW + KC * 4 + KC +
-                       (split ? (size_t)KC * 64 + 32 * (size_t)VROW : 0);
+    const size_t kcap = (size_t)min(KC, (Nk + 31) & ~31);
+    const size_t lds = (((size_t)p.trows * 4 + 15) & ~(size_t)15) + 2 * kcap * 64 + kcap * 4 + kcap + (split ? 2 * kcap * 64 : 0);
     if (lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
     if (split)
         return p.ones_col >= 0 ? launch_kw<true, true>(p, (int)grid, waves * 64, lds, st) : launch_kw<false, true>(p, (int)grid, waves * 64, lds, st);

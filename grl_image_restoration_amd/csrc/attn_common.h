@@ -24,8 +24,7 @@ __device__ __forceinline__ void load_table(float* tab, const float* src, int tro
     for (int i0 = tid; i0 < n4; i0 += 4 * nthreads) {
         float4 v[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * nthreads < n4) v[j] = s4[i0 + j * nthreads];
+        for (int j = 0; j < 4; ++j) v[j] = s4[min(i0 + j * nthreads, n4 - 1)];   // (conditional loads put v[] into scratch)
 #pragma unroll
         for (int j = 0; j < 4; ++j)
             if (i0 + j * nthreads < n4) d4[i0 + j * nthreads] = v[j];

@@ -53,6 +53,13 @@ __device__ __forceinline__ uint32_t pack_f16(float lo, float hi) {
     v[1] = to_f16(hi);
     return __builtin_bit_cast(uint32_t, v);
 }
+// ... without the saturation: for values bounded by construction (softmax weights <= 2^14)
+__device__ __forceinline__ uint32_t pack_f16_raw(float lo, float hi) {
+    f16x2 v;
+    v[0] = (f16)lo;
+    v[1] = (f16)hi;
+    return __builtin_bit_cast(uint32_t, v);
+}
 __device__ __forceinline__ f32x16 mfma32_f16(f16x8 a, f16x8 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
 }
