@@ -103,9 +103,16 @@ _REGISTERED = weakref.WeakKeyDictionary()   # module -> storage addresses of its
 
 
 def forget_parameters(module: torch.nn.Module) -> None:
-    """Drops the cached padded fp16 copies of ``module``'s weights (GRL.invalidate_plan: weights changed behind autograd's back)."""
+    """Drops the cached padded fp16 copies of ``module``'s weights (GRL.invalidate_plan: weights changed behind autograd's back).
+    The parameters may have been REPLACED by new tensors: the copies under the addresses the module was registered with go as
+    well (those addresses are free for other tensors now), and a registered module is registered again under its current ones."""
+    old = _REGISTERED.get(module)
+    for ptr in old or ():
+        _WEIGHTS.pop(ptr, None)
     for p in module.parameters():
         _WEIGHTS.pop(p.data_ptr(), None)
+    if old is not None:
+        register_parameters(module)
 
 
 def register_parameters(module: torch.nn.Module) -> None:

@@ -355,3 +355,32 @@ def test_integration_stub_matches_the_header():
         mine, theirs = getattr(_lib, name), ns[name]
         assert C.sizeof(theirs) == C.sizeof(mine), name
         assert [(f[0], getattr(theirs, f[0]).offset) for f in theirs._fields_] == [(f[0], getattr(mine, f[0]).offset) for f in mine._fields_], name
+
+
+def test_forget_parameters_follows_replaced_tensors():
+    """GRL.invalidate_plan after parameters were REPLACED (load_state_dict(assign=True), m.weight = nn.Parameter(...)): the fp16
+    weight copies cached under the old addresses are dropped and the module is registered under the new ones."""
+    import torch
+
+    from grl_image_restoration_amd import autograd as AG
+
+    m = torch.nn.Linear(8, 8)
+    AG.register_parameters(m)
+    old = set(p.data_ptr() for p in m.parameters())
+    assert AG._REGISTERED[m] == old
+    for ptr in old:
+        AG._WEIGHTS[ptr] = ("stale",)
+    keep_alive = list(m.parameters())          # the old storages stay allocated: the new tensors get new addresses
+    m.weight = torch.nn.Parameter(torch.zeros(8, 8))
+    m.bias = torch.nn.Parameter(torch.zeros(8))
+    new = set(p.data_ptr() for p in m.parameters())
+    assert not (new & old)
+    AG.forget_parameters(m)
+    assert not any(ptr in AG._WEIGHTS for ptr in old | new)
+    assert AG._REGISTERED[m] == new and all(AG._is_registered(ptr) for ptr in new)
+    assert not any(AG._is_registered(ptr) for ptr in old)
+    del keep_alive
+    # a module that was never registered stays unregistered
+    m2 = torch.nn.Linear(4, 4)
+    AG.forget_parameters(m2)
+    assert m2 not in AG._REGISTERED
