@@ -652,7 +652,10 @@ def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H
         key = (x.device, torch.cuda.current_stream(x.device).cuda_stream)
         cnt = _SE_COUNTERS.get(key)
         if cnt is None or cnt.numel() < B:
+            if torch.cuda.is_current_stream_capturing():   # (the buffer would live in the capturing graph's private pool)
+                raise RuntimeError("cab_conv2(se=...): run one eager forward on this stream before capturing it in a graph")
             cnt = _SE_COUNTERS[key] = torch.zeros(max(B, 64), dtype=torch.int32, device=x.device)
+        cnt[:B].zero_()   # explicit: an aborted launch must not leave arrivals behind (the kernel also returns them to zero)
         gate = torch.empty(B, 192, dtype=torch.float32, device=x.device)
         args.gate, args.se_counter = _ptr(gate), _ptr(cnt)
         args.se_w1, args.se_b1, args.se_w2, args.se_b2 = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
