@@ -17,6 +17,7 @@ EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
 # every symbol include/grl_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
     "grl_linear_fwd",
+    "grl_linear_split_blob_bytes",
     "grl_mlp_fwd",
     "grl_mlp_blob_bytes",
     "grl_block_tail_fwd",
@@ -90,6 +91,7 @@ class GrlLinearArgs(_Strict):
         ("ldo", C.c_int64),
         ("out_plane_stride", C.c_int64),
         ("out_lo", C.c_void_p),
+        ("w_regs", C.c_void_p),
     ]
 
 
@@ -376,6 +378,8 @@ def lib():
     L.grl_build_info.restype = C.c_char_p
     L.grl_linear_fwd.argtypes = [C.c_void_p, C.POINTER(GrlLinearArgs)]
     L.grl_linear_fwd.restype = C.c_int
+    L.grl_linear_split_blob_bytes.argtypes = [C.c_int32, C.c_int32]
+    L.grl_linear_split_blob_bytes.restype = C.c_int64
     L.grl_mlp_fwd.argtypes = [C.c_void_p, C.POINTER(GrlMlpArgs)]
     L.grl_mlp_fwd.restype = C.c_int
     L.grl_mlp_blob_bytes.argtypes = [C.c_int32, C.c_int32]

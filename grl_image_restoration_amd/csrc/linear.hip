@@ -25,6 +25,8 @@
 // linear_k1152.hip: K = 768 / 1152) so that they compile in parallel: one file took 8 minutes, then 2, now under one.
 int grl_linear_launch_k576(const GrlLinearArgs& p, hipStream_t st);
 int grl_linear_launch_k1152(const GrlLinearArgs& p, hipStream_t st);
+// csrc/linear_split.hip: weights-stationary kernel of the split-precision layers (GrlLinearArgs.w_regs)
+int grl_linear_split_launch(const GrlLinearArgs& p, hipStream_t st);
 
 extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     const GrlLinearArgs& p = *args;
@@ -37,6 +39,10 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.a_split == 3 && ((p.Kpad / 32) % 3 != 0 || p.a_dtype != GRL_DT_F32)) return GRL_ERR_BAD_ARG;
     if (p.a_split != 0 && p.a_split != 1 && p.a_split != 3) return GRL_ERR_BAD_ARG;
     if (p.out_lo != nullptr && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
+    if (p.a_split == 3 && p.w_regs != nullptr && !getenv("GRL_LINEAR_SPLIT_GENERIC")) {   // weights-stationary split kernel (csrc/linear_split.hip)
+        const int rc = grl_linear_split_launch(p, st);
+        if (rc != GRL_ERR_UNSUPPORTED) return rc;
+    }
     switch (p.Kpad / 32) {
         case 2: return launch_split<2>(p, st);
         case 3: return launch_split<3>(p, st);

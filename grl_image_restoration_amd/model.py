@@ -416,6 +416,7 @@ class GRL(nn.Module):
         hiq = (not hi) and float(max(sc_w.max(), sc_1.max(), sc_2.max())) > self.hiq_scale
         if hiq:
             pk.update(hiq=True, qkv_w3=ops.split3_weight(Wp))
+            pk["qkv_w3r"] = ops.pack_linear_split(pk["qkv_w3"])
         if not hi and CP in (64, 128, 192):  # one-pass streaming QKV kernel (csrc/qkv.hip)
             pk.update(qkv_blob=ops.pack_qkv(Wp, bp, gs), qkv_slots=G)
 
@@ -463,6 +464,9 @@ class GRL(nn.Module):
         pk.update(fc1_w=ops.split3_weight(W1) if hi else W1.to(G16), fc1_b=padv(blk.mlp.fc1.bias, HP),
                   fc2_w=ops.split3_weight(W2) if hi else W2.to(G16),
                   fc2_b=padv(blk.mlp.fc2.bias), n2_g=padv(blk.norm2.weight), n2_b=padv(blk.norm2.bias))
+        if hi:   # register images of the split weights for the weights-stationary kernel (csrc/linear_split.hip; None: generic kernel)
+            for k_ in ("qkv", "anc", "proj", "fc1", "fc2"):
+                pk[k_ + "_wr"] = ops.pack_linear_split(pk[k_ + "_w"])
         if not hi and CP in (64, 128, 192) and KA == CP and self.local_connection:   # + proj/norm1/CAB in front: one kernel per block tail
             pk["proj_blob"] = ops.pack_proj(Wop)
             # weights stationary in registers (csrc/tail_regs.hip, round 4): 255 against 290 us per 4 tiles; GRL_TAIL_REGS=0: streaming kernel
@@ -694,7 +698,7 @@ class GRL(nn.Module):
         if pk.get("hiq") and one_pass and "qa_lo" in pk and os.environ.get("GRL_QKV_SPLIT", "1") != "0":
             qkv, anc = ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W, lo_blob=pk["qa_lo"])
         elif pk.get("hiq"):
-            qkv = ops.linear(r, pk["qkv_w3"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3)
+            qkv = ops.linear(r, pk["qkv_w3"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3, w_regs=pk.get("qkv_w3r"))
             anc = ops.linear(r, pk["anc_w3"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True, a_split=3)
         elif one_pass:
             qkv, anc = ops.qkv_anchor(r, pk["qa_blob"], pk["qa_slots"][0], pk["qa_slots"][1], B, H, W)
@@ -734,18 +738,25 @@ class GRL(nn.Module):
         Ma = M // (geo.df * geo.df)
         qkv_lo = torch.empty(G, M, 32, dtype=ops.PLANE_DTYPE, device=r.device)
         anc_lo = torch.empty(geo.nh_s, Ma, 32, dtype=ops.PLANE_DTYPE, device=r.device)
-        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3, out_lo=qkv_lo)
-        anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(geo.df, H, W), planes=True,
-                         a_split=3, out_lo=anc_lo)
+        qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3, out_lo=qkv_lo, w_regs=pk.get("qkv_wr"))
+        if pk.get("anc_wr") is not None and Ma % 32 == 0:
+            # AnchorLinear's avg-pool (mixed_attn_block.py:727-736) as a reduction of its own, then the weights-stationary kernel on
+            # the M / df^2 pooled rows (the generic kernel with the pool fused into its A load: 440 us of a 384x384 x4 deblur block)
+            pooled = r.view(B, H // geo.df, geo.df, W // geo.df, geo.df, CP).mean(dim=(2, 4)).view(Ma, CP)
+            anc = ops.linear(pooled, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], planes=True, a_split=3,
+                             out_lo=anc_lo, w_regs=pk["anc_wr"])
+        else:
+            anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(geo.df, H, W), planes=True,
+                             a_split=3, out_lo=anc_lo)
         att = torch.empty(M, (geo.nh_w + geo.nh_s) * 32, dtype=f32, device=r.device)
         # attention on split operands too: q, k, v (and the anchor-side values) as fp16 hi + lo planes -> generic kernel
         self._attention(qkv, anc, att, pk, geo, B, H, W, qkv_lo=qkv_lo, anc_lo=anc_lo)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
-        p1 = ops.linear(att, pk["proj_w"], pk["proj_b"], out_dtype=f32, a_split=3)
+        p1 = ops.linear(att, pk["proj_w"], pk["proj_b"], out_dtype=f32, a_split=3, w_regs=pk.get("proj_wr"))
         r1 = ops.layernorm_res(p1, r, pk["n1_g"], pk["n1_b"], C, res_scale=self.res_scale, add2=cab, add2_scale=gate,
                                rows_per_image=H * W)
-        h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out_dtype=f32, a_split=3)
-        p2 = ops.linear(h, pk["fc2_w"], pk["fc2_b"], out_dtype=f32, a_split=3)
+        h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out_dtype=f32, a_split=3, w_regs=pk.get("fc1_wr"))
+        p2 = ops.linear(h, pk["fc2_w"], pk["fc2_b"], out_dtype=f32, a_split=3, w_regs=pk.get("fc2_wr"))
         return ops.layernorm_res(p2, r1, pk["n2_g"], pk["n2_b"], C, res_scale=self.res_scale)
 
     def forward_features(self, f, plan, B, H, W):

@@ -27,6 +27,27 @@ def split3_weight(w: torch.Tensor) -> torch.Tensor:
     return torch.cat([hi, hi, lo], dim=-1).contiguous()
 
 
+def pack_linear_split(w3: torch.Tensor) -> torch.Tensor:
+    """split3_weight output [Npad, 3K] -> `w_regs` of grl_linear_fwd (GrlLinearArgs.w_regs, csrc/linear_split.hip): per slab of
+    192 output columns and compute wave the hi and the lo MFMA A fragments of the wave's 32 columns; None for shapes the
+    kernel does not take (K not in 128 / 192 / 256 / 384)."""
+    Npad, K3 = w3.shape
+    K = K3 // 3
+    if K not in (128, 192, 256, 384) or Npad % 32:
+        return None
+    ns = (Npad + 191) // 192
+    hi = torch.zeros(ns * 192, K, dtype=GEMM_DTYPE, device=w3.device)
+    lo = torch.zeros_like(hi)
+    hi[:Npad], lo[:Npad] = w3[:, :K], w3[:, 2 * K :]
+
+    def frags(w):   # [ns * 6 tiles of 32 rows][K / 16 k-steps][64 lanes][8]: lane = 32 * (column half) + row
+        return w.view(ns * 6, 32, K // 16, 2, 8).permute(0, 2, 3, 1, 4).reshape(ns * 6, K // 16, 64, 8)
+
+    blob = torch.stack([frags(hi), frags(lo)], dim=1).contiguous().view(torch.uint8).reshape(-1)
+    assert blob.numel() == L.lib().grl_linear_split_blob_bytes(Npad, K)
+    return blob
+
+
 # ---- optional per-kernel timing with HIP events on the launching stream (used by bench.py) ----
 _PROFILE = None
 
@@ -106,12 +127,16 @@ def linear(
     a_scale: float = 1.0,
     out_scale: float = 1.0,
     out_lo: Optional[torch.Tensor] = None,
+    w_regs: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
     ``a_split=3``: split-precision operands -- ``w`` is packed by ``split3_weight`` ([hi | hi | lo], Kpad = 3 x the
     source width) and the kernel stages the fp32 ``a`` as [hi | lo | hi]."""
-    _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale)
+    _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale, w_regs)
+    if w_regs is not None:   # register image of the same weights for the weights-stationary split kernel (pack_linear_split)
+        assert a_split == 3 and w_regs.dtype == torch.uint8 and w_regs.is_contiguous()
+        assert w_regs.numel() == L.lib().grl_linear_split_blob_bytes(w.shape[0], w.shape[1] // 3)
     if add2 is not None:
         assert add2.dtype == GEMM_DTYPE and add2_scale is not None and rows_per_image > 0
         assert add2_scale.dtype == torch.float32 and add2_scale.is_contiguous()
@@ -149,6 +174,7 @@ def linear(
         ldadd2=add2.stride(0) if add2 is not None else 0,
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split, a_scale=a_scale, out_scale=out_scale,
         out_lo=_ptr(out_lo), out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
+        w_regs=_ptr(w_regs),
     )
     if out_lo is not None:   # rounding residuals of the fp16 outputs, same layout (split-precision attention operands)
         assert out_lo.dtype == torch.float16 and out_lo.shape == out.shape and out_lo.stride() == out.stride() and out.dtype == torch.float16
@@ -157,7 +183,7 @@ def linear(
     if epi == L.EPI_LN_RES:
         assert resid is not None and resid.dtype == torch.float32 and ln_g.numel() == Npad and ln_b.numel() == Npad
         assert out.dtype == torch.float32
-    with _timed("linear"):
+    with _timed(f"linear {Kpad}->{Npad}" if _PROFILE is not None else "linear"):
         L.check(L.lib().grl_linear_fwd(L.stream_ptr(), C.byref(args)), "grl_linear_fwd")
     return out
 

@@ -77,9 +77,17 @@ typedef struct GrlLinearArgs {
                               /* out[(c/32)*out_plane_stride + m*32 + c%32]  (ldo ignored)             */
     void* out_lo;             /* optional, GRL_DT_F16 outputs: the rounding residual v - fp16(v) of every output value, */
                               /* same layout as out (the low half of a split-precision attention operand)               */
+    const void* w_regs;       /* optional, a_split == 3: the weights once more, as the register image of the            */
+                              /* weights-stationary kernel (csrc/linear_split.hip; plain / GELU / GROUPNORM epilogues,  */
+                              /* fp32 A without pooling): per slab of 192 output columns and compute wave w = 0..5      */
+                              /* (columns 192 slab + 32 w ..) 2 x Ksrc/16 MFMA A fragments of 1 KiB, hi = fp16(W) first, */
+                              /* then lo = fp16(W - hi); fragment s, lane l, element e = W[column 32 (6 slab + w) +      */
+                              /* (l & 31)][16 s + 8 (l >> 5) + e]; columns >= Npad zero.  grl_linear_split_blob_bytes;   */
+                              /* ops.pack_linear_split.  NULL, or a shape it does not take: the generic kernel on `w`.   */
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
+int64_t grl_linear_split_blob_bytes(int32_t Npad, int32_t Ksrc);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused transformer MLP:  out = x + res_scale * LayerNorm(fc2(GELU(fc1(x))))  in one pass over x.

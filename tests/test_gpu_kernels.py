@@ -700,6 +700,63 @@ def test_linear_split_precision(M, K, N, epi):
     assert err < 2e-5 * max(1.0, ref.abs().max().item()) and err < e16 / 50
 
 
+@pytest.mark.parametrize("M,K,N,epi", [(4096, 192, 576, "groupnorm"), (32 * 515, 192, 192, "plain"), (8192, 192, 384, "gelu"), (2048, 384, 192, "plain"),
+                                       (32, 192, 576, "groupnorm"), (1024, 128, 384, "groupnorm"), (2080, 256, 128, "gelu"), (96, 128, 128, "plain"),
+                                       (32 * 700, 192, 576, "plain16")])
+def test_linear_split_weights_stationary(M, K, N, epi):
+    """csrc/linear_split.hip (GrlLinearArgs.w_regs) against the unrounded fp64 product and against the generic split kernel:
+    same three-term sum, so the two agree to fp32 accumulation order; planes, rounding-residual planes, slot-31 ones."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    g = torch.Generator().manual_seed(77)
+    a = torch.randn(M, K, generator=g) * 3
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = 0.1 * torch.randn(N, generator=g)
+    d = _dev()
+    ref = a.double() @ w.double().t() + b.double()
+    w3 = ops.split3_weight(w.to(d))
+    wr = ops.pack_linear_split(w3)
+    assert wr is not None
+    ad = torch.zeros(M, K + 16, device=d)[:, :K]        # row stride != K
+    ad.copy_(a)
+    bd = b.to(d)
+    if epi == "groupnorm":
+        gs = torch.rand(N // 32, generator=g) * 10 + 1
+        gs[1] = 0.0                       # pass-through group (a v slot)
+        gs[2] = -gs[2]                    # a K plane: 1.0 in column 31
+        lo_new = torch.zeros(N // 32, M, 32, dtype=torch.float16, device=d)
+        lo_old = torch.zeros_like(lo_new)
+        new = ops.linear(ad, w3, bd, epi=L.EPI_GROUPNORM, gscale=gs.to(d), planes=True, a_split=3, out_lo=lo_new, w_regs=wr)
+        old = ops.linear(ad, w3, bd, epi=L.EPI_GROUPNORM, gscale=gs.to(d), planes=True, a_split=3, out_lo=lo_old)
+        full_new = (new.double() + lo_new.double()).cpu().permute(1, 0, 2).reshape(M, N)
+        full_old = (old.double() + lo_old.double()).cpu().permute(1, 0, 2).reshape(M, N)
+        want = _groupnorm_ref(ref.view(M, N // 32, 32), gs).reshape(M, N)
+        scale = want.abs().max().item()
+        e_new, e_old = (full_new - want).abs().max().item(), (full_old - want).abs().max().item()
+        print(f"linear_split {M}x{K}x{N} groupnorm: hi+lo err {e_new:.2e} (generic {e_old:.2e}) of {scale:.1f}")
+        assert e_new < 3e-5 * scale and e_new < 2 * e_old + 1e-6 * scale
+        assert (new.float() - old.float()).abs().max().item() <= 2.0 ** -10 * scale   # the fp16 planes: at most an ulp apart
+        return
+    kw = dict(a_split=3)
+    if epi == "gelu":
+        kw["epi"] = L.EPI_GELU
+        ref = F.gelu(ref)
+    if epi == "plain16":
+        new = ops.linear(ad, w3, bd, out_dtype=torch.float16, w_regs=wr, **kw).float().cpu().double()
+        old = ops.linear(ad, w3, bd, out_dtype=torch.float16, **kw).float().cpu().double()
+        assert (new - ref).abs().max().item() < 1.5e-3 * ref.abs().max().item()
+        assert (new - old).abs().max().item() <= 2.0 ** -9 * ref.abs().max().item()
+        return
+    out = torch.full((M, N + 32), 7.0, device=d)[:, :N]     # ldo != N; the columns behind stay untouched
+    ops.linear(ad, w3, bd, out=out, out_dtype=torch.float32, w_regs=wr, **kw)
+    old = ops.linear(ad, w3, bd, out_dtype=torch.float32, **kw).cpu().double()
+    new = out.cpu().double()
+    err, err_old = (new - ref).abs().max().item(), (old - ref).abs().max().item()
+    print(f"linear_split {M}x{K}x{N} {epi}: err {err:.2e} (generic {err_old:.2e})")
+    assert err < 2e-5 * max(1.0, ref.abs().max().item()) and err < 2 * err_old + 1e-6
+    assert (out.as_strided((M, 32), (N + 32, 1), N) == 7.0).all()
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act", [(2, 20, 45, 64, 64, 0), (1, 16, 32, 128, 128, 0), (1, 17, 33, 3, 64, 0), (1, 12, 20, 180, 45, 1)])
 def test_conv3x3_split_precision(B, H, W, Cin, Cout, act):
     from grl_image_restoration_amd import ops
