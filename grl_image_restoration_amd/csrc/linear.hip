@@ -34,15 +34,16 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % 8 != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
     if (p.out_dtype != GRL_DT_F32 && p.out_plane_stride <= 0 && (p.ldo % 8) != 0) return GRL_ERR_BAD_ARG;  // 16-B stores
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
-    if (p.add2 != nullptr && (p.add2_dtype != GRL_DT_F16 || p.add2_scale == nullptr || p.rows_per_image <= 0)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     if (p.a_split == 3 && ((p.Kpad / 32) % 3 != 0 || p.a_dtype != GRL_DT_F32)) return GRL_ERR_BAD_ARG;
     if (p.a_split != 0 && p.a_split != 1 && p.a_split != 3) return GRL_ERR_BAD_ARG;
     if (p.out_lo != nullptr && p.out_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
+    if (p.add2 != nullptr && (p.add2_scale == nullptr || p.rows_per_image <= 0)) return GRL_ERR_BAD_ARG;
     if (p.a_split == 3 && p.w_regs != nullptr && !getenv("GRL_LINEAR_SPLIT_GENERIC")) {   // weights-stationary split kernel (csrc/linear_split.hip)
         const int rc = grl_linear_split_launch(p, st);
         if (rc != GRL_ERR_UNSUPPORTED) return rc;
     }
+    if (p.add2 != nullptr && p.add2_dtype != GRL_DT_F16) return GRL_ERR_UNSUPPORTED;   // (the generic LN_RES epilogue reads a 16-bit extra branch)
     switch (p.Kpad / 32) {
         case 2: return launch_split<2>(p, st);
         case 3: return launch_split<3>(p, st);

@@ -36,8 +36,9 @@ struct LsGeom {
     static constexpr int ROW = K * 2 + 16;          // fp16 plane row (16 B pad: conflict-free ds_read_b128)
     static constexpr int PLANE = LS_T * ROW;
     static constexpr int BUF = 2 * PLANE;           // hi | lo
-    static constexpr int OFF_VEC = 2 * BUF;         // [192] fp32 bias of the slab
-    static constexpr int LDS = OFF_VEC + LS_SLAB * 4;
+    static constexpr int OFF_VEC = 2 * BUF;         // 3 x [192] fp32: bias of the slab | LayerNorm gamma | beta
+    static constexpr int OFF_ST = OFF_VEC + 3 * LS_SLAB * 4;   // [6 waves][32 tokens] (mean, M2) of the LayerNorm epilogue
+    static constexpr int LDS = OFF_ST + LS_CW * LS_T * 8;
     static constexpr int NLD = K * LS_T / 4 / 128;  // 16-B loads per loader lane and tile
     static constexpr int SEGS = K / 4;              // 16-B segments per fp32 row
 };
@@ -48,7 +49,8 @@ __device__ __forceinline__ int ls_lane() {
     return x;
 }
 
-template <int KS>
+// LN: the LayerNorm + residual epilogue (an instance of its own: its extra barrier and live values stay out of the others)
+template <int KS, bool LN>
 __global__ __launch_bounds__(LS_THREADS) void linear_split_kernel(GrlLinearArgs p, int nslabs, int walkers) {
     using G = LsGeom<KS>;
     extern __shared__ __attribute__((aligned(1024))) char smem[];
@@ -64,7 +66,12 @@ __global__ __launch_bounds__(LS_THREADS) void linear_split_kernel(GrlLinearArgs 
     {
         const int i = 64 * wave + ls_lane();
         if (i < LS_SLAB) vec[i] = LS_SLAB * slab + i < p.Npad ? p.bias[LS_SLAB * slab + i] : 0.f;
+        if (LN && i < LS_SLAB) {   // (one slab; pad channels: zero affine, they stay exactly 0)
+            vec[LS_SLAB + i] = i < p.n_real ? p.ln_g[i] : 0.f;
+            vec[2 * LS_SLAB + i] = i < p.n_real ? p.ln_b[i] : 0.f;
+        }
     }
+    constexpr bool ln = LN;   // a second barrier per tile: the row statistics cross the waves
 
     if (wave >= LS_CW) {
         // ---------------- loader waves: fp32 rows -> hi / lo planes, two tiles ahead in registers ----------------
@@ -120,11 +127,13 @@ __global__ __launch_bounds__(LS_THREADS) void linear_split_kernel(GrlLinearArgs 
             __builtin_amdgcn_s_barrier();
             if (it + 1 < nmine) put(1, S1{});
             if (it + 1 + D < nmine) issue(it + 1 + D, S1{});
+            if (ln) __builtin_amdgcn_s_barrier();
             if (it + 1 >= nmine) break;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             if (it + 2 < nmine) put(0, S0{});
             if (it + 2 + D < nmine) issue(it + 2 + D, S0{});
+            if (ln) __builtin_amdgcn_s_barrier();
         }
         return;
     }
@@ -141,8 +150,37 @@ __global__ __launch_bounds__(LS_THREADS) void linear_split_kernel(GrlLinearArgs 
     for (int it = 0; it < nmine; ++it) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
-        if (!live) continue;
-        const int ln = ls_lane(), j = ln & 31, half = ln >> 5;
+        if (!live) {
+            if (ln) __builtin_amdgcn_s_barrier();
+            continue;
+        }
+        const int lid = ls_lane(), j = lid & 31, half = lid >> 5;
+        const int64_t m = (int64_t)(walker + (int64_t)it * walkers) * LS_T + j;
+        // LayerNorm epilogue: the residual (and the gated extra branch) of this lane's 16 channels, requested before the k loop
+        // (K >= 256: after it -- no registers to park them in)
+        constexpr bool EARLY = KS <= 12;
+        float4 rr[4], aa[4];
+        auto ln_loads = [&] {
+            const float* rrow = p.resid + m * p.ldr + 32 * wave + 4 * half;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) rr[g] = *(const float4*)(rrow + 8 * g);
+            if (p.add2 != nullptr) {
+                const float* grow = p.add2_scale + (int64_t)((walker + (int64_t)it * walkers) * LS_T / p.rows_per_image) * p.Npad + 32 * wave + 4 * half;
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    float4 e;
+                    if (p.add2_dtype == GRL_DT_F32) {
+                        e = *(const float4*)((const float*)p.add2 + m * p.ldadd2 + 32 * wave + 4 * half + 8 * g);
+                    } else {
+                        const f16x4 h = *(const f16x4*)((const f16*)p.add2 + m * p.ldadd2 + 32 * wave + 4 * half + 8 * g);
+                        e = float4{(float)h[0], (float)h[1], (float)h[2], (float)h[3]};
+                    }
+                    const float4 gt = *(const float4*)(grow + 8 * g);
+                    aa[g] = float4{e.x * gt.x, e.y * gt.y, e.z * gt.z, e.w * gt.w};
+                }
+            }
+        };
+        if constexpr (LN && EARLY) ln_loads();
         const char* bh = smem + (it & 1) * G::BUF + j * G::ROW + 16 * half;
         const char* bl = bh + G::PLANE;
         f32x16 acc;
@@ -172,10 +210,67 @@ __global__ __launch_bounds__(LS_THREADS) void linear_split_kernel(GrlLinearArgs 
             else { h0 = nh; l0 = nl; }
         }
         // ---- epilogue: register r <-> channel 32 nt + 4 half + (r & 3) + 8 (r >> 2) of token m ----
-        const int64_t m = (int64_t)(walker + (int64_t)it * walkers) * LS_T + j;
         float v[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) v[r] = acc[r];
+        if constexpr (LN) {
+            // out = resid + res_scale * LayerNorm(v) (+ add2 * gate[image]) over the n_real real channels of the row: per-wave
+            // (mean, M2) pairs through LDS, combined with Chan's formula (csrc/tail_regs.hip).  Pad channels are exact zeros.
+            if constexpr (!EARLY) ln_loads();
+            const int c0 = 32 * wave + 4 * half;
+            const int nw_i = min(32, max(0, p.n_real - 32 * wave));        // real channels of this wave's tile
+            const float inv_nw = nw_i > 0 ? 1.0f / (float)nw_i : 0.f;
+            float s = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) s += v[r];
+            const float mean_w = sum_halves(s) * inv_nw;
+            float qd = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float dlt = v[r] - mean_w;
+                if (c0 + (r & 3) + 8 * (r >> 2) < p.n_real) qd = fmaf(dlt, dlt, qd);
+            }
+            qd = sum_halves(qd);
+            float2* st = (float2*)(smem + G::OFF_ST);
+            if (half == 0) st[wave * LS_T + j] = float2{mean_w, qd};
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const float inv_n = 1.0f / (float)p.n_real;
+            float mean = 0.f;
+#pragma unroll
+            for (int w = 0; w < LS_CW; ++w)
+                if (32 * w < p.n_real) mean += (float)min(32, p.n_real - 32 * w) * st[w * LS_T + j].x;
+            mean *= inv_n;
+            float m2 = 0.f;
+#pragma unroll
+            for (int w = 0; w < LS_CW; ++w)
+                if (32 * w < p.n_real) {
+                    const float2 e = st[w * LS_T + j];
+                    const float dlt = e.x - mean;
+                    m2 += e.y + (float)min(32, p.n_real - 32 * w) * dlt * dlt;
+                }
+            const float rstd = rsqrtf(m2 * inv_n + p.ln_eps);
+            const float* gv = vec + LS_SLAB + c0;
+            const float* bv2 = vec + 2 * LS_SLAB + c0;
+            float* dst = (float*)p.out + m * p.ldo + c0;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const float4 gg = *(const float4*)(gv + 8 * g), bb = *(const float4*)(bv2 + 8 * g);
+                float4 y;
+                y.x = rr[g].x + p.res_scale * ((v[4 * g] - mean) * rstd * gg.x + bb.x);
+                y.y = rr[g].y + p.res_scale * ((v[4 * g + 1] - mean) * rstd * gg.y + bb.y);
+                y.z = rr[g].z + p.res_scale * ((v[4 * g + 2] - mean) * rstd * gg.z + bb.z);
+                y.w = rr[g].w + p.res_scale * ((v[4 * g + 3] - mean) * rstd * gg.w + bb.w);
+                if (p.add2 != nullptr) { y.x += aa[g].x; y.y += aa[g].y; y.z += aa[g].z; y.w += aa[g].w; }
+                const int c = c0 + 8 * g;
+                if (c + 0 >= p.n_real) y.x = 0.f;      // keep pad channels 0
+                if (c + 1 >= p.n_real) y.y = 0.f;
+                if (c + 2 >= p.n_real) y.z = 0.f;
+                if (c + 3 >= p.n_real) y.w = 0.f;
+                *(float4*)(dst + 8 * g) = y;
+            }
+            continue;
+        }
         if (p.epi == GRL_EPI_GROUPNORM) {
             // per 32-channel group (= one attention head slot): x / max(|x|, 1e-12) * |gscale|; gscale == 0: pass through (v);
             // gscale < 0: additionally 1.0 in column 31 (K plane).  F.normalize eps: efficient.py:85.
@@ -194,7 +289,6 @@ __global__ __launch_bounds__(LS_THREADS) void linear_split_kernel(GrlLinearArgs 
                 v[r] = e[0]; v[r + 1] = e[1];
             }
         }
-        if (m >= p.M) continue;   // (wave-divergent only in the last tile; nothing below synchronises)
         if (p.out_dtype == GRL_DT_F32) {
             float* dst = (float*)p.out + m * p.ldo + 32 * nt + 4 * half;
 #pragma unroll
@@ -222,7 +316,7 @@ int launch_ls(const GrlLinearArgs& p, hipStream_t st) {
     if (per_xcd < 1) per_xcd = 1;
     if (per_xcd > (ntiles + 7) / 8) per_xcd = (ntiles + 7) / 8;
     const int walkers = 8 * per_xcd;
-    auto kfn = linear_split_kernel<KS>;
+    auto kfn = p.epi == GRL_EPI_LN_RES ? linear_split_kernel<KS, true> : linear_split_kernel<KS, false>;
     hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS);
     if (e != hipSuccess) return (int)e;
     hipLaunchKernelGGL(kfn, dim3(walkers * nslabs), dim3(LS_THREADS), G::LDS, st, p, nslabs, walkers);
@@ -242,7 +336,12 @@ extern "C" int64_t grl_linear_split_blob_bytes(int32_t Npad, int32_t Ksrc) {
 int grl_linear_split_launch(const GrlLinearArgs& p, hipStream_t st) {
     if (p.w_regs == nullptr || p.a_split != 3 || p.a_dtype != GRL_DT_F32 || p.pool_df > 1) return GRL_ERR_UNSUPPORTED;
     if ((p.a_scale != 0.0f && p.a_scale != 1.0f) || (p.out_scale != 0.0f && p.out_scale != 1.0f)) return GRL_ERR_UNSUPPORTED;
-    if (p.epi != GRL_EPI_PLAIN && p.epi != GRL_EPI_GELU && p.epi != GRL_EPI_GROUPNORM) return GRL_ERR_UNSUPPORTED;
+    if (p.epi == GRL_EPI_LN_RES) {   // LayerNorm + residual (+ gated extra branch) epilogue: the whole row in one slab, fp32 out
+        if (p.Npad > LS_SLAB || p.n_real <= 0 || p.n_real > p.Npad || p.resid == nullptr || p.out_dtype != GRL_DT_F32 || (p.ldr % 4)) return GRL_ERR_UNSUPPORTED;
+        if (p.add2 != nullptr && (p.add2_scale == nullptr || p.rows_per_image <= 0 || (p.rows_per_image % LS_T) ||
+                                  (p.add2_dtype != GRL_DT_F32 && p.add2_dtype != GRL_DT_F16) || (p.ldadd2 % 4)))
+            return GRL_ERR_UNSUPPORTED;
+    } else if (p.epi != GRL_EPI_PLAIN && p.epi != GRL_EPI_GELU && p.epi != GRL_EPI_GROUPNORM) return GRL_ERR_UNSUPPORTED;
     if ((p.Kpad % 3) || (p.Npad % 32) || p.M <= 0 || (p.M % LS_T)) return GRL_ERR_UNSUPPORTED;   // (whole 32-token tiles)
     if (p.out_dtype == GRL_DT_F32 ? (p.ldo % 4) != 0 : (p.out_plane_stride <= 0 && (p.ldo % 8) != 0)) return GRL_ERR_BAD_ARG;
     if (p.out_lo != nullptr && p.out_dtype == GRL_DT_F32) return GRL_ERR_BAD_ARG;

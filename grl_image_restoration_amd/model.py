@@ -752,10 +752,22 @@ class GRL(nn.Module):
         # attention on split operands too: q, k, v (and the anchor-side values) as fp16 hi + lo planes -> generic kernel
         self._attention(qkv, anc, att, pk, geo, B, H, W, qkv_lo=qkv_lo, anc_lo=anc_lo)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
-        p1 = ops.linear(att, pk["proj_w"], pk["proj_b"], out_dtype=f32, a_split=3, w_regs=pk.get("proj_wr"))
-        r1 = ops.layernorm_res(p1, r, pk["n1_g"], pk["n1_b"], C, res_scale=self.res_scale, add2=cab, add2_scale=gate,
-                               rows_per_image=H * W)
+        # norm + residual (+ gated CAB branch) in the epilogue of the weights-stationary kernel where it takes the shape (a row of
+        # <= 192 channels is one slab): the fp32 products p1 / p2 never reach memory
+        fuse = (CP <= 192 and M % 32 == 0 and (H * W) % 32 == 0 and pk.get("proj_wr") is not None and pk.get("fc2_wr") is not None
+                and os.environ.get("GRL_HIGH_FUSE_LN", "1") != "0")
+        if fuse:
+            r1 = ops.linear(att, pk["proj_w"], pk["proj_b"], epi=L.EPI_LN_RES, out_dtype=f32, a_split=3, w_regs=pk["proj_wr"],
+                            ln_g=pk["n1_g"], ln_b=pk["n1_b"], n_real=C, res_scale=self.res_scale, resid=r, add2=cab, add2_scale=gate,
+                            rows_per_image=H * W)
+        else:
+            p1 = ops.linear(att, pk["proj_w"], pk["proj_b"], out_dtype=f32, a_split=3, w_regs=pk.get("proj_wr"))
+            r1 = ops.layernorm_res(p1, r, pk["n1_g"], pk["n1_b"], C, res_scale=self.res_scale, add2=cab, add2_scale=gate,
+                                   rows_per_image=H * W)
         h = ops.linear(r1, pk["fc1_w"], pk["fc1_b"], epi=L.EPI_GELU, out_dtype=f32, a_split=3, w_regs=pk.get("fc1_wr"))
+        if fuse:
+            return ops.linear(h, pk["fc2_w"], pk["fc2_b"], epi=L.EPI_LN_RES, out_dtype=f32, a_split=3, w_regs=pk["fc2_wr"],
+                              ln_g=pk["n2_g"], ln_b=pk["n2_b"], n_real=C, res_scale=self.res_scale, resid=r1)
         p2 = ops.linear(h, pk["fc2_w"], pk["fc2_b"], out_dtype=f32, a_split=3, w_regs=pk.get("fc2_wr"))
         return ops.layernorm_res(p2, r1, pk["n2_g"], pk["n2_b"], C, res_scale=self.res_scale)
 

@@ -138,7 +138,7 @@ def linear(
         assert a_split == 3 and w_regs.dtype == torch.uint8 and w_regs.is_contiguous()
         assert w_regs.numel() == L.lib().grl_linear_split_blob_bytes(w.shape[0], w.shape[1] // 3)
     if add2 is not None:
-        assert add2.dtype == GEMM_DTYPE and add2_scale is not None and rows_per_image > 0
+        assert (add2.dtype == GEMM_DTYPE or (w_regs is not None and add2.dtype == torch.float32)) and add2_scale is not None and rows_per_image > 0
         assert add2_scale.dtype == torch.float32 and add2_scale.is_contiguous()
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == GEMM_DTYPE
     assert a.dtype in (torch.float32, GEMM_DTYPE) and bias.dtype == torch.float32

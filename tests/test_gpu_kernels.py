@@ -757,6 +757,50 @@ def test_linear_split_weights_stationary(M, K, N, epi):
     assert (out.as_strided((M, 32), (N + 32, 1), N) == 7.0).all()
 
 
+@pytest.mark.parametrize("M,K,N,n_real,add2", [(2048, 192, 192, 180, "f32"), (1024, 384, 192, 180, None), (512, 256, 128, 128, "f16"),
+                                                (64, 128, 128, 100, None), (32 * 300, 192, 192, 180, "f16"), (256, 192, 64, 60, "f32")])
+def test_linear_split_layernorm_epilogue(M, K, N, n_real, add2):
+    """out = resid + res_scale * LayerNorm(a W^T + b) (+ add2 * gate[image]) in the epilogue of the weights-stationary split
+    kernel (GRL_EPI_LN_RES with w_regs) against fp64; pad channels of the output stay 0."""
+    from grl_image_restoration_amd import _lib as L, ops
+
+    g = torch.Generator().manual_seed(78)
+    rpi = 32 * max(1, M // 64)                     # two images (the gate row changes inside the launch)
+    nimg = (M + rpi - 1) // rpi
+    a = torch.randn(M, K, generator=g) * 2
+    w = torch.zeros(N, K)
+    w[:n_real] = torch.randn(n_real, K, generator=g) / math.sqrt(K)
+    b = torch.zeros(N)
+    b[:n_real] = 0.1 * torch.randn(n_real, generator=g)
+    gam, bet = torch.zeros(N), torch.zeros(N)
+    gam[:n_real], bet[:n_real] = 1 + 0.2 * torch.randn(n_real, generator=g), 0.1 * torch.randn(n_real, generator=g)
+    resid = torch.zeros(M, N)
+    resid[:, :n_real] = torch.randn(M, n_real, generator=g) * 3
+    ext = torch.zeros(M, N)
+    ext[:, :n_real] = torch.randn(M, n_real, generator=g)
+    gate = torch.rand(nimg, N, generator=g)
+    res_scale = 0.7
+    y = a.double() @ w.double().t() + b.double()
+    yr = y[:, :n_real]
+    mu, var = yr.mean(1, keepdim=True), yr.var(1, unbiased=False, keepdim=True)
+    ref = torch.zeros(M, N, dtype=torch.float64)
+    ref[:, :n_real] = resid[:, :n_real].double() + res_scale * ((yr - mu) / torch.sqrt(var + 1e-5) * gam[:n_real].double() + bet[:n_real].double())
+    d = _dev()
+    kw = {}
+    if add2 is not None:
+        e = ext.to(d).to(torch.float16 if add2 == "f16" else torch.float32)
+        kw = dict(add2=e, add2_scale=gate.to(d), rows_per_image=rpi)
+        img = torch.arange(M) // rpi
+        ref[:, :n_real] += e.cpu().double()[:, :n_real] * gate.double()[img][:, :n_real]
+    w3 = ops.split3_weight(w.to(d))
+    out = ops.linear(a.to(d), w3, b.to(d), epi=L.EPI_LN_RES, out_dtype=torch.float32, a_split=3, w_regs=ops.pack_linear_split(w3),
+                     ln_g=gam.to(d), ln_b=bet.to(d), n_real=n_real, res_scale=res_scale, resid=resid.to(d), **kw).cpu().double()
+    err = (out - ref).abs().max().item()
+    print(f"linear_split LN epilogue {M}x{K}x{N} ({n_real} real, add2 {add2}): err {err:.2e}")
+    assert err < 3e-5 * ref.abs().max().item()
+    assert out[:, n_real:].abs().max().item() == 0 if n_real < N else True
+
+
 @pytest.mark.parametrize("B,H,W,Cin,Cout,act", [(2, 20, 45, 64, 64, 0), (1, 16, 32, 128, 128, 0), (1, 17, 33, 3, 64, 0), (1, 12, 20, 180, 45, 1)])
 def test_conv3x3_split_precision(B, H, W, Cin, Cout, act):
     from grl_image_restoration_amd import ops
