@@ -76,8 +76,9 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
         }
     };
 
-    // x_split == 3: the virtual input channels are [hi(x) | lo(x) | hi(x)] over CinP / 3 source channels (grl_hip.h)
-    const int csrc = p.x_split == 3 ? p.CinP / 3 : p.CinP;
+    // x_split == 3: the virtual input channels are [hi(x) | lo(x) | hi(x)] over CinP / 3 source channels (grl_hip.h);
+    // x_split == 2: [hi(x) | lo(x)] over CinP / 2 -- the activations split, the weights twice as they are
+    const int csrc = p.x_split == 3 ? p.CinP / 3 : (p.x_split == 2 ? p.CinP / 2 : p.CinP);
     const float xsc = p.x_scale != 0.0f ? p.x_scale : 1.0f;   // backward pass: gradients pre-scaled into fp16 range
     const float osc = p.out_scale != 0.0f ? p.out_scale : 1.0f;
     auto stage_input = [&](int kc) {
@@ -86,7 +87,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
             const int pix = s / SEG_ROW, cc = s % SEG_ROW;
             const int vch = kc * KC + cc * 8;             // first virtual channel of this 16-B segment
             int part = 0, ch0 = vch;
-            if (p.x_split == 3) {                         // (uniform; keeps the integer division out of the common path)
+            if (p.x_split >= 2) {                         // (uniform; keeps the integer division out of the common path)
                 part = vch / csrc;
                 ch0 = vch - part * csrc;
             }
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                     const float e[8] = {a0.x * xsc, a0.y * xsc, a0.z * xsc, a0.w * xsc, a1.x * xsc, a1.y * xsc, a1.z * xsc, a1.w * xsc};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = to_f16(e[i]);
-                    if (p.x_split == 3 && part == 1) {
+                    if (p.x_split >= 2 && part == 1) {
 #pragma unroll
                         for (int i = 0; i < 8; ++i) v[i] = (f16)(e[i] - (float)v[i]);
                     }
@@ -375,8 +376,8 @@ extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     const GrlConvArgs& p = *args;
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return GRL_ERR_BAD_ARG;
     if (p.CinP % 32 || p.CoutP % 16 || p.CoutP > 192 || (p.ldx % 8) || (p.ldo % 4)) return GRL_ERR_BAD_ARG;
-    if (p.x_split != 0 && p.x_split != 1 && p.x_split != 3) return GRL_ERR_BAD_ARG;
-    if (p.x_split == 3 && (p.x_dtype != GRL_DT_F32 || p.CinP % 24 != 0)) return GRL_ERR_BAD_ARG;   // parts are whole 8-channel segments
+    if (p.x_split < 0 || p.x_split > 3) return GRL_ERR_BAD_ARG;
+    if (p.x_split >= 2 && (p.x_dtype != GRL_DT_F32 || p.CinP % (8 * p.x_split) != 0)) return GRL_ERR_BAD_ARG;   // parts are whole 8-channel segments
     if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;
     if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;

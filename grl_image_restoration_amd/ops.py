@@ -564,7 +564,9 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: in
     """torch conv weight [Cout, Cin, 3, 3] -> fp16 [9, cout_pad, cin_pad] (tap = ky*3+kx, K contiguous).
     With ``shuffle_r`` the output channels are re-ordered from PixelShuffle's (c, i, j) to (i, j, c) with
     ``shuffle_cg`` (>= c, multiple of 4) slots per sub-pixel so the kernel can store whole channel groups.
-    ``split=3``: [9, cout_pad, 3*cin_pad] = [hi | hi | lo] along K (split-precision operands, ``x_split=3``)."""
+    ``split=3``: [9, cout_pad, 3*cin_pad] = [hi | hi | lo] along K (split-precision operands, ``x_split=3``);
+    ``split=2``: [9, cout_pad, 2*cin_pad] = [hi | hi] (``x_split=2``: only the activations are split -- for sites where the
+    rounding of x matters and that of W does not)."""
     cout, cin = w.shape[:2]
     w9 = w.detach().float().permute(2, 3, 0, 1).reshape(9, cout, cin)
     out = torch.zeros(9, cout_pad, cin_pad, dtype=torch.float32, device=w.device)
@@ -577,6 +579,9 @@ def pack_conv_weight(w: torch.Tensor, cin_pad: int, cout_pad: int, shuffle_r: in
         out[:, :cout, :cin] = w9
     if split == 3:
         return split3_weight(out)
+    if split == 2:
+        hi = out.to(GEMM_DTYPE)
+        return torch.cat([hi, hi], dim=-1).contiguous()
     return out.to(GEMM_DTYPE).contiguous()
 
 
@@ -601,7 +606,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, GEMM_DTYPE)
     assert w.dtype == GEMM_DTYPE and w.is_contiguous() and w.dim() == 3 and w.shape[0] == 9
     CoutP, CinP = w.shape[1], w.shape[2]
-    assert x_split in (1, 3) and x.shape[0] >= B * H * W and x.shape[1] >= CinP // x_split and bias.numel() == CoutP
+    assert x_split in (1, 2, 3) and x.shape[0] >= B * H * W and x.shape[1] >= CinP // x_split and bias.numel() == CoutP
     assert x_split == 1 or x.dtype == torch.float32
     if shuffle_r > 1:
         rows, cols = B * H * W * shuffle_r * shuffle_r, shuffle_cg

@@ -823,6 +823,16 @@ def test_conv3x3_split_precision(B, H, W, Cin, Cout, act):
     got = out.cpu().double().view(B, H, W, CoutP)[..., :Cout].permute(0, 3, 1, 2)
     err = (got - ref).abs().max().item()
     assert err < 2e-5 * max(1.0, ref.abs().max().item()), err
+    # x_split = 2: only the activations are split ([hi | lo] against the fp16 weights twice): exact in x, fp16-rounded in w
+    wp2 = ops.pack_conv_weight(w.to(d), CinP, CoutP, split=2)
+    assert wp2.shape == (9, CoutP, 2 * CinP)
+    if (2 * CinP) % 32 == 0:
+        ref2 = F.conv2d(x.double(), w.to(torch.float16).double(), b.double(), padding=1)
+        if act == 1:
+            ref2 = F.gelu(ref2)
+        out2 = ops.conv3x3(xt.to(d), wp2, bp, B, H, W, act=act, x_split=2)
+        got2 = out2.cpu().double().view(B, H, W, CoutP)[..., :Cout].permute(0, 3, 1, 2)
+        assert (got2 - ref2).abs().max().item() < 2e-5 * max(1.0, ref2.abs().max().item())
 
 
 def test_layernorm_res():

@@ -52,6 +52,14 @@ def run(**mode):
     return "max %.2e rms %.2e" % ((y - ref).abs().max().item(), (y - ref).pow(2).mean().sqrt().item())
 hf = torch.float16
 print(name)
+if len(sys.argv) > 2 and sys.argv[2] == "combo":
+    # python tools/precision_sites.py <fixture> combo "site.in,site.w;..."  -- everything fp16 EXCEPT the listed operands, one run per
+    # semicolon-separated list: which half of a split (activations `.in`, weights `.w`) a site actually needs
+    for combo in sys.argv[3].split(";"):
+        mode = {"*": hf}
+        mode.update({k: torch.float32 for k in combo.split(",") if k})
+        print(("fp16 except " + combo)[:100].ljust(102), run(**mode), flush=True)
+    sys.exit(0)
 print("all fp16".ljust(40), run(**{"*": hf}))
 if len(sys.argv) > 2 and sys.argv[2] == "attn":
     for s in ("qk", "p", "v", "attn_out"):

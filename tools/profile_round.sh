@@ -4,6 +4,7 @@
 #   pmc_hbm.txt          FETCH_SIZE / WRITE_SIZE per kernel (separate --pmc passes) over the per-kernel micro-benchmark
 #   pmc_sq.txt           SQ / GRBM counters (MFMA-busy, VALU, wait buckets) for attention, QKV, block tail, CAB convs
 #   bench_line.json      the default bench.py line;  bench_config2.json / bench_config4.json: BASELINE configs[1] / [3]
+#   step_breakdown_configN.txt   tools/step_breakdown.py: share of a forward per C-ABI entry point, random-init and trained scales
 set -u
 ROOT=$(pwd)
 export TMPDIR=/tmp
@@ -32,6 +33,12 @@ tools/pmc_kernels.sh gpurun_out/prof/pmc_sq_all.txt --tiles 4 --iters 3 --only $
 grep -v "at6native\|rocclr" gpurun_out/prof/pmc_sq_all.txt > $OUT/pmc_sq.txt; rm -f gpurun_out/prof/pmc_sq_all.txt
 python tools/bench_kernels.py --tiles 4 2>&1 | grep -v amdgpu.ids > $OUT/bench_kernels.txt
 python tools/bench_kernels.py --tiles 4 --logit-scale 100 --only attn_window,attn_a2w,attn_w2a,qkv_anchor,qkv_split 2>&1 | grep -v amdgpu.ids > $OUT/bench_kernels_scale100.txt
+# per-entry-point share of one forward (single stream, HIP events): the three bench configurations at random-init and at
+# checkpoint-like logit scales
+for c in "8 3" "16 2" "4 4"; do
+  set -- $c
+  { python tools/step_breakdown.py $1 $2; python tools/step_breakdown.py $1 $2 --trained; } 2>&1 | grep -v amdgpu.ids > $OUT/step_breakdown_config$2.txt
+done
 python bench.py --config 2 --tiles 16 --no-cpu-baseline > $OUT/bench_config2.json 2> $OUT/bench_config2.err
 python bench.py --config 4 --tiles 4 --no-cpu-baseline > $OUT/bench_config4.json 2> $OUT/bench_config4.err
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
