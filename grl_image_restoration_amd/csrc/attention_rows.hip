@@ -141,6 +141,9 @@ __global__ __launch_bounds__(RW * 64, D32 ? 3 : 4) void attn_rows_kernel(GrlAttn
         const float mq = p.lazy_floor[head];
         if (!D32 && half) { q01[7] = (f16)(-mq); q11[7] = (f16)(-mq); }   // head-dim slot 31 (K holds 1.0 there)
     }
+    // (pinned here: left alone the region labels are re-derived inside each instance of the chunk loop, and the row / column values
+    // they come from stay alive -- in spill slots -- across the other instance)
+    asm volatile("" : "+v"(idq0), "+v"(idq1));
     float nm0 = -p.lazy_floor[head], nm1 = nm0, l0 = 0.f, l1 = 0.f;   // (D32 only)
     f32x16 O0, O1;
 #pragma unroll
@@ -407,12 +410,16 @@ __global__ __launch_bounds__(RW * 64, D32 ? 3 : 4) void attn_rows_kernel(GrlAttn
         const int lane = lane_id(), half = lane >> 5, l31 = lane & 31;
         const int wq = 32 * sg + l31;
         const float mq0 = D32 ? -nm0 : -xhalf((float)q01[7]), mq1 = D32 ? -nm1 : -xhalf((float)q11[7]);   // lower half-wave <- the upper one's slot 31
-        locate(p.q, b, wy, wx, hq0 * p.q.ww + wq, row, rid);
+        // (an opaque copy of the window width: otherwise the reciprocal and the row / column values of the prologue's locate() are
+        // kept alive across the whole key loop for this one -- five registers in spill slots on a 128-register budget)
+        GrlTokenGrid gq = p.q;
+        asm volatile("" : "+s"(gq.ww));
+        locate(gq, b, wy, wx, hq0 * gq.ww + wq, row, rid);
         float l = D32 ? l0 + xhalf(l0) : ones_row(O0, p.ones_col, half);
         if (poison) l = __builtin_nanf("");
         store_o(p, O0, 1.0f / l, row, head, half);
         if (p.lse != nullptr && half == 0) p.lse[(int64_t)head * p.lse_stride + row] = mq0 + __builtin_amdgcn_logf(l);
-        locate(p.q, b, wy, wx, (hq0 + 1) * p.q.ww + wq, row, rid);
+        locate(gq, b, wy, wx, (hq0 + 1) * gq.ww + wq, row, rid);
         l = D32 ? l1 + xhalf(l1) : ones_row(O1, p.ones_col, half);
         if (poison) l = __builtin_nanf("");
         store_o(p, O1, 1.0f / l, row, head, half);

@@ -6,8 +6,10 @@
 set -u
 cd "$(dirname "$0")/../grl_image_restoration_amd/csrc"
 echo "# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage  (tools/kernel_resources.sh)"
-for f in attention attention_rows attention_bwd mlp tail_regs qkv qkv_anchor conv cab_conv2 grad misc linear linear_k576; do
-  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -I../../include --cuda-device-only -c $f.hip -o /dev/null \
+for f in attention attention_rows attention_bwd mlp tail_regs qkv qkv_anchor conv cab_conv2 linear_split grad misc linear linear_k576; do
+  extra=""
+  case $f in attention|attention_bwd) extra="-mllvm -amdgpu-mfma-vgpr-form";; esac   # as in csrc/Makefile
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -I../../include --cuda-device-only $extra -c $f.hip -o /dev/null \
         -Rpass-analysis=kernel-resource-usage 2>&1 |
     awk '/remark: Function Name:/{name=$(NF-1)} /remark: +TotalSGPRs:/{s=$(NF-1)} /remark: +VGPRs:/{v=$(NF-1)} /remark: +AGPRs:/{a=$(NF-1)}
          /remark: +ScratchSize/{sc=$(NF-1)} /remark: +Occupancy/{o=$(NF-1)} /remark: +VGPRs Spill:/{sp=$(NF-1)}

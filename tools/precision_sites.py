@@ -60,6 +60,11 @@ if len(sys.argv) > 2 and sys.argv[2] == "combo":
         mode.update({k: torch.float32 for k in combo.split(",") if k})
         print(("fp16 except " + combo)[:100].ljust(102), run(**mode), flush=True)
     sys.exit(0)
+if len(sys.argv) > 2 and sys.argv[2] == "only":
+    # python tools/precision_sites.py <fixture> only "site.in;site.w,other.w;..."  -- everything exact EXCEPT the listed operands
+    for combo in sys.argv[3].split(";"):
+        print(("only " + combo + " fp16")[:100].ljust(102), run(**{k: hf for k in combo.split(",") if k}), flush=True)
+    sys.exit(0)
 print("all fp16".ljust(40), run(**{"*": hf}))
 if len(sys.argv) > 2 and sys.argv[2] == "attn":
     for s in ("qk", "p", "v", "attn_out"):
