@@ -167,12 +167,30 @@ def training_leg(args, dev, rank, world):
     for _ in range(2):
         step()
     torch.cuda.synchronize()
+    # single GPU: the whole step (forward, L1, backward, FusedAdamW) replayed as one captured HIP graph -- eager, the ~19 k launches
+    # of a step are host-bound (train_graph.py); the eager time of the same step is reported next to it.  DDP steps stay eager.
+    graphed, eager_ms = None, None
+    if world == 1 and not args.no_train_graph:
+        from grl_image_restoration_amd import GraphedTrainStep
+
+        t0 = time.perf_counter()
+        for _ in range(2):
+            step()
+        torch.cuda.synchronize()
+        eager_ms = (time.perf_counter() - t0) / 2 * 1e3
+        graphed = GraphedTrainStep(net, opt, lambda y, t: (y - t).abs().mean(), lq, gt, warmup=1)
+        for _ in range(2):
+            graphed(lq, gt)
+        run = lambda: graphed(lq, gt)
+    else:
+        run = step
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.train_steps):
-        loss = step()
+        loss = run()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -183,6 +201,8 @@ def training_leg(args, dev, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert math.isfinite(float(loss.detach()))
+    if graphed is not None:
+        graphed.finish()
     ops.profile_begin()
     step()
     prof = ops.profile_end()
@@ -200,6 +220,8 @@ def training_leg(args, dev, rank, world):
     return {
         "workload": "BASELINE configs[4]: GRL-Base x4 SR training, 64x64 LQ synthetic pairs, L1 loss, FusedAdamW(lr 2e-4, wd 1e-4)",
         "batch_per_gpu": bsz, "steps": args.train_steps, "ms_per_step": round(dt / args.train_steps * 1e3, 2),
+        "step_mode": "one captured HIP graph per step (forward + L1 + backward + FusedAdamW), replayed" if graphed is not None else "eager",
+        "eager_ms_per_step": round(eager_ms, 2) if eager_ms is not None else None,
         "samples_per_s": round(world * bsz * args.train_steps / dt, 2),
         "value": round(world * bsz * side * side * args.train_steps / dt / 1e6, 4), "unit": "LQ megapixels/s (training)",
         "parallelism": f"DDP x{world} over RCCL, 32 MB gradient buckets" if world > 1 else "single GPU",
@@ -379,6 +401,7 @@ def main():
     ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS), help="BASELINE config (3 = the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-trained-scales", action="store_true")
+    ap.add_argument("--no-train-graph", action="store_true", help="training leg: eager steps instead of the captured HIP graph")
     ap.add_argument("--no-tiled", action="store_true")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3)

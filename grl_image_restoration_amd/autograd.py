@@ -45,11 +45,26 @@ class _State:
     # (keying by thread as well would hide the value from the thread that called backward())
     scales: dict = {}
     target = 64.0        # the largest incoming gradient is brought to about this magnitude
+    frozen = False       # frozen_grad_scale(): keep the current scales (no host read of max|dL/dy|: graph capture)
 
 
 def _scale_key(device) -> int:
     idx = torch.device(device).index if device is not None else None
     return idx if idx is not None else torch.cuda.current_device()
+
+
+class frozen_grad_scale:
+    """Context: the backward passes inside keep the gradient operand scale of the last pass before it instead of reading
+    max|dL/dy| back to the host -- what a step captured in a HIP graph needs (the scale is a power of two with 2^10 of headroom to
+    the fp16 range: it only has to be of the right order of magnitude)."""
+
+    def __enter__(self):
+        self._prev, _State.frozen = _State.frozen, True
+        return self
+
+    def __exit__(self, *exc):
+        _State.frozen = self._prev
+        return False
 
 
 def grad_scale(device=None) -> float:
@@ -65,6 +80,8 @@ class GradScaleTop(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if _State.frozen:
+            return dy
         amax = float(dy.abs().max())
         _State.scales[_scale_key(dy.device)] = 2.0 ** math.floor(math.log2(_State.target / amax)) if amax > 0 and math.isfinite(amax) else 1.0
         return dy
@@ -261,53 +278,58 @@ def _conv_backward(ctx, dy):
 conv3x3_op.register_autograd(_conv_backward, setup_context=_conv_setup)
 
 
-def _attn_operands(q, k, v, d):
+def _attn_operands(q, k, v, d, prepared):
+    """fp16 copies of the head planes for the kernels.  ``prepared``: the caller has already put the constants into the pad
+    columns (GRL._to_planes: 1.0 in k's slot 31 and in v's column d) -- otherwise two index fills per call."""
     q16 = q.detach().to(ops.PLANE_DTYPE)
     k16 = k.detach().to(ops.PLANE_DTYPE)
     v16 = v.detach().to(ops.PLANE_DTYPE)
-    if d <= 30:
-        k16[..., 31] = 1.0          # partner of the kernel's running softmax offset (q slot 31)
-    if d < 32:
-        v16[..., d] = 1.0           # ones column: the softmax denominator falls out of the PV product
+    if not prepared:
+        if d <= 30:
+            k16[..., 31] = 1.0          # partner of the kernel's running softmax offset (q slot 31)
+        if d < 32:
+            v16[..., d] = 1.0           # ones column: the softmax denominator falls out of the PV product
     return q16, k16, v16
 
 
 @torch.library.custom_op("grl::attention", mutates_args=())
 def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, floor: torch.Tensor, qgeo: Sequence[int],
-                 kgeo: Sequence[int], B: int, nh: int, d: int, masked: bool) -> tuple[torch.Tensor, torch.Tensor]:
+                 kgeo: Sequence[int], B: int, nh: int, d: int, masked: bool,
+                 prepared: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """softmax(q k^T + bias (+ mask)) v over every window (grl_attention_fwd); operands are fp32 head planes [nh, tokens, 32]
     (fp16 in the kernel): q = normalised * scale * log2e, k normalised, v raw; ``table`` from tables.kernel_table; ``floor`` from
-    tables.lazy_floor; qgeo / kgeo = (Himg, Wimg, wh, ww, shy, shx).  Returns (fp32 planes [nh, q_tokens, 32], log2-sum-exp2)."""
-    q16, k16, v16 = _attn_operands(q, k, v, d)
+    tables.lazy_floor; qgeo / kgeo = (Himg, Wimg, wh, ww, shy, shx).  Returns (fp32 planes [nh, q_tokens, 32], log2-sum-exp2,
+    and the fp16 operand planes the kernel ran on -- kept for the backward pass instead of converting them again)."""
+    q16, k16, v16 = _attn_operands(q, k, v, d, prepared)
     o = torch.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
     lse = torch.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
     TG = ops.TokenGrid
     ops.attention(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), B=B, nh=nh, table=table.detach().contiguous(),
                   masked=masked, ones_col=d if d < 32 else -1, head_dim=d, k_one31=d <= 30, lazy_floor=floor if d <= 30 else None, lse=lse)
-    return o, lse
+    return o, lse, q16, k16, v16
 
 
 @attention_op.register_fake
-def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked):
-    return q.new_empty(nh, q.shape[1], 32, dtype=torch.float32), q.new_empty(nh, q.shape[1], dtype=torch.float32)
+def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared=False):
+    h = lambda t: t.new_empty(t.shape, dtype=ops.PLANE_DTYPE)
+    return q.new_empty(nh, q.shape[1], 32, dtype=torch.float32), q.new_empty(nh, q.shape[1], dtype=torch.float32), h(q), h(k), h(v)
 
 
 def _attn_setup(ctx, inputs, output):
-    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked = inputs
-    o, lse = output
-    ctx.save_for_backward(q, k, v, table, o, lse)
+    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared = inputs
+    o, lse, q16, k16, v16 = output
+    ctx.save_for_backward(q16, k16, v16, table, o, lse)
     ctx.geo = (tuple(qgeo), tuple(kgeo), B, nh, d, masked)
 
 
-def _attn_backward(ctx, d_o, d_lse):
-    q, k, v, table, o, lse = ctx.saved_tensors
+def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
+    q16, k16, v16, table, o, lse = ctx.saved_tensors
     qgeo, kgeo, B, nh, d, masked = ctx.geo
-    q16, k16, v16 = _attn_operands(q, k, v, d)
     TG = ops.TokenGrid
     dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o.float().contiguous(),
                                          lse, B=B, nh=nh, table=table.detach().contiguous(), masked=masked, ones_col=d if d < 32 else -1,
                                          head_dim=d, g_scale=grad_scale(d_o.device))
-    return dq, dk, dv, dtab, None, None, None, None, None, None, None
+    return dq, dk, dv, dtab, None, None, None, None, None, None, None, None
 
 
 attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
@@ -319,7 +341,8 @@ class AttentionFn:
 
     @staticmethod
     def apply(q, k, v, table, geo):
-        return attention_op(q, k, v, table, geo["floor"], list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]))[0]
+        return attention_op(q, k, v, table, geo["floor"], list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]),
+                            bool(geo.get("prepared", False)))[0]
 
 
 def linear(x, w, b=None):

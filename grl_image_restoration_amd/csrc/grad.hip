@@ -127,6 +127,11 @@ __global__ __launch_bounds__(256) void adamw_kernel(GrlAdamWArgs p) {
     float* m = (float*)p.exp_avg[t];
     float* v = (float*)p.exp_avg_sq[t];
     const float wd = p.weight_decay_flags != nullptr && p.weight_decay_flags[t] == 0 ? 0.f : p.weight_decay;
+    float bc1 = p.bias_correction1, bc2s = p.bias_correction2_sqrt;
+    if (p.bias_corrections_dev != nullptr) {   // graph replay: the step count, and what depends on it, live on the device
+        bc1 = p.bias_corrections_dev[0];
+        bc2s = p.bias_corrections_dev[1];
+    }
 #pragma unroll 4
     for (int64_t i = off + threadIdx.x; i < min(n, off + 4096); i += 256) {
         const float gi = g[i] * p.grad_scale;
@@ -136,8 +141,8 @@ __global__ __launch_bounds__(256) void adamw_kernel(GrlAdamWArgs p) {
         const float vi = p.beta2 * v[i] + (1.0f - p.beta2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
-        const float denom = sqrtf(vi) / p.bias_correction2_sqrt + p.eps;
-        w[i] = wi - (p.lr / p.bias_correction1) * (mi / denom);
+        const float denom = sqrtf(vi) / bc2s + p.eps;
+        w[i] = wi - (p.lr / bc1) * (mi / denom);
     }
 }
 

@@ -852,11 +852,23 @@ class GRL(nn.Module):
         m = x.new_empty(x.shape[0] // rows_per_image, 1, 1).bernoulli_(keep) / keep
         return (x.view(-1, rows_per_image, x.shape[1]) * m).view_as(x)
 
-    @staticmethod
-    def _to_planes(t, extra: int = 32):
-        """[tokens, nh, d] -> fp32 head planes [nh, tokens, 32] (zero padded)."""
-        return F.pad(t.permute(1, 0, 2), (0, extra - t.shape[-1])).contiguous()   # pads the permuted view: fill + one strided copy
-        #                                      (head_dim 32: nothing to pad, .contiguous() makes the copy)
+    def _to_planes(self, t, one_col: int = -1, extra: int = 32):
+        """[tokens, nh, d] -> fp32 head planes [nh, tokens, 32] in ONE launch: a cat with a cached constant block for the pad
+        columns (F.pad is a fill plus a strided copy) -- zeros, and 1.0 in plane column ``one_col`` where the attention kernel
+        wants a constant (k: slot 31, the partner of the running softmax offset; v: column d, the softmax denominator), so that
+        the attention op needs no index fills (``prepared`` operands)."""
+        M, nh, d = t.shape
+        if d == extra:
+            return t.permute(1, 0, 2).contiguous()
+        cache = self.__dict__.setdefault("_coords_cache", {})
+        key = ("padblk", nh, M, extra - d, one_col, str(t.device))
+        blk = cache.get(key)
+        if blk is None:
+            blk = torch.zeros(nh, M, extra - d, dtype=torch.float32, device=t.device)
+            if one_col >= d:
+                blk[..., one_col - d] = 1.0
+            cache[key] = blk
+        return torch.cat([t.permute(1, 0, 2), blk], dim=2)
 
     def _attn_table(self, m: _Affine, win, df, dev):
         key = (tuple(win), df, str(dev))
@@ -887,6 +899,8 @@ class GRL(nn.Module):
         qw, kw, vw = qkv[:, : 3 * C // 2].reshape(M, 3, nh_w, d_w).unbind(1)
         qs, ks, vs = qkv[:, 3 * C // 2 :].reshape(M, 3, nh_s, d_s).unbind(1)
         P = self._to_planes
+        k1_w, k1_s = (31 if d_w <= 30 else -1), (31 if d_s <= 30 else -1)     # plane columns that hold a constant 1.0 (see _to_planes)
+        v1_w, v1_s = (d_w if d_w < 32 else -1), (d_s if d_s < 32 else -1)
 
         def floor(sc):   # tables.lazy_floor from the already scaled value: sc = clamped scale * log2e
             return -1.0 - torch.ceil(sc.detach())
@@ -900,24 +914,27 @@ class GRL(nn.Module):
         # window attention (efficient.py:128-165)
         tw = a.window_attn.attn_transform
         sw = self._scale(tw)
-        ow = AG.AttentionFn.apply(P(F.normalize(qw, dim=-1) * sw.view(1, nh_w, 1)), P(F.normalize(kw, dim=-1)), P(vw),
+        ow = AG.AttentionFn.apply(P(F.normalize(qw, dim=-1) * sw.view(1, nh_w, 1)), P(F.normalize(kw, dim=-1), k1_w), P(vw, v1_w),
                                   self._attn_table(tw, geo.window, 1, dev),
-                                  dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh_w, d=d_w, masked=sh > 0, floor=floor(sw)))
+                                  dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh_w, d=d_w, masked=sh > 0, floor=floor(sw), prepared=True))
         # anchored stripe attention (efficient.py:215-270): anchors -> stripe tokens, then stripe tokens -> anchors
         t1, t2 = a.stripe_attn.attn_transform1, a.stripe_attn.attn_transform2
         an = F.normalize(anc, dim=-1)
         s1, s2 = self._scale(t1), self._scale(t2)
-        y = AG.AttentionFn.apply(P(an * s1.view(1, nh_s, 1)), P(F.normalize(ks, dim=-1)), P(vs),
+        y = AG.AttentionFn.apply(P(an * s1.view(1, nh_s, 1)), P(F.normalize(ks, dim=-1), k1_s), P(vs, v1_s),
                                  self._attn_table(t1, geo.stripe, df, dev),
-                                 dict(q=g_anc, k=g_tok_s, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s1)))
+                                 dict(q=g_anc, k=g_tok_s, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s1), prepared=True))
         cache = self.__dict__.setdefault("_coords_cache", {})
         dmask = cache.get(("dmask", d_s, str(dev)))
         if dmask is None:
             dmask = cache[("dmask", d_s, str(dev))] = (torch.arange(32, device=dev) < d_s).float()
-        yv = y * dmask                                                  # real head dims only (the kernel's ones column is not a value)
-        os_ = AG.AttentionFn.apply(P(F.normalize(qs, dim=-1) * s2.view(1, nh_s, 1)), P(an), yv,
+        onev = cache.get(("onev", d_s, str(dev)))
+        if onev is None:
+            onev = cache[("onev", d_s, str(dev))] = (torch.arange(32, device=dev) == v1_s).float()
+        yv = torch.addcmul(onev, y, dmask)                              # real head dims only, and the constant 1.0 in column d again
+        os_ = AG.AttentionFn.apply(P(F.normalize(qs, dim=-1) * s2.view(1, nh_s, 1)), P(an, k1_s), yv,
                                    self._attn_table(t2, geo.stripe, df, dev),
-                                   dict(q=g_tok_s, k=g_anc, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s2)))
+                                   dict(q=g_tok_s, k=g_anc, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s2), prepared=True))
         att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
         x1 = r + self.res_scale * self._drop_path(F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp, self.training)

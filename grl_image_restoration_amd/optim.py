@@ -22,6 +22,8 @@ class FusedAdamW(torch.optim.Optimizer):
             raise ValueError("invalid AdamW hyper-parameter")
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
+        self._step_dev = None     # capture mode (enable_capture): per group, the step count as a device tensor
+        self._pinned = {}         # per group: pinned host table of gradient pointers, read by the captured copy on every replay
 
     def _group_tables(self, gi, plist):
         """Device pointer / size tables of a parameter group (rebuilt when the set of tensors or their storage changes)."""
@@ -71,6 +73,30 @@ class FusedAdamW(torch.optim.Optimizer):
                 if k in s and (s[k].dtype != torch.float32 or not s[k].is_contiguous() or s[k].device != p.device):
                     s[k] = s[k].to(device=p.device, dtype=torch.float32).contiguous()
 
+    def enable_capture(self):
+        """Makes ``step()`` replayable from a HIP graph (train_graph.GraphedTrainStep): the step count moves to device memory
+        (incremented by a captured op; the bias corrections are computed from it on the device, in float64 like the host path,
+        and handed to the kernel as GrlAdamWArgs.bias_corrections_dev) and the table of gradient pointers is copied from pinned
+        host memory.  Call after at least one eager step (the moments must exist)."""
+        self._step_dev = {}
+        for gi, group in enumerate(self.param_groups):
+            steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]}
+            if len(steps) != 1:
+                raise RuntimeError("FusedAdamW.enable_capture: run an eager step first (every parameter of a group needs the same step count)")
+            dev = group["params"][0].device
+            self._step_dev[gi] = torch.full((1,), steps.pop(), dtype=torch.int64, device=dev)
+            # (allocated here: pinning host memory is not allowed while a stream is capturing)
+            self._pinned[gi] = torch.zeros(len(group["params"]), dtype=torch.int64).pin_memory()
+
+    def sync_step_from_device(self):
+        """After graph replays: the host-side ``state[p]['step']`` (what state_dict() saves) <- the device counters."""
+        if self._step_dev:
+            for gi, group in enumerate(self.param_groups):
+                n = int(self._step_dev[gi].item())
+                for p in group["params"]:
+                    if p in self.state and "step" in self.state[p]:
+                        self.state[p]["step"] = n
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = None
@@ -95,17 +121,33 @@ class FusedAdamW(torch.optim.Optimizer):
             if len(steps) != 1:
                 raise RuntimeError("FusedAdamW: parameters of one group must share their step count")
             step = steps.pop() + 1
-            for p in plist:
-                self.state[p]["step"] = step
-            ent = self._group_tables(gi, plist)
-            grads = torch.tensor([p.grad.data_ptr() for p in plist], dtype=torch.int64, device=plist[0].device)
+            capturing = torch.cuda.is_current_stream_capturing()
+            if capturing and self._step_dev is None:
+                raise RuntimeError("FusedAdamW: call enable_capture() before capturing step() in a graph")
+            if not capturing:              # (a captured step does not execute: the device counter advances on replay only)
+                for p in plist:
+                    self.state[p]["step"] = step
             b1, b2 = group["betas"]
+            bc_dev = None
+            if self._step_dev is not None:
+                sd = self._step_dev[gi]
+                sd.add_(1)
+                t = sd.double()
+                bc_dev = torch.cat([1.0 - b1 ** t, (1.0 - b2 ** t).sqrt()]).float()   # (1 - 0.999^t cancels in float32: 6e-5 off at t = 2)
+            ent = self._group_tables(gi, plist)
+            if capturing:
+                host = self._pinned[gi][: len(plist)]
+                host.copy_(torch.tensor([p.grad.data_ptr() for p in plist], dtype=torch.int64))
+                grads = host.to(plist[0].device, non_blocking=True)
+            else:
+                grads = torch.tensor([p.grad.data_ptr() for p in plist], dtype=torch.int64, device=plist[0].device)
             args = L.GrlAdamWArgs(
                 params=ent["params"].data_ptr(), grads=grads.data_ptr(), exp_avg=ent["exp_avg"].data_ptr(),
                 exp_avg_sq=ent["exp_avg_sq"].data_ptr(), numel=ent["numel"].data_ptr(), weight_decay_flags=None,
                 chunk_tensor=ent["chunk_tensor"].data_ptr(), chunk_offset=ent["chunk_offset"].data_ptr(), num_chunks=ent["n"],
                 lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
                 bias_correction1=1.0 - b1 ** step, bias_correction2_sqrt=(1.0 - b2 ** step) ** 0.5, grad_scale=grad_scale,
+                bias_corrections_dev=bc_dev.data_ptr() if bc_dev is not None else None,
             )
             L.check(lib.grl_adamw_step(L.stream_ptr(), C.byref(args)), "grl_adamw_step")
             # the kernel wrote through raw pointers: tell autograd (and GRL's plan version stamp) that the tensors changed in place

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 18
+#define GRL_ABI_VERSION 19
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -482,6 +482,9 @@ typedef struct GrlAdamWArgs {
     float lr, beta1, beta2, eps, weight_decay;
     float bias_correction1, bias_correction2_sqrt;
     float grad_scale;                    /* gradients are multiplied by this (1 / loss scale, DDP averaging) */
+    const float* bias_corrections_dev;   /* optional: {bias_correction1, bias_correction2_sqrt} in DEVICE memory, computed on the */
+                                         /* device from a device-side step count; the two host fields above are then ignored --   */
+                                         /* a launch captured in a HIP graph stays correct when it is replayed                    */
 } GrlAdamWArgs;
 
 int grl_adamw_step(void* stream, const GrlAdamWArgs* args);

@@ -412,3 +412,71 @@ def test_training_gradients_other_geometries_vs_oracle_autograd(model, geom, up,
     print(f"{model}/{geom}: loss {loss.item():.6f} vs {lo.item():.6f}; d/dx {ex:.2e}; median {med:.2e}; worst {[(k, round(e, 4)) for k, e in srt[:4]]}")
     # fp16 operands forward and backward: 1e-2 typical; the smallest gradients (CPB-MLP biases of late blocks) up to a few percent
     assert ex < 5e-2 and med < 1e-2 and srt[0][1] < 6e-2, srt[:4]
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_matches_eager_steps():
+    """train_graph.GraphedTrainStep: forward + L1 + backward + FusedAdamW captured once as a HIP graph and replayed follows the
+    eager steps as closely as two eager runs follow each other (the gradient GEMMs accumulate with atomics and Adam's first steps
+    turn noise-level gradients into +-lr updates, so no two runs are bit-identical), the optimizer's step count arrives on the
+    host, and the eager / inference paths pick the updated weights up afterwards."""
+    from grl_image_restoration_amd import GRL, FusedAdamW, GraphedTrainStep, make_config
+
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[2, 2], num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+                      drop_path_rate=0.0)
+    models, opts = [], []
+    for _ in range(3):                                   # two eager runs (the yardstick) and the graphed one
+        torch.manual_seed(0)
+        m = GRL(**cfg)
+        m.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0), strict=True)
+        models.append(m.cuda().train())
+        opts.append(FusedAdamW(models[-1].parameters(), lr=2e-4, weight_decay=1e-4))
+    lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=2, seed=12)
+    lq, gt = lq.cuda(), gt.cuda()
+    loss_fn = lambda y, t: (y - t).abs().mean()
+    n_replays = 3
+
+    def eager(i):
+        out = []
+        for _ in range(1 + n_replays):                   # 1 warm-up step + as many as the graph replays
+            opts[i].zero_grad(set_to_none=True)
+            loss = loss_fn(models[i](lq), gt)
+            loss.backward()
+            opts[i].step()
+            out.append(float(loss.detach()))
+        return out[1:]
+
+    la, lb = eager(0), eager(1)
+    step = GraphedTrainStep(models[2], opts[2], loss_fn, lq, gt, warmup=1)
+    lg = [float(step(lq, gt).detach()) for _ in range(n_replays)]
+    step.finish()
+
+    def dist(i, j):    # mean |difference| over all parameters
+        num = sum(float((p - q).abs().sum()) for p, q in zip(models[i].parameters(), models[j].parameters()))
+        return num / sum(p.numel() for p in models[i].parameters())
+
+    d_ee, d_eg = dist(0, 1), dist(0, 2)
+    l_ee = max(abs(a - b) for a, b in zip(la, lb))
+    l_eg = max(abs(a - b) for a, b in zip(la, lg))
+    print(f"losses eager {la} | eager {lb} | graph {lg}")
+    print(f"mean |dp| eager-eager {d_ee:.3e}, eager-graph {d_eg:.3e}; max |dloss| {l_ee:.3e} / {l_eg:.3e}")
+    assert lg[-1] < lg[0] and all(abs(a - b) <= 2e-4 * abs(a) for a, b in zip(la, lg))
+    assert d_eg <= 4 * d_ee + 1e-7 and l_eg <= 4 * l_ee + 2e-6
+    p2 = next(iter(models[2].parameters()))
+    assert opts[2].state[p2]["step"] == 1 + n_replays and opts[0].state[next(iter(models[0].parameters()))]["step"] == 1 + n_replays
+    # one more EAGER step on the graphed model: the optimizer state and the cached fp16 weight copies are in step
+    before = dist(0, 2)
+    for i in (0, 2):
+        opts[i].zero_grad(set_to_none=True)
+        loss_fn(models[i](lq), gt).backward()
+        opts[i].step()
+    assert dist(0, 2) <= 2 * before + 4 * d_ee + 1e-7
+    with torch.no_grad():
+        y0, y2 = models[0].eval()(lq), models[2].eval()(lq)
+    assert float((y0 - y2).abs().max()) <= 2e-3        # (different weights by the noise above; the inference path sees the UPDATED ones:)
+    with torch.no_grad():
+        torch.manual_seed(0)
+        fresh = GRL(**cfg)
+        fresh.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in fresh.state_dict().items()}, 0), strict=True)
+        y_init = fresh.cuda().eval()(lq)
+    assert float((y2 - y_init).abs().max()) > 10 * float((y0 - y2).abs().max())
