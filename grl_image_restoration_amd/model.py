@@ -896,8 +896,11 @@ class GRL(nn.Module):
         qkv = AG.linear(r, a.qkv.body.weight, a.qkv.body.bias)                                 # QKVProjection (mixed_attn_block.py:669-676)
         pooled = r.view(B, Ha, df, Wa, df, C).mean(dim=(2, 4)).reshape(B * Ha * Wa, C)          # AnchorLinear avg-pool (:727-736)
         anc = AG.linear(pooled, a.anchor.body[0].reduction.weight, a.anchor.body[0].reduction.bias).view(-1, nh_s, d_s)
-        qw, kw, vw = qkv[:, : 3 * C // 2].reshape(M, 3, nh_w, d_w).unbind(1)
-        qs, ks, vs = qkv[:, 3 * C // 2 :].reshape(M, 3, nh_s, d_s).unbind(1)
+        if (nh_w, d_w) == (nh_s, d_s):   # one view, one unbind: the backward is a single stack instead of two slice-backwards (zeros + copy) and an add
+            qw, kw, vw, qs, ks, vs = qkv.view(M, 6, nh_w, d_w).unbind(1)
+        else:
+            qw, kw, vw = qkv[:, : 3 * C // 2].reshape(M, 3, nh_w, d_w).unbind(1)
+            qs, ks, vs = qkv[:, 3 * C // 2 :].reshape(M, 3, nh_s, d_s).unbind(1)
         P = self._to_planes
         k1_w, k1_s = (31 if d_w <= 30 else -1), (31 if d_s <= 30 else -1)     # plane columns that hold a constant 1.0 (see _to_planes)
         v1_w, v1_s = (d_w if d_w < 32 else -1), (d_s if d_s < 32 else -1)
@@ -935,7 +938,10 @@ class GRL(nn.Module):
         os_ = AG.AttentionFn.apply(P(F.normalize(qs, dim=-1) * s2.view(1, nh_s, 1)), P(an, k1_s), yv,
                                    self._attn_table(t2, geo.stripe, df, dev),
                                    dict(q=g_tok_s, k=g_anc, B=B, nh=nh_s, d=d_s, masked=geo.stripe_shift, floor=floor(s2), prepared=True))
-        att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
+        if d_w == d_s:                    # one cat of the planes, one slice (its backward: one zeros + copy instead of two)
+            att = torch.cat([ow, os_], dim=0).permute(1, 0, 2)[..., :d_w].reshape(M, C)
+        else:
+            att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
         x1 = r + self.res_scale * self._drop_path(F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp, self.training)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
