@@ -877,7 +877,15 @@ class GRL(nn.Module):
         if coords is None:
             coords = cache[key] = tables.coords_table(win, df, device=dev)
         h = F.relu(F.linear(coords, m.cpb_mlp[0].weight, m.cpb_mlp[0].bias))
-        return tables.kernel_table(16.0 * torch.sigmoid(F.linear(h, m.cpb_mlp[2].weight)))     # differentiable w.r.t. the CPB-MLP
+        # tables.kernel_table(16 * sigmoid(.)) -- transpose, exp2 domain, reversed rows, padded to 4 -- as ONE gather and one scale
+        # (the chain of t / mul / flip / pad and its backward were ~15 launches per attention call, 120 calls per step); the pad
+        # entries repeat row 0 instead of being zero: no valid (query, key) pair addresses them
+        rows = coords.shape[0]
+        idx = cache.get(("revidx", rows, str(dev)))
+        if idx is None:
+            idx = cache[("revidx", rows, str(dev))] = torch.cat([torch.arange(rows - 1, -1, -1, device=dev),
+                                                                   torch.zeros((-rows) % 4, dtype=torch.long, device=dev)])
+        return torch.sigmoid(F.linear(h, m.cpb_mlp[2].weight)).t().index_select(1, idx) * (16.0 * LOG2E)     # differentiable w.r.t. the CPB-MLP
 
     @staticmethod
     def _scale(m: _Affine):
