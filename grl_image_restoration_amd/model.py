@@ -523,11 +523,14 @@ class GRL(nn.Module):
             se = blk.conv.cab[3].attention
             Cm = c0.weight.shape[0]
             CmO, CmI = (Cm + 15) // 16 * 16, _pad32(Cm)  # conv1 writes CmO channels of a zeroed CmI-wide matrix
-            if hi:
+            hi_c = hi and not self._high_cab_fp16()   # (the CAB convs of an auto-resolved `high` Base-width model stay on fp16 operands)
+            if hi_c:
                 CmO = CmI   # fp32 mid tensor written by the plain store path: every channel of its row comes from the conv
-            sp = 3 if hi else 1
+            sp = 3 if hi_c else 1
             sites = _split_sites(os.environ.get("GRL_SPLIT_SITES", self.split_sites))
-            pk["cab0_split"] = 3 if hi else sites.get("cab0", 1)   # the CAB's first conv on split operands (per-site precision, see _plan)
+            # the CAB's first conv on split operands: everything-split `high`; the fast path's per-site choice (see _plan); fp16 in the
+            # auto-resolved `high` of a Base-width model (_high_cab_fp16: every other site is split there, so this one can afford it)
+            pk["cab0_split"] = 3 if hi_c else (1 if hi else sites.get("cab0", 1))
             pk.update(
                 cab0_w=ops.pack_conv_weight(c0.weight.to(dev), CP, CmO, split=pk["cab0_split"]), cab0_b=ops.pack_conv_bias(c0.bias.to(dev), CmO),
                 cab2_w=ops.pack_conv_weight(c2.weight.to(dev), CmI, CP, split=sp), cab2_b=ops.pack_conv_bias(c2.bias.to(dev), CP),
@@ -537,9 +540,20 @@ class GRL(nn.Module):
                 se3_w=se[3].weight.detach().float().reshape(C, -1).to(dev).clone(),
                 se3_b=se[3].bias.detach().float().to(dev).clone(),
             )
-            if not hi and CP == 192 and Cm <= 48 and CmI >= 56 and os.environ.get("GRL_CAB_CONV2", "1") != "0":
+            if not hi_c and CP == 192 and Cm <= 48 and CmI >= 56 and os.environ.get("GRL_CAB_CONV2", "1") != "0":
                 pk["cab2_blob"], pk["cab2_bias"] = ops.pack_cab_conv2(c2.weight.to(dev), c2.bias.to(dev))   # csrc/cab_conv2.hip
         return pk
+
+    def _high_cab_fp16(self) -> bool:
+        """In a `high` that `auto` chose for a Base-width model (deblur / denoise at checkpoint-like scales) the two CAB convolutions
+        stay on fp16 operands with the fast path's kernels: emulated per operand on the clamp-scale deblur fixture
+        (tools/precision_sites.py only ...) they are the least sensitive sites of the net -- conv1 3.4e-4 / 2.5e-4 (weights /
+        input alone), conv2 1.9e-4 / 2.3e-4, against 1e-3 for the stage conv's weights alone -- and on split operands they were 41
+        of a 188 ms forward.  An explicit precision='high' (and GRL-Tiny) keeps every contraction split.  GRL_HIGH_CAB=split|fp16."""
+        mode = os.environ.get("GRL_HIGH_CAB", "")
+        if mode in ("split", "fp16"):
+            return mode == "fp16"
+        return self._precision_arg == "auto" and self.embed_dim >= 160
 
     def _resolve_precision(self) -> str:
         """precision='auto' for the weights the module holds NOW (called when a plan is built, i.e. after every weight change).
@@ -643,7 +657,7 @@ class GRL(nn.Module):
     def _cab(self, r, pk, B, H, W, CP):
         """CAB branch (mixed_attn_block.py:948-983): returns the un-gated conv output and the per-image squeeze-excite
         gate; the gate is applied inside the proj+norm1 epilogue.  fast: fp16 intermediates; high: fp32 + split operands."""
-        hi = self.precision == "high"
+        hi = self.precision == "high" and not self._high_cab_fp16()
         sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
         mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=pk["cab0_split"])

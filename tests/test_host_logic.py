@@ -254,9 +254,10 @@ def test_training_contractions_are_registered_torch_ops():
     c = torch.ops.grl.conv3x3(torch.empty(2 * 8 * 8, 180, device="meta"), torch.empty(45, 180, 3, 3, device="meta"), torch.empty(45, device="meta"), 2, 8, 8)
     assert c.shape == (128, 45)
     q = torch.empty(3, 256, 32, device="meta")
-    o, lse = torch.ops.grl.attention(q, q, q, torch.empty(3, 228, device="meta"), torch.empty(3, device="meta"), [16, 16, 8, 8, 4, 4],
-                                     [16, 16, 8, 8, 4, 4], 1, 3, 30, True)
+    o, lse, q16, k16, v16 = torch.ops.grl.attention(q, q, q, torch.empty(3, 228, device="meta"), torch.empty(3, device="meta"), [16, 16, 8, 8, 4, 4],
+                                                    [16, 16, 8, 8, 4, 4], 1, 3, 30, True)
     assert o.shape == (3, 256, 32) and lse.shape == (3, 256)
+    assert all(t.shape == q.shape and t.dtype == torch.float16 for t in (q16, k16, v16))   # the operand planes the kernel ran on (kept for backward)
 
 
 def test_training_operand_caches():
