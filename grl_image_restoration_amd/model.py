@@ -559,7 +559,8 @@ class GRL(nn.Module):
         """precision='auto' for the weights the module holds NOW (called when a plan is built, i.e. after every weight change).
         GRL-Tiny: high.  The narrow / same-resolution models (GRL-Small, anything without the smoothing upsampler tail: denoise,
         deblur) hold the 1e-3 bar on fp16 operands only at random-init logit scales (7.2e-4 / 8.2e-4); with checkpoint-like
-        scales the round-4 clamp-scale fixtures measure 2.5e-3 (Base deblur) and worse (Small), against 4.5e-5 in `high` -- the
+        scales the round-4 clamp-scale fixtures measure 2.5e-3 (Base deblur) and worse (Small), against 5.9e-4 in the `high` chosen here
+        (5.0e-5 with every contraction split, _high_cab_fp16) -- the
         cosine logits are multiplied by up to 100 and these nets have no tail that averages the error out.  So above
         GRL_NARROW_HIGH_SCALE (25: random init draws 5 .. 20) they run on split operands throughout.  GRL-Base SR stays fast at
         every scale (blocks above GRL_HIQ_SCALE take the split-operand q / k / anchor projection: 8.1e-4 at the clamp)."""

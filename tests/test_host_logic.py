@@ -385,3 +385,73 @@ def test_forget_parameters_follows_replaced_tensors():
     m2 = torch.nn.Linear(4, 4)
     AG.forget_parameters(m2)
     assert m2 not in AG._REGISTERED
+
+
+def test_transposed_view_is_the_same_attention_on_the_oracle():
+    """GrlTokenGrid.transposed + ops.transpose_table (round 4): launching a (query window, key window) pair on the transposed view
+    of its grids with the transposed bias table is the SAME attention.  Checked on the oracle's own index arithmetic
+    (models/common/ops.py:352-375 as restated in oracle/grl_oracle.py): for every (query, key) pair the row of the transposed
+    table that the transposed geometry addresses holds the entry the original geometry addresses -- and the shifted-window masks
+    of the transposed problem are the original ones with the token order transposed."""
+    import torch
+
+    from grl_image_restoration_amd import ops
+    from oracle import grl_oracle as O
+
+    for win, df, w2a in (((8, 4), 2, True), ((8, 4), 2, False), ((12, 24), 4, True), ((6, 6), 1, True), ((16, 32), 4, False)):
+        awin = (win[0] // df, win[1] // df)
+        q_win, k_win = (win, awin) if w2a else (awin, win)
+        idx = O.rel_index(win, df, w2a)                                   # [Nq, Nk] -> row of the (Dy*Dx)-row table
+        winT, q_winT, k_winT = (win[1], win[0]), (q_win[1], q_win[0]), (k_win[1], k_win[0])
+        idxT = O.rel_index(winT, df, w2a)                                 # the transposed problem's rows
+        rows = (q_win[0] + k_win[0] - 1) * (q_win[1] + k_win[1] - 1)
+        assert int(idx.max()) == rows - 1 == int(idxT.max())
+        bias = torch.arange(rows, dtype=torch.float32).view(rows, 1) * 1.0 + 0.25     # a table whose entries identify their row
+        biasT = ops.transpose_table(bias, q_win, k_win)
+        # token (h, w) of a window is token (w, h) of the transposed window
+        def perm(wn):
+            h, w = torch.meshgrid(torch.arange(wn[0]), torch.arange(wn[1]), indexing="ij")
+            return (w * wn[0] + h).reshape(-1)                            # position in the transposed window's row-major order
+        pq, pk = perm(q_win), perm(k_win)
+        got = biasT[idxT.reshape(-1), 0].view(idxT.shape)[pq][:, pk]      # entry the transposed launch adds for the ORIGINAL (q, k) pair
+        want = bias[idx.reshape(-1), 0].view(idx.shape)
+        assert torch.equal(got, want), (win, df, w2a)
+
+    # region masks: transposing image, window and shift transposes the token order inside each window and the order of the windows
+    res, win, shift = (16, 24), (8, 12), (4, 6)
+    m = O.shift_mask(res, win, shift, mode="w")                           # [nW, N, N]
+    mT = O.shift_mask((res[1], res[0]), (win[1], win[0]), (shift[1], shift[0]), mode="w")
+    nwy, nwx = res[0] // win[0], res[1] // win[1]
+    h, w = torch.meshgrid(torch.arange(win[0]), torch.arange(win[1]), indexing="ij")
+    p = (w * win[0] + h).reshape(-1)
+    for wy in range(nwy):
+        for wx in range(nwx):
+            assert torch.equal(mT[wx * nwy + wy][p][:, p], m[wy * nwx + wx])
+
+
+def test_split_site_spec_and_linear_split_blob_layout():
+    """model._split_sites ('name' = both operands split, 'name:x' = activations only) and ops.pack_linear_split: the register image
+    of include/grl_hip.h (GrlLinearArgs.w_regs) -- per slab of 192 columns and compute wave the hi, then the lo A fragments, lane l
+    element e of k-step s = W[32 (6 slab + wave) + (l & 31)][16 s + 8 (l >> 5) + e], columns beyond Npad zero."""
+    import torch
+
+    from grl_image_restoration_amd import _lib, ops
+    from grl_image_restoration_amd.model import _split_sites
+
+    assert _split_sites("stage_conv:x,after,last,cab0") == {"stage_conv": 2, "after": 3, "last": 3, "cab0": 3}
+    assert _split_sites("") == {}
+    g = torch.Generator().manual_seed(5)
+    for N, K in ((576, 192), (96, 192), (128, 128), (192, 384)):
+        w = torch.randn(N, K, generator=g)
+        w3 = ops.split3_weight(w)
+        blob = ops.pack_linear_split(w3)
+        ns = (N + 191) // 192
+        assert blob.numel() == _lib.lib().grl_linear_split_blob_bytes(N, K) == ns * 6 * 2 * (K // 16) * 1024
+        img = blob.view(torch.float16).view(ns, 6, 2, K // 16, 64, 8)
+        hi, lo = w3[:, :K], w3[:, 2 * K :]
+        for (sl, wv, s, l, e) in ((0, 0, 0, 0, 0), (ns - 1, 2, K // 16 - 1, 63, 7), (0, 5, 3, 37, 2), (ns - 1, 0, 1, 31, 5)):
+            col, k = 32 * (6 * sl + wv) + (l & 31), 16 * s + 8 * (l >> 5) + e
+            want_hi = hi[col, k] if col < N else torch.tensor(0.0, dtype=torch.float16)
+            want_lo = lo[col, k] if col < N else torch.tensor(0.0, dtype=torch.float16)
+            assert img[sl, wv, 0, s, l, e] == want_hi and img[sl, wv, 1, s, l, e] == want_lo
+    assert ops.pack_linear_split(ops.split3_weight(torch.randn(64, 96, generator=g))) is None      # K = 96: not a shape the kernel takes
