@@ -14,5 +14,5 @@ for f in attention attention_rows attention_bwd mlp tail_regs qkv qkv_anchor con
     awk '/remark: Function Name:/{name=$(NF-1)} /remark: +TotalSGPRs:/{s=$(NF-1)} /remark: +VGPRs:/{v=$(NF-1)} /remark: +AGPRs:/{a=$(NF-1)}
          /remark: +ScratchSize/{sc=$(NF-1)} /remark: +Occupancy/{o=$(NF-1)} /remark: +VGPRs Spill:/{sp=$(NF-1)}
          /remark: +LDS Size/{printf "Function Name: %s\tTotalSGPRs: %s\tVGPRs: %s\tAGPRs: %s\tScratchSize [bytes/lane]: %s\tVGPRs Spill: %s\tOccupancy [waves/SIMD]: %s\n", name, s, v, a, sc, sp, o}' |
-    if [ ${f:0:6} = linear ]; then grep -E "linear_kernelILi(6|12|18)ELi(6|8|12)E"; else cat; fi
+    if [ $f = linear ] || [ $f = linear_k576 ]; then grep -E "linear_kernelILi(6|12|18)ELi(6|8|12)E"; else cat; fi
 done
