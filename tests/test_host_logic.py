@@ -455,3 +455,48 @@ def test_split_site_spec_and_linear_split_blob_layout():
             want_lo = lo[col, k] if col < N else torch.tensor(0.0, dtype=torch.float16)
             assert img[sl, wv, 0, s, l, e] == want_hi and img[sl, wv, 1, s, l, e] == want_lo
     assert ops.pack_linear_split(ops.split3_weight(torch.randn(64, 96, generator=g))) is None      # K = 96: not a shape the kernel takes
+
+
+def test_training_glue_shortcuts_equal_the_plain_torch_chains():
+    """Round-4 launch-count shortcuts of the training path, on the CPU: GRL._attn_table's single gather + scale equals
+    tables.kernel_table(16 * sigmoid(CPB-MLP)) on every entry a (query, key) pair can address (the pad entries repeat row 0 instead
+    of being zero), with the same gradient for the CPB-MLP; GRL._to_planes's single cat equals the pad + permute it replaced, with
+    the constants the attention kernel wants (k slot 31, v column d) in place."""
+    import math
+
+    import torch
+    import torch.nn.functional as F
+
+    from grl_image_restoration_amd import GRL, make_config, tables
+
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[1], num_heads_window=[3], num_heads_stripe=[3])
+    torch.manual_seed(3)
+    m = GRL(**cfg)
+    blk = m.layers[0].blocks[0]
+    for tr, win, df in ((blk.attn.window_attn.attn_transform, (32, 32), 1), (blk.attn.stripe_attn.attn_transform1, (64, 64), 2)):
+        coords = tables.coords_table(win, df, device="cpu")
+        rows = coords.shape[0]
+        got = m._attn_table(tr, win, df, torch.device("cpu"))
+        h = F.relu(F.linear(coords, tr.cpb_mlp[0].weight, tr.cpb_mlp[0].bias))
+        want = tables.kernel_table(16.0 * torch.sigmoid(F.linear(h, tr.cpb_mlp[2].weight)))
+        assert got.shape == want.shape and got.is_contiguous()
+        assert torch.allclose(got[:, :rows], want[:, :rows], rtol=2e-7, atol=0)
+        assert torch.equal(got[:, rows:], got[:, rows - 1 : rows].expand(-1, got.shape[1] - rows))      # pad = row 0 (last after the reversal)
+        gw = torch.randn(got.shape, generator=torch.Generator().manual_seed(4))
+        gw[:, rows:] = 0                                                                             # nothing reads the pad entries
+        g1 = torch.autograd.grad((got * gw).sum(), tr.cpb_mlp[2].weight, retain_graph=True)[0]
+        g2 = torch.autograd.grad((want * gw).sum(), tr.cpb_mlp[2].weight)[0]
+        assert torch.allclose(g1, g2, rtol=1e-5, atol=1e-7)
+
+    t = torch.randn(96, 3, 30, generator=torch.Generator().manual_seed(6), requires_grad=True)
+    plain = F.pad(t, (0, 2)).permute(1, 0, 2).contiguous()
+    assert torch.equal(m._to_planes(t), plain)
+    k = m._to_planes(t, 31)
+    assert torch.equal(k[..., :31], plain[..., :31]) and bool((k[..., 31] == 1).all())
+    v = m._to_planes(t, 30)
+    assert torch.equal(v[..., :30], plain[..., :30]) and bool((v[..., 30] == 1).all()) and bool((v[..., 31] == 0).all())
+    (g,) = torch.autograd.grad(k.sum(), t)
+    assert bool((g == 1).all())                                                                        # the constant block takes no gradient
+    t32 = torch.randn(64, 2, 32)
+    assert torch.equal(m._to_planes(t32, -1), t32.permute(1, 0, 2).contiguous())
+    assert math.isclose(float((m._to_planes(t, 31).sum() - plain.sum()).detach()), 96 * 3, rel_tol=1e-5)
