@@ -59,6 +59,16 @@ class FusedAdamW(torch.optim.Optimizer):
         super().load_state_dict(state_dict)
         self._tables = {}
         self._normalise_state()
+        if self._step_dev:   # capture mode: the device counters follow the loaded step counts IN PLACE (a captured graph holds their addresses)
+            for gi, group in enumerate(self.param_groups):
+                steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]}
+                if len(steps) == 1:
+                    self._step_dev[gi].fill_(steps.pop())
+
+    def state_dict(self):
+        """(In capture mode the step counts live on the device: they are read back first.)"""
+        self.sync_step_from_device()
+        return super().state_dict()
 
     def __setstate__(self, state):
         super().__setstate__(state)
@@ -78,6 +88,9 @@ class FusedAdamW(torch.optim.Optimizer):
         (incremented by a captured op; the bias corrections are computed from it on the device, in float64 like the host path,
         and handed to the kernel as GrlAdamWArgs.bias_corrections_dev) and the table of gradient pointers is copied from pinned
         host memory.  Call after at least one eager step (the moments must exist)."""
+        if self._step_dev:                       # already in capture mode (a second graph): the device counters are the truth and
+            self.sync_step_from_device()         # keep their addresses -- an earlier graph increments them too
+            return
         self._step_dev = {}
         for gi, group in enumerate(self.param_groups):
             steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]}
@@ -86,7 +99,8 @@ class FusedAdamW(torch.optim.Optimizer):
             dev = group["params"][0].device
             self._step_dev[gi] = torch.full((1,), steps.pop(), dtype=torch.int64, device=dev)
             # (allocated here: pinning host memory is not allowed while a stream is capturing)
-            self._pinned[gi] = torch.zeros(len(group["params"]), dtype=torch.int64).pin_memory()
+            host = torch.zeros(len(group["params"]), dtype=torch.int64)
+            self._pinned[gi] = host.pin_memory() if dev.type == "cuda" else host
 
     def sync_step_from_device(self):
         """After graph replays: the host-side ``state[p]['step']`` (what state_dict() saves) <- the device counters."""

@@ -500,3 +500,33 @@ def test_training_glue_shortcuts_equal_the_plain_torch_chains():
     t32 = torch.randn(64, 2, 32)
     assert torch.equal(m._to_planes(t32, -1), t32.permute(1, 0, 2).contiguous())
     assert math.isclose(float((m._to_planes(t, 31).sum() - plain.sum()).detach()), 96 * 3, rel_tol=1e-5)
+
+
+def test_fused_adamw_capture_mode_bookkeeping():
+    """FusedAdamW.enable_capture (host logic, CPU tensors: no launch): the step counts move to device counters, state_dict() and a
+    second enable_capture read them back, load_state_dict pushes loaded counts into the SAME counter tensors (a captured graph
+    holds their addresses)."""
+    import torch
+
+    from grl_image_restoration_amd import FusedAdamW
+
+    ps = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+    opt = FusedAdamW(ps, lr=1e-3)
+    with pytest.raises(RuntimeError):
+        opt.enable_capture()                                  # no eager step yet: no state
+    for p in ps:
+        opt.state[p] = dict(step=7, exp_avg=torch.zeros_like(p), exp_avg_sq=torch.zeros_like(p))
+    opt.enable_capture()
+    ctr = opt._step_dev[0]
+    assert int(ctr) == 7 and opt._pinned[0].numel() == 2
+    ctr.add_(3)                                               # three replays of a captured step
+    sd = opt.state_dict()
+    assert all(int(s["step"]) == 10 for s in sd["state"].values())
+    opt.enable_capture()                                      # a second graph shares the counters of the first
+    assert opt._step_dev[0] is ctr and int(ctr) == 10
+    keep = opt._step_dev[0]
+    for s in sd["state"].values():
+        s["step"] = 4
+    opt.load_state_dict(sd)
+    assert opt._step_dev[0] is keep and int(keep) == 4
+    assert all(opt.state[p]["step"] == 4 for p in ps)
