@@ -762,6 +762,9 @@ int launch_fast(const GrlAttnArgs& p, hipStream_t st) {
 // csrc/attention_rows.hip: hand-scheduled row-streaming kernel for the 32-aligned geometries
 bool grl_attn_rows_supported(const GrlAttnArgs& p);
 int grl_attn_rows_launch(const GrlAttnArgs& p, hipStream_t st);
+// csrc/attention_pipe.hip (round 5): the same geometries at head_dim <= 30 with the key-row loop software-pipelined inside each wave
+bool grl_attn_pipe_supported(const GrlAttnArgs& p);
+int grl_attn_pipe_launch(const GrlAttnArgs& p, hipStream_t st);
 
 extern "C" int grl_attention_rows_geometry_ok(const GrlAttnArgs* args) { return grl_attn_rows_supported(*args) ? 1 : 0; }
 
@@ -789,6 +792,9 @@ extern "C" int grl_attention_fwd(void* stream, const GrlAttnArgs* args) {
     static const int rows_off = getenv("GRL_ATTN_ROWS") ? atoi(getenv("GRL_ATTN_ROWS")) == 0 : 0;   // 0: round-2 fast kernels (A/B)
     // head_dim 32 (GRL-Small): no spare slot; the row-streaming kernel carries offset and denominator on the VALU instead
     const bool d32_ok = !split && p.head_dim == 32 && p.ones_col < 0 && p.lazy_floor != nullptr;
+    // opt-in (GRL_ATTN_PIPE=1): measured in the whole network it does not beat the row-streaming kernel yet
+    static const int pipe_on = getenv("GRL_ATTN_PIPE") ? atoi(getenv("GRL_ATTN_PIPE")) != 0 : 0;
+    if (lazy_ok && pipe_on && !rows_off && !getenv("GRL_ATTN_GENERIC") && grl_attn_pipe_supported(p)) return grl_attn_pipe_launch(p, st);
     if ((lazy_ok || d32_ok) && !rows_off && !getenv("GRL_ATTN_GENERIC") && grl_attn_rows_supported(p)) return grl_attn_rows_launch(p, st);
     if (lazy_ok && !p.q.transposed && p.ones_col >= 0 && (p.q.ww % 32) == 0 && (p.k.ww % 32) == 0 && (p.q.wh % 2) == 0 &&
         (p.k.wh % 8) == 0 && fast_lds_bytes(p, 1) <= 160 * 1024 && !getenv("GRL_ATTN_GENERIC"))
