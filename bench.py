@@ -7,25 +7,26 @@
 
 Workload (BASELINE.json configs[2], the configuration the metric is quoted on): GRL-Base x4 SR,
 released-checkpoint geometry (window 32, stripes 64x64, anchor /2), batches of 256x256 LQ tiles,
-synthetic uniform-random pixels, random-init weights.  One step = one forward of `--tiles` tiles
-per GPU with the tiles already resident in HBM.  Tiles are independent units: ranks shard them
+synthetic uniform-random pixels, random-init weights WITH CHECKPOINT-LIKE LOGIT SCALES (round 5: the released checkpoints
+sit at / around the clamp exp(ln 100), where this implementation takes its split-operand projection and the attention
+offsets move more often -- the regime a user of the reference's checkpoints sees; `--random-init-scales` times the
+constructor's scales instead).  One step = one forward of `--tiles` tiles per GPU with the tiles already resident in HBM.  Tiles are independent units: ranks shard them
 with no data-path collective (weak scaling); the only collectives are the timing barrier/max.
 
 The timed region contains no probes.  After it, separate untimed passes collect
   roofline       : the dominant kernel (cosine window / stripe attention, MFMA-bound): algorithmic FLOPs per launch /
-                   its mean launch duration from HIP events on the launching stream over K more steps of the same
-                   schedule (two tile groups on two streams -> residency under overlap) and with the overlap off
-                   (`exclusive_*`), against the 2.5 PFLOP/s fp16/bf16 dense peak
-  trained_scales : the same K steps with every logit scale at / around the clamp exp(ln 100) (what a trained
-                   checkpoint looks like): the fast attention kernels must stay selected (ratio ~ 1)
+                   its mean launch duration from HIP events on the launching stream, against the 2.5 PFLOP/s fp16/bf16 dense peak.
+                   `frac` = the kernel alone on the GPU (overlap off, `exclusive_*`); `concurrent_frac` = its residency inside the timed
+                   schedule (two tile groups on two streams share the chip); `whole_network_frac` = the step's FLOPs / time / peak
+  random_init_scales : the same K steps with the logit scales the reference constructor sets (10 for every head; the headline of
+                   rounds 1-4) -- `trained_scales` when --random-init-scales swaps the legs
   tiled          : (N > 1) strong-scaling leg: tiling.forward_tiled of a fixed 8 x N-tile list, sharded over the ranks
                    with its RCCL all-gather
   training       : BASELINE configs[4] in short: GRL-Base x4 SR training steps on 64x64 LQ patches, batch 8 per GPU, L1 loss,
                    autograd over the HIP kernels + FusedAdamW (one launch for the 1390 tensors); N > 1: DistributedDataParallel
                    over RCCL (bucketed gradient all-reduce overlapped with the backward pass)
-  cpu_baseline   : the CPU oracle (a torch-fp32 port of the reference forward) on this box's host cores: a
-                   128x128 LQ tile of the same network (1/4 of a bench tile), 1 warm-up + median of 2, thread
-                   count picked by a sweep on a 64x64 tile.
+  cpu_baseline   : the CPU oracle (a torch-fp32 port of the reference forward) on this box's host cores: ONE FULL tile of the
+                   workload (256x256 LQ for config 3: 60-120 s), thread count picked by a warm-up sweep on 64x64 tiles.
 --config 2 / --config 4 measure BASELINE configs[1] / configs[3] (Small denoise 128x128; Base deblur 384x384 tiles) with
 the same harness (their lines are kept under profiles/).
 """
@@ -73,22 +74,24 @@ def attention_flops_per_launch(cfg, tiles, hw):
     return tiles * (win + 2 * a2w) / 3.0  # mean over the three launches of a block
 
 
-def cpu_baseline(cfg):
-    """Reference algorithm on the host cores: oracle/grl_oracle.py (kind 'port')."""
+def cpu_baseline(cfg, side):
+    """Reference algorithm on the host cores: oracle/grl_oracle.py (kind 'port': a torch-fp32 restatement pinned against the
+    unmodified reference; the reference sources themselves do not travel to the GPU box).  One full tile of the metric's own
+    configuration (256x256 LQ for config 3): nothing is extrapolated.  Thread count from a sweep on a 64x64 tile."""
     from oracle import grl_oracle as O
 
     from grl_image_restoration_amd import GRL
 
     torch.manual_seed(0)
 
-    def make(side):
+    def make(sd_side):
         c = dict(cfg)
-        c["img_size"] = side
+        c["img_size"] = sd_side
         m = GRL(**c)
         return c, {k: v.detach().clone() for k, v in m.state_dict().items()}
 
-    def run(c, sd, side):
-        x = torch.rand(1, 3, side, side, generator=torch.Generator().manual_seed(1))
+    def run(c, sd, sd_side):
+        x = torch.rand(1, 3, sd_side, sd_side, generator=torch.Generator().manual_seed(1))
         t0 = time.time()
         with torch.no_grad():
             O.grl_forward(x, c, sd)
@@ -103,10 +106,8 @@ def cpu_baseline(cfg):
         sweep[th] = run(c64, sd, 64)
     best = min(sweep, key=sweep.get)
     torch.set_num_threads(best)
-    side = 128
-    c128, _ = make(side)
-    times = sorted(run(c128, sd, side) for _ in range(3))   # (the thread sweep above has paged everything in)
-    dt = times[1]
+    cfull, _ = make(side)
+    dt = run(cfull, sd, side)     # (the thread sweep above has paged everything in; one forward: 60 .. 120 s for a 256x256 Base tile)
     return {
         "value": round(side * side / dt / 1e6, 6),
         "unit": "LQ megapixels/s",
@@ -114,10 +115,8 @@ def cpu_baseline(cfg):
         "host_cpus": ncpu,
         "kind": "port",
         "thread_sweep_s_per_64x64_tile": {str(k): round(v, 2) for k, v in sweep.items()},
-        "sample": f"one 128x128 LQ tile (1/4 of the pixels of a bench tile, same network / window / stripe geometry), fp32 torch CPU, "
-                  f"median of 3: {dt:.1f} s per forward on {best} threads.  `value` is that tile's own pixels per second; "
-                  f"a 256x256 tile costs 4x the pixel-wise work at the same per-pixel attention cost (window 32, stripe 64x64 "
-                  f"divide both sizes), i.e. ~{4 * dt:.0f} s per bench tile at the same rate (SURVEY 8(d) measured 99 s on 8 threads)",
+        "sample": f"one full {side}x{side} LQ tile of the benchmark configuration (same network / window / stripe geometry, fp32 torch CPU, "
+                  f"{best} threads after a warm-up + thread sweep on 64x64 tiles): {dt:.1f} s per forward; nothing extrapolated",
     }
 
 
@@ -247,12 +246,24 @@ def run(args, rank, world, local_rank):
     x = torch.rand(args.tiles, 3, side, side, generator=g).to(dev)
     scale = cfg["upscale"]
 
+    # The timed leg runs on CHECKPOINT-LIKE logit scales (round 5): every released checkpoint of the reference has its
+    # logit scales at / around the clamp exp(min(., ln 100)) (efficient.py:39), where the q / k / anchor projection runs on split operands
+    # and the lazy softmax offsets of the attention kernel move more often.  Same seeded draw as the *_hiscale parity fixtures.  The
+    # random-init scales (10 for every head) are the secondary leg `random_init_scales`.
+    scale_params = [(n, p_) for n, p_ in model.named_parameters() if n.endswith("logit_scale")]
+    init_scales = [p_.detach().clone() for _, p_ in scale_params]
+    trained_regime = not args.random_init_scales
+    if trained_regime:
+        gs = torch.Generator().manual_seed(7)
+        with torch.no_grad():
+            for _, p_ in scale_params:
+                p_.copy_((math.log(100.0) + 0.3 * torch.randn(p_.shape, generator=gs)).to(dev))
     with torch.no_grad():
         for _ in range(args.warmup):
             y = model(x)
     dt, y = timed_steps(model, x, args.steps, world)
     assert torch.isfinite(y).all()
-    precision_mode = model.precision   # (of the timed leg: `auto` is resolved per weight set, the trained-scale leg may differ)
+    precision_mode = model.precision   # (of the timed leg: `auto` is resolved per weight set, the other leg may differ)
 
     # ---- untimed passes (rank 0 measures; every rank runs the same launches so that the barriers match) ----
     groups = model.stream_groups(args.tiles)   # tile groups advancing on separate HIP streams (one launch = one group)
@@ -277,20 +288,25 @@ def run(args, rank, world, local_rank):
                         "exclusive_achieved": round(fl1 / (ms1 * 1e-3) / 1e12, 2),
                         "exclusive_frac": round(fl1 / (ms1 * 1e-3) / 1e12 / PEAK_F16_TFLOPS, 4)}
 
-    # trained-scale leg: logit scales around the clamp (same seeded draw as the *_hiscale parity fixtures)
-    trained = None
-    if not args.no_trained_scales:
-        gs = torch.Generator().manual_seed(7)
+    # the other logit-scale regime, same K steps
+    other = None
+    if not args.no_other_scales:
         with torch.no_grad():
-            for n, p_ in model.named_parameters():
-                if n.endswith("logit_scale"):
+            if trained_regime:
+                for (_, p_), v in zip(scale_params, init_scales):
+                    p_.copy_(v)
+            else:
+                gs = torch.Generator().manual_seed(7)
+                for _, p_ in scale_params:
                     p_.copy_((math.log(100.0) + 0.3 * torch.randn(p_.shape, generator=gs)).to(dev))
             for _ in range(max(1, args.warmup)):
                 yt = model(x)
         dt_t, yt = timed_steps(model, x, args.steps, world)
         assert torch.isfinite(yt).all()
-        trained = {"ms_per_step": round(dt_t / args.steps * 1e3, 3), "ratio_to_random_init": round(dt_t / dt, 4), "precision_mode": model.precision,
-                   "logit_scales": "exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at the clamp"}
+        other = {"ms_per_step": round(dt_t / args.steps * 1e3, 3), "value": round(world * args.tiles * side * side * args.steps / dt_t / 1e6, 4),
+                 "unit": "LQ megapixels/s", "ratio_to_timed_leg": round(dt_t / dt, 4), "precision_mode": model.precision,
+                 "logit_scales": "as initialised by the reference constructor (10 for every head)" if trained_regime else
+                                 "exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at the clamp"}
 
     # strong-scaling leg: one fixed tile list sharded over the ranks, stitched through the RCCL all-gather
     tiled = None
@@ -324,7 +340,9 @@ def run(args, rank, world, local_rank):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_tile")  # PMC pass (profiles/), per tile
             traffic = traffic * (args.tiles // groups) if traffic else None
         conf = {
-            "workload": label + ", random-init weights",
+            "workload": label + (", random-init weights with checkpoint-like logit scales exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at "
+                                 "the clamp, the regime of every released checkpoint" if trained_regime else ", random-init weights and logit scales (10)"),
+            "logit_scale_regime": "checkpoint-like" if trained_regime else "random-init",
             "tiles_per_gpu_per_step": args.tiles,
             "hr_megapixels_per_s": round(mp * scale * scale, 2),
             "parallelism": f"tile-sharded x{world}, no data-path collective",
@@ -332,6 +350,39 @@ def run(args, rank, world, local_rank):
         }
         if gflop_tile:
             conf.update(gflop_per_tile=gflop_tile, model_tflops=round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12, 2))
+        # Roofline of the dominant kernel.  `frac` is the kernel alone on the GPU (the `exclusive` pass: overlap off, one launch per
+        # attention call over all tiles) -- what the kernel is capable of; `concurrent_frac` is its per-launch residency inside the timed
+        # schedule, where a launch shares the GPU with the other tile group's kernels and therefore understates it; `whole_network_frac`
+        # prices the whole step's algorithmic FLOPs (5468.5 GFLOP per tile) against the same peak.
+        roofline = {
+            # the row-streaming kernel serves the 32-aligned geometry of config 3; the window-12 / -16 geometries of configs 2 and 4
+            # run the generic kernel (grl_attention_fwd's dispatch, csrc/attention.hip)
+            "kernel": "attn_rows_kernel (cosine window / anchored-stripe attention, csrc/attention_rows.hip)" if args.config == 3 else
+                      "attn_kernel (generic cosine window / anchored-stripe attention, csrc/attention.hip)",
+            "bound": "mfma",
+            "achieved": excl.get("exclusive_achieved", round(ach, 2)),
+            "peak": PEAK_F16_TFLOPS,
+            "unit": "TFLOP/s",
+            "frac": excl.get("exclusive_frac", round(ach / PEAK_F16_TFLOPS, 4)),
+            "frac_is": "exclusive (kernel alone on the GPU)" if excl else "concurrent (no exclusive pass: one stream group)",
+            "concurrent_achieved": round(ach, 2),
+            "concurrent_frac": round(ach / PEAK_F16_TFLOPS, 4),
+            "whole_network_frac": round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4) if gflop_tile else None,
+            "logit_scale_regime": "checkpoint-like" if trained_regime else "random-init",
+            "traffic": traffic,
+            "traffic_source": "profiles/attention_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the round, "
+                              "not measured in this run)" if traffic else None,
+            "launches_timed": len(att),
+            "mean_launch_ms": round(att_ms, 4),
+            "flops_per_launch": fl,
+            "probe_pass_ms_per_step": round(dt_probe / args.steps * 1e3, 3),
+            "time_share_of_step": round(sum(att) / (dt_probe * 1e3), 3) if att else None,
+            "time_share_note": "sum of the launches' own durations / step time; the tile groups run on concurrent streams, so launches overlap "
+                               "and the shares of all kernels add up to more than 1" if groups > 1 else None,
+            "concurrent_streams": groups,
+            "tiles_per_launch": args.tiles // groups,
+            **excl,
+        }
         line = {
             "metric": "LQ megapixels/s, " + label.split(":")[1].split(",")[0].strip() + f", {side}x{side} LQ tiles",
             "value": round(mp, 4),
@@ -346,39 +397,16 @@ def run(args, rank, world, local_rank):
             "dtype": "f16 MFMA operands (attention, linear, conv), f32 accumulate + residual stream",
             "data": "synthetic",
             "config": conf,
-            "roofline": {
-                # the row-streaming kernel serves the 32-aligned geometry of config 3; the window-12 / -16 geometries of configs 2 and 4
-                # run the generic kernel (grl_attention_fwd's dispatch, csrc/attention.hip)
-                "kernel": "attn_rows_kernel (cosine window / anchored-stripe attention, csrc/attention_rows.hip)" if args.config == 3 else
-                          "attn_kernel (generic cosine window / anchored-stripe attention, csrc/attention.hip)",
-                "bound": "mfma",
-                "achieved": round(ach, 2),
-                "peak": PEAK_F16_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(ach / PEAK_F16_TFLOPS, 4),
-                "traffic": traffic,
-                "traffic_source": "profiles/attention_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the round, "
-                                  "not measured in this run)" if traffic else None,
-                "launches_timed": len(att),
-                "mean_launch_ms": round(att_ms, 4),
-                "flops_per_launch": fl,
-                "probe_pass_ms_per_step": round(dt_probe / args.steps * 1e3, 3),
-                "time_share_of_step": round(sum(att) / (dt_probe * 1e3), 3) if att else None,
-                "time_share_note": "sum of the launches' own durations / step time; the tile groups run on concurrent streams, so launches overlap "
-                                   "and the shares of all kernels add up to more than 1" if groups > 1 else None,
-                "concurrent_streams": groups,
-                "tiles_per_launch": args.tiles // groups,
-                **excl,
-            },
+            "roofline": roofline,
         }
-        if trained:
-            line["trained_scales"] = trained
+        if other:
+            line["random_init_scales" if trained_regime else "trained_scales"] = other
         if tiled:
             line["tiled"] = tiled
         if training:
             line["training"] = training
         if not args.no_cpu_baseline and world == 1:      # rank 0 at N = 1 only: the other ranks would sit in the barrier
-            line["cpu_baseline"] = cpu_baseline(cfg)
+            line["cpu_baseline"] = cpu_baseline(cfg, side if not args.cpu_baseline_side else args.cpu_baseline_side)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
@@ -400,7 +428,9 @@ def main():
     ap.add_argument("--tiles", type=int, default=8, help="LQ tiles per GPU per step")
     ap.add_argument("--config", type=int, default=3, choices=sorted(WORKLOADS), help="BASELINE config (3 = the metric's)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-trained-scales", action="store_true")
+    ap.add_argument("--cpu-baseline-side", type=int, default=0, help="tile side of the CPU baseline leg (default: the workload's own tile)")
+    ap.add_argument("--random-init-scales", action="store_true", help="time the random-init logit scales (the pre-round-5 headline) instead of checkpoint-like ones")
+    ap.add_argument("--no-other-scales", "--no-trained-scales", dest="no_other_scales", action="store_true", help="skip the leg on the other logit-scale regime")
     ap.add_argument("--no-train-graph", action="store_true", help="training leg: eager steps instead of the captured HIP graph")
     ap.add_argument("--no-tiled", action="store_true")
     ap.add_argument("--no-train", action="store_true")

@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 19
+ABI_VERSION = 20
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -355,6 +355,7 @@ class GrlAdamWArgs(_Strict):
         ("bias_correction2_sqrt", C.c_float),
         ("grad_scale", C.c_float),
         ("bias_corrections_dev", C.c_void_p),
+        ("hyper_dev", C.c_void_p),
     ]
 
 

@@ -71,6 +71,14 @@ def grad_scale(device=None) -> float:
     return _State.scales.get(_scale_key(device), 1.0)
 
 
+def last_grad_scale(device=None) -> float:
+    """The power-of-two gradient operand scale of the most recent (non-frozen) backward pass on ``device``: what a captured step
+    froze, and what GraphedTrainStep compares against when it re-calibrates."""
+    if device is None and _State.scales:
+        return next(reversed(_State.scales.values()))
+    return _State.scales.get(_scale_key(device), 1.0)
+
+
 class GradScaleTop(torch.autograd.Function):
     """Identity on the network output; in backward it fixes the gradient scale of the pass from max|dL/dy|."""
 

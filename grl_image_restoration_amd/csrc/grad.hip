@@ -126,7 +126,10 @@ __global__ __launch_bounds__(256) void adamw_kernel(GrlAdamWArgs p) {
     const float* g = (const float*)p.grads[t];
     float* m = (float*)p.exp_avg[t];
     float* v = (float*)p.exp_avg_sq[t];
-    const float wd = p.weight_decay_flags != nullptr && p.weight_decay_flags[t] == 0 ? 0.f : p.weight_decay;
+    // (captured launches: learning rate and weight decay come from device memory, refreshed by the host before each replay)
+    const float lr = p.hyper_dev != nullptr ? p.hyper_dev[0] : p.lr;
+    const float wd_all = p.hyper_dev != nullptr ? p.hyper_dev[1] : p.weight_decay;
+    const float wd = p.weight_decay_flags != nullptr && p.weight_decay_flags[t] == 0 ? 0.f : wd_all;
     float bc1 = p.bias_correction1, bc2s = p.bias_correction2_sqrt;
     if (p.bias_corrections_dev != nullptr) {   // graph replay: the step count, and what depends on it, live on the device
         bc1 = p.bias_corrections_dev[0];
@@ -136,13 +139,13 @@ __global__ __launch_bounds__(256) void adamw_kernel(GrlAdamWArgs p) {
     for (int64_t i = off + threadIdx.x; i < min(n, off + 4096); i += 256) {
         const float gi = g[i] * p.grad_scale;
         float wi = w[i];
-        wi *= 1.0f - p.lr * wd;                               // decoupled weight decay (torch.optim.AdamW)
+        wi *= 1.0f - lr * wd;                               // decoupled weight decay (torch.optim.AdamW)
         const float mi = p.beta1 * m[i] + (1.0f - p.beta1) * gi;
         const float vi = p.beta2 * v[i] + (1.0f - p.beta2) * gi * gi;
         m[i] = mi;
         v[i] = vi;
         const float denom = sqrtf(vi) / bc2s + p.eps;
-        w[i] = wi - (p.lr / bc1) * (mi / denom);
+        w[i] = wi - (lr / bc1) * (mi / denom);
     }
 }
 

@@ -43,7 +43,7 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
     // a_split == 3: virtual K = [hi | lo | hi] over a source of KS3 k-steps (KSTEPS = 3 * KS3)
     const bool split = p.a_split == 3;
     const float asc = p.a_scale != 0.0f ? p.a_scale : 1.0f;   // backward pass: gradients pre-scaled into fp16 range
-    constexpr int KS3 = KSTEPS / 3;
+    constexpr int KS3 = KSTEPS >= 3 ? KSTEPS / 3 : 1;   // (never used as a divisor of 0: instantiations with KSTEPS < 3 are never run with a_split == 3)
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
         int m = row0 + 16 * mt + r;

@@ -23,7 +23,10 @@ class FusedAdamW(torch.optim.Optimizer):
         super().__init__(params, dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
         self._tables = {}
         self._step_dev = None     # capture mode (enable_capture): per group, the step count as a device tensor
-        self._pinned = {}         # per group: pinned host table of gradient pointers, read by the captured copy on every replay
+        self._hyper_dev = {}      # capture mode: per group, {lr, weight_decay} as a device tensor the captured launch reads
+        self._frozen = {}         # capture mode: per group, the hyper-parameters a captured launch holds BY VALUE (betas, eps)
+        self._pinned = {}         # per group: pinned host table of gradient pointers of the NEXT capture (one table per capture:
+        self._pinned_all = []     # a replay copies from the table of its own graph; all of them are kept alive here)
 
     def _group_tables(self, gi, plist):
         """Device pointer / size tables of a parameter group (rebuilt when the set of tensors or their storage changes)."""
@@ -56,14 +59,31 @@ class FusedAdamW(torch.optim.Optimizer):
     def load_state_dict(self, state_dict):
         """Accepts this class's own state and the one of ``torch.optim.AdamW`` (what the reference's Lightning checkpoints hold
         under ``optimizer_states``: ``step`` as a 0-dim tensor per parameter)."""
+        # capture mode: a captured launch holds the ADDRESSES of the moment buffers, of the pointer tables and of the step counters.
+        # The loaded values therefore go INTO the existing buffers (torch's load_state_dict would replace the tensors: a replay
+        # would keep updating the old moments and ignore the loaded ones -- ADVICE r4), and the tables stay.
+        keep = {}
+        if self._step_dev:
+            keep = {p: (s["exp_avg"], s["exp_avg_sq"]) for p, s in self.state.items() if "exp_avg" in s}
         super().load_state_dict(state_dict)
-        self._tables = {}
         self._normalise_state()
-        if self._step_dev:   # capture mode: the device counters follow the loaded step counts IN PLACE (a captured graph holds their addresses)
+        if keep:
+            with torch.no_grad():
+                for p, (m_old, v_old) in keep.items():
+                    s = self.state.get(p)
+                    if s is None or "exp_avg" not in s:
+                        continue
+                    if s["exp_avg"] is not m_old:
+                        m_old.copy_(s["exp_avg"]); s["exp_avg"] = m_old
+                    if s["exp_avg_sq"] is not v_old:
+                        v_old.copy_(s["exp_avg_sq"]); s["exp_avg_sq"] = v_old
             for gi, group in enumerate(self.param_groups):
                 steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]}
                 if len(steps) == 1:
                     self._step_dev[gi].fill_(steps.pop())
+            self.refresh_capture_hyper()
+        else:
+            self._tables = {}
 
     def state_dict(self):
         """(In capture mode the step counts live on the device: they are read back first.)"""
@@ -72,7 +92,8 @@ class FusedAdamW(torch.optim.Optimizer):
 
     def __setstate__(self, state):
         super().__setstate__(state)
-        self._tables = {}
+        if not getattr(self, "_step_dev", None):   # (capture mode: load_state_dict keeps buffers and tables, see there)
+            self._tables = {}
         self._normalise_state()
 
     def _normalise_state(self):
@@ -88,19 +109,42 @@ class FusedAdamW(torch.optim.Optimizer):
         (incremented by a captured op; the bias corrections are computed from it on the device, in float64 like the host path,
         and handed to the kernel as GrlAdamWArgs.bias_corrections_dev) and the table of gradient pointers is copied from pinned
         host memory.  Call after at least one eager step (the moments must exist)."""
-        if self._step_dev:                       # already in capture mode (a second graph): the device counters are the truth and
+        first = not self._step_dev
+        if not first:                            # already in capture mode (a second graph): the device counters are the truth and
             self.sync_step_from_device()         # keep their addresses -- an earlier graph increments them too
-            return
-        self._step_dev = {}
+        else:
+            self._step_dev = {}
         for gi, group in enumerate(self.param_groups):
-            steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]}
-            if len(steps) != 1:
-                raise RuntimeError("FusedAdamW.enable_capture: run an eager step first (every parameter of a group needs the same step count)")
             dev = group["params"][0].device
-            self._step_dev[gi] = torch.full((1,), steps.pop(), dtype=torch.int64, device=dev)
-            # (allocated here: pinning host memory is not allowed while a stream is capturing)
+            if first:
+                steps = {int(self.state[p]["step"]) for p in group["params"] if p in self.state and "step" in self.state[p]}
+                if len(steps) != 1:
+                    raise RuntimeError("FusedAdamW.enable_capture: run an eager step first (every parameter of a group needs the same step count)")
+                self._step_dev[gi] = torch.full((1,), steps.pop(), dtype=torch.int64, device=dev)
+                self._hyper_dev[gi] = torch.tensor([group["lr"], group["weight_decay"]], dtype=torch.float32, device=dev)
+                self._frozen[gi] = (tuple(group["betas"]), group["eps"])
+            # ONE pinned table of gradient pointers PER CAPTURE (allocated here: pinning host memory is not allowed while a stream is
+            # capturing).  A shared table would be overwritten by the next capture, and a replay of the earlier graph would then
+            # update from another graph's gradient buffers (ADVICE r4).
             host = torch.zeros(len(group["params"]), dtype=torch.int64)
-            self._pinned[gi] = host.pin_memory() if dev.type == "cuda" else host
+            host = host.pin_memory() if dev.type == "cuda" else host
+            self._pinned[gi] = host
+            self._pinned_all.append(host)
+
+    def refresh_capture_hyper(self):
+        """Capture mode: brings the device copy of {lr, weight_decay} up to date with ``param_groups`` -- call before every replay
+        of a captured step (GraphedTrainStep does), so that LR schedulers act on replays.  betas / eps are held by value in a
+        captured launch: changing them after a capture raises here instead of being silently ignored."""
+        if not self._step_dev:
+            return
+        for gi, group in enumerate(self.param_groups):
+            if self._frozen.get(gi) != (tuple(group["betas"]), group["eps"]):
+                raise RuntimeError("FusedAdamW: betas / eps changed after a step was captured; they are frozen in the graph -- re-capture")
+            hd = self._hyper_dev[gi]
+            want = (float(group["lr"]), float(group["weight_decay"]))
+            if getattr(hd, "_host_copy", None) != want:
+                hd.copy_(torch.tensor(want, dtype=torch.float32))
+                hd._host_copy = want
 
     def sync_step_from_device(self):
         """After graph replays: the host-side ``state[p]['step']`` (what state_dict() saves) <- the device counters."""
@@ -143,6 +187,8 @@ class FusedAdamW(torch.optim.Optimizer):
                     self.state[p]["step"] = step
             b1, b2 = group["betas"]
             bc_dev = None
+            if self._step_dev is not None and not capturing:
+                self.refresh_capture_hyper()      # (eager steps between replays read the same device copy)
             if self._step_dev is not None:
                 sd = self._step_dev[gi]
                 sd.add_(1)
@@ -162,6 +208,7 @@ class FusedAdamW(torch.optim.Optimizer):
                 lr=group["lr"], beta1=b1, beta2=b2, eps=group["eps"], weight_decay=group["weight_decay"],
                 bias_correction1=1.0 - b1 ** step, bias_correction2_sqrt=(1.0 - b2 ** step) ** 0.5, grad_scale=grad_scale,
                 bias_corrections_dev=bc_dev.data_ptr() if bc_dev is not None else None,
+                hyper_dev=self._hyper_dev[gi].data_ptr() if (self._step_dev is not None and gi in self._hyper_dev) else None,
             )
             L.check(lib.grl_adamw_step(L.stream_ptr(), C.byref(args)), "grl_adamw_step")
             # the kernel wrote through raw pointers: tell autograd (and GRL's plan version stamp) that the tensors changed in place

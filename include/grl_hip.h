@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 19
+#define GRL_ABI_VERSION 20
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -485,6 +485,10 @@ typedef struct GrlAdamWArgs {
     const float* bias_corrections_dev;   /* optional: {bias_correction1, bias_correction2_sqrt} in DEVICE memory, computed on the */
                                          /* device from a device-side step count; the two host fields above are then ignored --   */
                                          /* a launch captured in a HIP graph stays correct when it is replayed                    */
+    const float* hyper_dev;              /* optional (ABI 20): {lr, weight_decay} in DEVICE memory; the host fields `lr` and           */
+                                         /* `weight_decay` are then ignored -- an LR scheduler (the reference trains with MultiStepLR / */
+                                         /* cosine / warm-up schedules, config/lr_scheduler) keeps working across replays of a captured  */
+                                         /* launch: the caller refreshes the two floats before each replay                              */
 } GrlAdamWArgs;
 
 int grl_adamw_step(void* stream, const GrlAdamWArgs* args);

@@ -480,3 +480,51 @@ def test_graphed_train_step_matches_eager_steps():
         fresh.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in fresh.state_dict().items()}, 0), strict=True)
         y_init = fresh.cuda().eval()(lq)
     assert float((y2 - y_init).abs().max()) > 3 * float((y0 - y2).abs().max())
+
+
+@pytest.mark.gpu
+def test_graphed_train_step_follows_lr_schedule_and_resume():
+    """a captured optimizer launch reads lr / weight decay from device memory that GraphedTrainStep refreshes from
+    param_groups before every replay (lr 0 -> the replay moves nothing; lr back -> it moves again), an eval forward between replays
+    sees the replayed update without finish(), and load_state_dict in capture mode lands in the buffers the graph points at."""
+    import copy
+
+    from grl_image_restoration_amd import GRL, FusedAdamW, GraphedTrainStep, make_config
+
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[1], num_heads_window=[3], num_heads_stripe=[3], drop_path_rate=0.0)
+    torch.manual_seed(0)
+    m = GRL(**cfg).cuda().train()
+    opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=0.0)
+    lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=2, seed=12)
+    lq, gt = lq.cuda(), gt.cuda()
+    step = GraphedTrainStep(m, opt, lambda y, t: (y - t).abs().mean(), lq, gt, warmup=1)
+    snap = lambda: torch.cat([p.detach().flatten() for p in m.parameters()]).clone()
+    step(lq, gt)
+    w0 = snap()
+    with torch.no_grad():
+        y_a = m.eval()(lq).clone()
+    m.train()
+    opt.param_groups[0]["lr"] = 0.0                       # what an LR scheduler does between steps
+    step(lq, gt)
+    torch.cuda.synchronize()
+    assert torch.equal(snap(), w0), "a replay at lr = 0 must not move the weights"
+    opt.param_groups[0]["lr"] = 2e-4
+    step(lq, gt)
+    w2 = snap()
+    assert float((w2 - w0).abs().max()) > 1e-5
+    with torch.no_grad():
+        y_b = m.eval()(lq)                                # no finish() in between: the plan must have been rebuilt from the new weights
+    m.train()
+    assert float((y_b - y_a).abs().max()) > 0
+    # resume in capture mode: loaded moments land in the buffers the captured launch updates
+    sd = copy.deepcopy(opt.state_dict())
+    p0 = next(iter(m.parameters()))
+    ptr = opt.state[p0]["exp_avg"].data_ptr()
+    for s in sd["state"].values():
+        s["exp_avg"].zero_(); s["exp_avg_sq"].zero_()
+    opt.load_state_dict(sd)
+    assert opt.state[p0]["exp_avg"].data_ptr() == ptr and float(opt.state[p0]["exp_avg"].abs().max()) == 0.0
+    step(lq, gt)
+    torch.cuda.synchronize()
+    assert float(opt.state[p0]["exp_avg"].abs().max()) > 0.0   # the replay wrote the (re-started) moments, not stale buffers
+    step.finish()

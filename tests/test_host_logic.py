@@ -530,3 +530,44 @@ def test_fused_adamw_capture_mode_bookkeeping():
     opt.load_state_dict(sd)
     assert opt._step_dev[0] is keep and int(keep) == 4
     assert all(opt.state[p]["step"] == 4 for p in ps)
+
+
+def test_fused_adamw_capture_mode_keeps_addresses_and_follows_schedulers():
+    """ADVICE r4 (all three mediums), host logic on CPU tensors: in capture mode (a) load_state_dict copies the loaded moments INTO the
+    buffers a captured launch points at and keeps the pointer tables, (b) every capture gets its own pinned gradient-pointer table,
+    (c) lr / weight decay live in a device tensor that refresh_capture_hyper() keeps equal to param_groups, and betas / eps -- held by
+    value in a captured launch -- refuse to change silently."""
+    import torch
+
+    from grl_image_restoration_amd import FusedAdamW
+
+    ps = [torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(3, 2))]
+    opt = FusedAdamW(ps, lr=1e-3, weight_decay=1e-2)
+    for p in ps:
+        opt.state[p] = dict(step=2, exp_avg=torch.full_like(p, 0.5), exp_avg_sq=torch.full_like(p, 0.25))
+    opt.enable_capture()
+    first_table = opt._pinned[0]
+    m_ptr = [opt.state[p]["exp_avg"].data_ptr() for p in ps]
+    v_ptr = [opt.state[p]["exp_avg_sq"].data_ptr() for p in ps]
+    opt._tables[0] = dict(key="sentinel")                     # stands for the device pointer tables of a captured launch
+    import copy
+    sd = copy.deepcopy(opt.state_dict())                      # (a checkpoint read back from disk: state_dict() itself aliases the live state)
+    for s in sd["state"].values():
+        s["exp_avg"] = s["exp_avg"] * 0 + 3.0
+        s["exp_avg_sq"] = s["exp_avg_sq"] * 0 + 9.0
+        s["step"] = 11
+    opt.load_state_dict(sd)
+    assert [opt.state[p]["exp_avg"].data_ptr() for p in ps] == m_ptr and [opt.state[p]["exp_avg_sq"].data_ptr() for p in ps] == v_ptr
+    assert all(float(opt.state[p]["exp_avg"].mean()) == 3.0 and float(opt.state[p]["exp_avg_sq"].mean()) == 9.0 for p in ps)
+    assert opt._tables[0]["key"] == "sentinel" and int(opt._step_dev[0]) == 11
+    opt.enable_capture()                                      # a second capture: its own pinned table, the first one stays alive
+    assert opt._pinned[0] is not first_table and any(t is first_table for t in opt._pinned_all)
+    # schedulers: lr / weight decay follow param_groups through the device copy
+    assert torch.allclose(opt._hyper_dev[0], torch.tensor([1e-3, 1e-2]))
+    opt.param_groups[0]["lr"] = 5e-4
+    opt.param_groups[0]["weight_decay"] = 0.0
+    opt.refresh_capture_hyper()
+    assert torch.allclose(opt._hyper_dev[0], torch.tensor([5e-4, 0.0]))
+    opt.param_groups[0]["betas"] = (0.8, 0.999)
+    with pytest.raises(RuntimeError):
+        opt.refresh_capture_hyper()
