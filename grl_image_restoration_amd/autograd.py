@@ -27,7 +27,7 @@ import torch
 import torch.nn.functional as F
 
 from . import _lib as L
-from . import ops
+from . import composite, ops
 
 _SIZES = (64, 96, 128, 192, 256, 384, 576, 768, 1152)   # widths both as N (n-tile chunks of 4/6/8) and as K (k-steps) of grl_linear_fwd
 
@@ -349,13 +349,19 @@ class AttentionFn:
 
     @staticmethod
     def apply(q, k, v, table, geo):
+        if not q.is_cuda:
+            return composite.attention(q, k, v, table, list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]))
         return attention_op(q, k, v, table, geo["floor"], list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]),
                             bool(geo.get("prepared", False)))[0]
 
 
 def linear(x, w, b=None):
+    if not x.is_cuda:                      # CPU tensors: the composite torch path (composite.py; never a CUDA tensor)
+        return composite.linear(x, w, b)
     return linear_op(x, w, b)
 
 
 def conv3x3(x, w, b, B, H, W):
+    if not x.is_cuda:
+        return composite.conv3x3(x, w, b, B, H, W)
     return conv3x3_op(x, w, b, B, H, W)

@@ -980,7 +980,7 @@ class GRL(nn.Module):
         """GRL.forward (grl.py:506-551) as a differentiable graph over the HIP kernels (autograd.py)."""
         H0, W0 = x.shape[2:]
         first = self.conv_first.weight
-        if getattr(self, "_ag_registered", None) != (first.data_ptr(), first.device):   # (re)register after .to() / load
+        if x.is_cuda and getattr(self, "_ag_registered", None) != (first.data_ptr(), first.device):   # (re)register after .to() / load
             AG.register_parameters(self)
             self._ag_registered = (first.data_ptr(), first.device)
         x = self.check_image_size(x.float())
@@ -1037,7 +1037,8 @@ class GRL(nn.Module):
             if self.in_channels == self.out_channels:
                 y = x + y
         y = y / self.img_range + mean
-        return AG.GradScaleTop.apply(y[:, :, : H0 * s, : W0 * s].contiguous())
+        y = y[:, :, : H0 * s, : W0 * s].contiguous()
+        return AG.GradScaleTop.apply(y) if y.is_cuda else y      # (the gradient operand scale belongs to the fp16 HIP contractions)
 
     @staticmethod
     def _tokens(x, cpad):
@@ -1091,10 +1092,16 @@ class GRL(nn.Module):
 
     def _forward_eager(self, x):
         if not x.is_cuda:
-            raise RuntimeError(
-                "grl_image_restoration_amd.GRL runs only on an AMD GPU (MI355X/gfx950): got a CPU tensor and "
-                "there is deliberately no CPU fallback"
-            )
+            # CPU tensor: the composite torch path (composite.py; SURVEY 8(b) "errors", BASELINE configs[0]).  Not a fallback of the
+            # GPU path -- a CUDA tensor never gets here and still fails loudly below when the HIP library is missing.
+            if os.environ.get("GRL_NO_CPU_COMPOSITE", "0") == "1":
+                raise RuntimeError("grl_image_restoration_amd.GRL: got a CPU tensor and GRL_NO_CPU_COMPOSITE=1 forbids the composite torch path "
+                                   "(no CPU fallback)")
+            if any(p.is_cuda for p in self.parameters()):
+                raise RuntimeError("grl_image_restoration_amd.GRL: CPU input but the parameters live on the GPU")
+            from . import composite
+            composite.announce()
+            return self._forward_train(x)
         L.lib()  # fail loudly if the extension is missing
         if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
             return self._forward_train(x)      # autograd path: every contraction, forward and backward, in libgrl_hip.so

@@ -28,10 +28,23 @@ def tile_list(h: int, w: int, tile: int, overlap: int) -> Tuple[int, List[Tuple[
 
 
 def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int, int]:
-    """Contiguous chunk [lo, hi) of n tiles for ``rank`` and the padded per-rank count."""
-    per = (n + world - 1) // world
-    lo = min(rank * per, n)
-    return lo, min(lo + per, n), per
+    """Contiguous chunk [lo, hi) of n tiles for ``rank`` and the padded per-rank count of the all-gather.  Balanced: the first
+    n % world ranks take one tile more than the others, so no rank idles while another holds two tiles more than it needs to
+    (the reference's default GoPro split, 6 tiles of 480, on 4 ranks: 2 2 1 1, not 2 2 2 0; 8 tiles of 384 on 8 ranks: one each).
+    Whole tiles are the unit -- the tile list is the reference's and so is the result -- so with fewer tiles than ranks
+    (6 tiles on 8 GPUs) the last ranks only take part in the collective."""
+    q, r = divmod(n, world)
+    lo = rank * q + min(rank, r)
+    return lo, lo + q + (1 if rank < r else 0), q + (1 if r else 0)
+
+
+def shard_of_tile(t: int, n: int, world: int) -> Tuple[int, int]:
+    """(rank, index inside the rank's chunk) of tile t under shard_bounds."""
+    q, r = divmod(n, world)
+    if t < r * (q + 1):
+        return divmod(t, q + 1)
+    k, i = divmod(t - r * (q + 1), max(q, 1))
+    return r + k, i
 
 
 def stitch(outs: Sequence[torch.Tensor], origins: Sequence[Tuple[int, int]], shape, tile: int, scale: int) -> torch.Tensor:
@@ -79,6 +92,6 @@ def forward_tiled(model: Callable[[torch.Tensor], torch.Tensor], x: torch.Tensor
     dist.all_gather_into_tensor(recv, send, group=group)
     outs = []
     for t in range(n):
-        r, i = divmod(t, per)
+        r, i = shard_of_tile(t, n, world)
         outs.append(recv[r * per + i])
     return stitch(outs, origins, (b, oc, h, w), tile, scale)

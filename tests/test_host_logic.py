@@ -86,8 +86,12 @@ def test_boundary_contract_on_cpu():
     ck = {"model." + k: v for k, v in m.state_dict().items()}
     ck["model.table_w"] = torch.zeros(1)
     assert "model.table_w" not in m.convert_checkpoint(ck)
-    with pytest.raises(RuntimeError, match="no CPU fallback"):
-        m.eval()(torch.zeros(1, 3, 64, 64))
+    os.environ["GRL_NO_CPU_COMPOSITE"] = "1"
+    try:
+        with pytest.raises(RuntimeError, match="no CPU fallback"):
+            m.eval()(torch.zeros(1, 3, 64, 64))
+    finally:
+        del os.environ["GRL_NO_CPU_COMPOSITE"]
     with pytest.raises(NotImplementedError):
         GRL(**{**cfg, "qkv_proj_type": "separable_conv"})
     base = GRL(**make_config("base", "sr_ckpt_df2", upscale=4))
