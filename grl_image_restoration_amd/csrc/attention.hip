@@ -49,8 +49,8 @@ constexpr unsigned short F16_INF = 0x7C00;
 // ------------------------------------------------------------------------------------------------
 // Generic kernel: any window shape (12x12 windows, 8-anchor stripes, ragged key counts, head_dim 32), online softmax.
 // ------------------------------------------------------------------------------------------------
-// SPLIT: split-precision operands (precision "high"): S = q_hi k_hi + q_lo k_hi + q_hi k_lo, O = P v_hi + P v_lo with the fp16
-// residual planes q_lo / k_lo / v_lo (3 + 2 MFMA terms instead of 1 + 1: ~22-bit operands; P stays fp16).
+// SPLIT: split-precision operands (precision "high"): S = q_hi k_hi + q_lo k_hi + q_hi k_lo, O = P_hi v_hi + P_lo v_hi + P_hi v_lo with the fp16
+// residual planes q_lo / k_lo / v_lo and the rounding residual of the weights (3 + 3 MFMA terms instead of 1 + 1: ~22-bit operands).
 typedef uint32_t u32x4v __attribute__((ext_vector_type(4)));
 typedef __fp16 tr_h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
 
@@ -249,6 +249,7 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
             }
             // online softmax; numerators packed straight into the PV B-operand order
             f16x8 pb[QT][2];
+            f16x8 pl[SPLIT ? QT : 1][2];   // SPLIT: rounding residual of the weights, p - fp16(p) (round 5: the third PV term)
 #pragma unroll
             for (int t = 0; t < QT; ++t) {
                 float mx = S[t][0];
@@ -270,16 +271,21 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                 float ps = 0.f;
                 const float nsub = P_TOP - mnew;   // weights <= 2^14: 28 binades of fp16 normals below the row maximum
                 const f32x2v ns2 = {nsub, nsub};
-                uint32_t pw[8];
+                uint32_t pw[8], pwl[SPLIT ? 8 : 1];
 #pragma unroll
                 for (int r = 0; r < 16; r += 2) {
                     const f32x2v e2 = f32x2v{S[t][r], S[t][r + 1]} + ns2;
                     const float p0 = __builtin_amdgcn_exp2f(e2[0]), p1 = __builtin_amdgcn_exp2f(e2[1]);
                     if constexpr (!ONES) ps += p0 + p1;
                     pw[r >> 1] = pack_f16_raw(p0, p1);
+                    if constexpr (SPLIT) pwl[r >> 1] = pack_f16_raw(p0 - (float)(f16)p0, p1 - (float)(f16)p1);
                 }
                 pb[t][0] = __builtin_bit_cast(f16x8, u32x4v{pw[0], pw[1], pw[2], pw[3]});
                 pb[t][1] = __builtin_bit_cast(f16x8, u32x4v{pw[4], pw[5], pw[6], pw[7]});
+                if constexpr (SPLIT) {
+                    pl[t][0] = __builtin_bit_cast(f16x8, u32x4v{pwl[0], pwl[1], pwl[2], pwl[3]});
+                    pl[t][1] = __builtin_bit_cast(f16x8, u32x4v{pwl[4], pwl[5], pwl[6], pwl[7]});
+                }
                 if constexpr (!ONES) lrun[t] += ps;
             }
             // V^T fragments: rows = head dim l31; k-slot e <-> key kb + 16*s + 8*(e>>2) + 4*half + (e&3)
@@ -291,6 +297,14 @@ __global__ __launch_bounds__(256) void attn_kernel(GrlAttnArgs p) {
                 O[t] = mfma32_f16(vf[1], pb[t][1], O[t]);
             }
             if constexpr (SPLIT) {
+                // O = P_hi v_hi + P_lo v_hi + P_hi v_lo.  The P_lo term is new in round 5: with the weights rounded to fp16 the
+                // everything-split path left 5.8e-3 on the ill-conditioned clamp-scale fixture of GRL-Small (CPU emulation of that
+                // one rounding alone: 6.4e-3; the reference's own fp32 arithmetic is 2.4e-4 from its float64 run there), with it 4.6e-4
+#pragma unroll
+                for (int t = 0; t < QT; ++t) {
+                    O[t] = mfma32_f16(vf[0], pl[t][0], O[t]);
+                    O[t] = mfma32_f16(vf[1], pl[t][1], O[t]);
+                }
                 f16x8 v2[2];
                 vt_frags(Vs2 + kb * 64, lane, v2);
 #pragma unroll

@@ -293,7 +293,7 @@ typedef struct GrlAttnArgs {
     int64_t lse_stride;      /* logits per query token row (what the backward kernel re-normalises with) */
     const void* q_lo;        /* optional split-precision operands (precision "high"): fp16 residuals q - fp16(q), ... on   */
     const void* k_lo;        /* the grids of q, k, v (same ld / hstride / col0).  With any of them the generic kernel forms */
-    const void* v_lo;        /* S = q_hi k_hi + q_lo k_hi + q_hi k_lo and O = P v_hi + P v_lo (~22-bit operands)            */
+    const void* v_lo;        /* S = q_hi k_hi + q_lo k_hi + q_hi k_lo and O = P_hi v_hi + P_lo v_hi + P_hi v_lo (~22-bit operands; P_lo = p - fp16(p))            */
     void* o_lo;              /* optional, GRL_DT_F16 output: residual o - fp16(o) on o's grid (the next attention's v_lo)    */
     const float* lazy_ceil;  /* optional [nh]: upper bound of every logit of the head (log2 domain: ceil(scale*log2e) + max of its   */
                              /* table).  Once the running offsets of a wave's queries are within 13.5 of it no weight can reach     */

@@ -144,7 +144,8 @@ def bias_table(p: Dict[str, Tensor], prefix: str, table: Tensor) -> Tensor:
     Linear(512,heads,no bias) (mixed_attn_block.py:24-31).  The reference applies the sigmoid
     after the gather; gather and elementwise sigmoid commute.
     """
-    h = F.relu(F.linear(table.reshape(-1, 2), p[prefix + "cpb_mlp.0.weight"], p[prefix + "cpb_mlp.0.bias"]))
+    w0 = p[prefix + "cpb_mlp.0.weight"]
+    h = F.relu(F.linear(table.reshape(-1, 2).to(w0.dtype), w0, p[prefix + "cpb_mlp.0.bias"]))   # (the oracle also runs in float64: tests' "truth")
     return 16.0 * torch.sigmoid(F.linear(h, p[prefix + "cpb_mlp.2.weight"]))
 
 

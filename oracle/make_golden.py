@@ -124,5 +124,41 @@ def main(only=None):
         print(f"{name}: in {tuple(lq.shape)} out {tuple(y.shape)} oracle-vs-reference max|d| = {err:.3e}", flush=True)
 
 
+def main_fp64(only=None):
+    """Adjudication of the checkpoint-like fixtures (VERDICT r4 #4a): the unmodified reference in FLOAT64 on the same inputs and
+    weights.  tests/golden/fp64/<name>.npz stores ref_fp32 - ref_fp64 (float32, on a strided lattice for the large outputs) and its
+    maximum: the GPU test then knows how far the reference's own fp32 arithmetic is from the exact network, and asserts
+    |hip - fp64| <= max(1e-3, 2 x |ref_fp32 - fp64|)."""
+    GRL = refshim.import_reference_grl()
+    out_dir = os.path.join(ROOT, "tests", "golden", "fp64")
+    os.makedirs(out_dir, exist_ok=True)
+    for name, model, geom, up, size, hw, task, ex in FIXTURES:
+        if "scale" not in name or (only and name not in only):
+            continue
+        z = np.load(os.path.join(ROOT, "tests", "golden", name + ".npz"), allow_pickle=False)
+        cfg = make_config(model, geom, upscale=up, img_size=size)
+        torch.manual_seed(0)
+        ref = GRL(**cfg).eval()
+        shapes = {k: tuple(v.shape) for k, v in ref.state_dict().items()}
+        sd = O.seeded_state_dict(shapes, seed=0, **ex.get("sd", {}))
+        full = ref.state_dict()
+        full.update(sd)
+        ref.load_state_dict(full, strict=True)
+        lq = torch.from_numpy(z["input"])
+        with torch.no_grad():
+            y32 = ref(lq)
+            y64 = ref.double()(lq.double())
+        d = (y32.double() - y64)
+        s_ = 4 if d.numel() > 600_000 else 1
+        meta = dict(name=name, stride=s_, max_abs_ref32_minus_fp64=float(d.abs().max()), rms=float(d.pow(2).mean().sqrt()),
+                    out_shape=list(d.shape))
+        np.savez_compressed(os.path.join(out_dir, name + ".npz"), meta=json.dumps(meta),
+                            ref32_sub=y32[..., ::s_, ::s_].contiguous().numpy(), ref32_minus_fp64_sub=d[..., ::s_, ::s_].float().contiguous().numpy())
+        print(f"{name}: max|ref_fp32 - ref_fp64| = {meta['max_abs_ref32_minus_fp64']:.3e} (rms {meta['rms']:.3e}), lattice stride {s_}", flush=True)
+
+
 if __name__ == "__main__":
-    main(set(sys.argv[1:]) or None)
+    if len(sys.argv) > 1 and sys.argv[1] == "--fp64":
+        main_fp64(set(sys.argv[2:]) or None)
+    else:
+        main(set(sys.argv[1:]) or None)

@@ -26,6 +26,17 @@ def load_golden(name):
     return meta, out
 
 
+def load_fp64(name):
+    """(meta, tensors) of the float64 adjudication of a fixture (oracle/make_golden.py --fp64: the unmodified reference run in
+    double precision on the fixture's input): ``ref32_sub`` and ``ref32_minus_fp64_sub`` on a lattice of ``meta['stride']``;
+    None when the fixture has none."""
+    path = os.path.join(GOLDEN_DIR, "fp64", name + ".npz")
+    if not os.path.isfile(path):
+        return None
+    z = np.load(path, allow_pickle=False)
+    return json.loads(str(z["meta"])), {k: torch.from_numpy(z[k]) for k in z.files if k != "meta"}
+
+
 def golden_state_dict(meta):
     """The seeded weights a fixture was generated with (reproducible anywhere: grl_oracle.seeded_state_dict)."""
     return O.seeded_state_dict(product_shapes(meta["cfg"]), meta["weight_seed"], **meta.get("sd_kwargs", {}))
