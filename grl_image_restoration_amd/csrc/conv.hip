@@ -372,6 +372,10 @@ __global__ __launch_bounds__(1024) void se_kernel(const float* __restrict__ part
 
 }  // namespace
 
+// csrc/conv192.hip (round 5): the 192 -> 192 fp32 stage / after-body convolution on 32x32x16 MFMAs, one barrier per 16-channel chunk
+bool grl_conv192_supported(const GrlConvArgs& p);
+int grl_conv192_launch(const GrlConvArgs& p, hipStream_t st);
+
 extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     const GrlConvArgs& p = *args;
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return GRL_ERR_BAD_ARG;
@@ -381,6 +385,8 @@ extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;
     if (p.shuffle_r > 1 && (p.shuffle_cg <= 0 || (p.shuffle_cg % 4) || (p.CoutP % p.shuffle_cg))) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
+    static const int c192_off = getenv("GRL_CONV192") ? atoi(getenv("GRL_CONV192")) == 0 : 0;   // 0: generic kernel (A/B)
+    if (!c192_off && grl_conv192_supported(p)) return grl_conv192_launch(p, st);
     static const int kc_env = getenv("GRL_CONV_KC") ? atoi(getenv("GRL_CONV_KC")) : 0;   // tuning knob: 32 forces the 32-channel chunks
     if (p.CinP % 64 == 0 && kc_env != 32) return launch_conv_nt<64>(p, st);
     return launch_conv_nt<32>(p, st);

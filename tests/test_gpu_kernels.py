@@ -630,6 +630,35 @@ def test_conv3x3(B, H, W, Cin, Cout, act, src_bf16):
     assert (sums - pooled).abs().max().item() < 2e-3 * max(1.0, pooled.abs().max().item())
 
 
+@pytest.mark.parametrize("B,H,W,with_resid", [(2, 20, 45, True), (1, 64, 64, False), (3, 8, 32, True), (1, 17, 70, True)])
+def test_conv3x3_stage_shape_192(B, H, W, with_resid):
+    """The stage / after-body convolution of GRL-Base (180 -> 180 channels = 192 padded, fp32 in and out, + residual; grl.py:164-170,516)
+    takes csrc/conv192.hip since round 5 (32x32x16 MFMAs, weights of a 16-channel chunk by LDS-DMA, one barrier per chunk): ragged
+    tile edges in both directions, with and without residual, pad channels stay what the residual holds, against the fp64 convolution
+    of the fp16-rounded operands."""
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(17)
+    C, CP = 180, 192
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, C, 3, 3, generator=g) / math.sqrt(9 * C)
+    b = 0.1 * torch.randn(C, generator=g)
+    xt = torch.zeros(B * H * W, CP)
+    xt[:, :C] = x.permute(0, 2, 3, 1).reshape(-1, C)
+    ref = F.conv2d(x.to(torch.float16).double(), w.to(torch.float16).double(), b.double(), padding=1).permute(0, 2, 3, 1)
+    resid = torch.randn(B * H * W, CP, generator=g) if with_resid else None
+    d = _dev()
+    wp, bp = ops.pack_conv_weight(w.to(d), CP, CP), ops.pack_conv_bias(b.to(d), CP)
+    out = ops.conv3x3(xt.to(d), wp, bp, B, H, W, resid=resid.to(d) if with_resid else None)
+    got = out.cpu().double().view(B, H, W, CP)
+    want = ref + (resid.double().view(B, H, W, CP)[..., :C] if with_resid else 0.0)
+    err = (got[..., :C] - want).abs().max().item()
+    print(f"conv 192->192 {B}x{H}x{W} resid={with_resid}: max|err| = {err:.3e}")
+    assert err < 2e-3
+    pad_want = resid.double().view(B, H, W, CP)[..., C:] if with_resid else torch.zeros(B, H, W, CP - C, dtype=torch.float64)
+    assert (got[..., C:] - pad_want).abs().max().item() == 0
+
+
 @pytest.mark.parametrize("r,c,Cin", [(2, 64, 64), (3, 64, 64), (2, 3, 64), (4, 3, 96)])
 def test_conv3x3_pixel_shuffle(r, c, Cin):
     from grl_image_restoration_amd import ops

@@ -12,9 +12,9 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-trained-scales > $OUT/prof_bench_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-other-scales > $OUT/prof_bench_stdout.txt 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
-echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-trained-scales" > $OUT/kernel_stats.txt
+echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-other-scales" > $OUT/kernel_stats.txt
 tail -1 $OUT/prof_bench_stdout.txt >> $OUT/kernel_stats.txt
 python $ROOT/tools/rocprof_summary.py "$DB" 30 >> $OUT/kernel_stats.txt 2>&1
 KERN=attn_window,attn_a2w,attn_w2a,qkv_anchor,block_tail_regs,cab_conv1,cab_conv2_regs,se,stage_conv
