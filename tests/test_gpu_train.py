@@ -460,7 +460,9 @@ def test_graphed_train_step_matches_eager_steps():
     l_eg = max(abs(a - b) for a, b in zip(la, lg))
     print(f"losses eager {la} | eager {lb} | graph {lg}")
     print(f"mean |dp| eager-eager {d_ee:.3e}, eager-graph {d_eg:.3e}; max |dloss| {l_ee:.3e} / {l_eg:.3e}")
-    assert lg[-1] < lg[0] and all(abs(a - b) <= 2e-4 * abs(a) for a, b in zip(la, lg))
+    # (round 5: this line used a fixed 2e-4 relative bound on the losses and failed when two EAGER runs differed by 2.9e-4 in the third
+    # loss -- the atomics of the weight-gradient GEMMs; the bound now scales with the eager-eager yardstick like the ones below)
+    assert lg[-1] < lg[0] and all(abs(a - b) <= max(2e-4 * abs(a), 4 * l_ee + 5e-5) for a, b in zip(la, lg))
     assert d_eg <= 4 * d_ee + 1e-6 and l_eg <= 4 * l_ee + 5e-5      # (absolute floors: two eager runs can also happen to agree)
     p2 = next(iter(models[2].parameters()))
     assert opts[2].state[p2]["step"] == 1 + n_replays and opts[0].state[next(iter(models[0].parameters()))]["step"] == 1 + n_replays
