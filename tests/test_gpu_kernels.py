@@ -1020,3 +1020,22 @@ def test_cab_conv2_register_resident_filters(shape):
         mean = ref_s.to(dev).float() / (H * W)
         gref = torch.sigmoid(torch.relu(mean @ w1.t() + b1) @ w2.t() + b2)
         assert (gate[:, :Cout] - gref).abs().max().item() < 1e-4 and (gate[:, Cout:] == 0).all()
+
+
+def test_attention_pipelined_kernel_opt_in():
+    """csrc/attention_pipe.hip (round 5, opt-in: GRL_ATTN_PIPE=1 -- read once per process, hence the subprocess): the software-pipelined
+    kernel serves the 32-aligned head_dim <= 30 geometries; the same reference comparisons as the default kernel, at random-init and
+    at clamp scales (where its first pass runs over all keys), fp16 / fp32 output and the log-sum-exp side output."""
+    import os
+    import subprocess
+    import sys
+
+    env = dict(os.environ, GRL_ATTN_PIPE="1")
+    sel = "(test_attention_vs_oracle_indexing or test_attention_logit_scale_at_clamp or test_attention_fp32_output_and_lse or test_attention_transposed_view) " \
+          "and (win32_shift or a2w_64_df2 or w2a_64_df2 or w2a_64x128_df2 or w2a_tall_d30) and not online and not d32"
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.abspath(__file__), "-q", "-x", "-k", sel], env=env, capture_output=True, text=True,
+                         timeout=900, cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    tail = out.stdout.strip().splitlines()[-1] if out.stdout.strip() else out.stderr[-500:]
+    print(tail)
+    assert out.returncode == 0 and " passed" in tail and "failed" not in tail, out.stdout[-2000:]
+    assert int(tail.split(" passed")[0].split()[-1]) >= 18, tail
