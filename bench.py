@@ -147,42 +147,68 @@ def training_leg(args, dev, rank, world):
     from grl_image_restoration_amd import GRL, FusedAdamW, baseline_config, ddp, ops
 
     cfg = baseline_config(5)
-    torch.manual_seed(0)
-    model = GRL(**cfg).to(dev).train()
-    net = ddp.wrap(model, device=dev, bucket_mb=32) if world > 1 else model
-    opt = FusedAdamW(model.parameters(), lr=2e-4, weight_decay=1e-4)
     bsz, side, sc = args.train_batch, 64, cfg["upscale"]
     g = torch.Generator().manual_seed(100 + rank)
     lq = torch.rand(bsz, 3, side, side, generator=g).to(dev)
     gt = torch.rand(bsz, 3, side * sc, side * sc, generator=g).to(dev)
 
-    def step():
-        opt.zero_grad(set_to_none=True)
-        loss = (net(lq) - gt).abs().mean()
-        loss.backward()
-        opt.step()
-        return loss
+    def fresh():
+        torch.manual_seed(0)
+        m = GRL(**cfg).to(dev).train()
+        return m, FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
 
-    for _ in range(2):
-        step()
-    torch.cuda.synchronize()
-    # single GPU: the whole step (forward, L1, backward, FusedAdamW) replayed as one captured HIP graph -- eager, the ~19 k launches
-    # of a step are host-bound (train_graph.py); the eager time of the same step is reported next to it.  DDP steps stay eager.
-    graphed, eager_ms = None, None
-    if world == 1 and not args.no_train_graph:
+    def eager_stepper(net, opt):
+        def step():
+            opt.zero_grad(set_to_none=True)
+            loss = (net(lq) - gt).abs().mean()
+            loss.backward()
+            opt.step()
+            return loss
+        return step
+
+    # The whole step replayed from captured HIP graphs -- eager, the ~19 k launches of a step are host-bound (train_graph.py).  One
+    # GPU: ONE graph (forward, L1, backward, FusedAdamW), the eager time of the same step reported next to it.  Replicas: graph A
+    # (forward .. flat gradient buffer), one RCCL all-reduce, graph B (FusedAdamW); if that path fails on this node the leg falls
+    # back to the eager DistributedDataParallel step and says so.
+    graphed, eager_ms, graph_error = None, None, None
+    model, opt = fresh()
+    if not args.no_train_graph:
         from grl_image_restoration_amd import GraphedTrainStep
 
-        t0 = time.perf_counter()
+        try:
+            if world == 1:
+                step = eager_stepper(model, opt)
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    step()
+                torch.cuda.synchronize()
+                eager_ms = (time.perf_counter() - t0) / 2 * 1e3
+            graphed = GraphedTrainStep(model, opt, lambda y, t: (y - t).abs().mean(), lq, gt, warmup=1 if world == 1 else 3)
+            for _ in range(2):
+                graphed(lq, gt)
+            run = lambda: graphed(lq, gt)
+        except Exception as e:          # noqa: BLE001 -- (only the multi-GPU path is allowed to fall back: it has never met N > 1 ranks)
+            if world == 1:
+                raise
+            graphed, graph_error = None, f"{type(e).__name__}: {e}"[:300]
+            torch.cuda.synchronize()
+            model, opt = fresh()
+    if world > 1 and not args.no_train_graph:      # the ranks fall back together or not at all
+        bad = torch.tensor([0.0 if graphed is not None else 1.0], device=dev)
+        dist.all_reduce(bad, op=dist.ReduceOp.MAX)
+        if bad.item() > 0 and graphed is not None:
+            graphed, graph_error = None, "another rank could not capture the step"
+            model, opt = fresh()
+    if graphed is None:
+        net = ddp.wrap(model, device=dev, bucket_mb=32) if world > 1 else model
+        step = run = eager_stepper(net, opt)
         for _ in range(2):
             step()
-        torch.cuda.synchronize()
-        eager_ms = (time.perf_counter() - t0) / 2 * 1e3
-        graphed = GraphedTrainStep(net, opt, lambda y, t: (y - t).abs().mean(), lq, gt, warmup=1)
-        for _ in range(2):
-            graphed(lq, gt)
-        run = lambda: graphed(lq, gt)
     else:
-        run = step
+        step = eager_stepper(model, opt) if world == 1 else None
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -203,7 +229,10 @@ def training_leg(args, dev, rank, world):
     if graphed is not None:
         graphed.finish()
     ops.profile_begin()
-    step()
+    if step is not None:
+        step()
+    else:                       # replicas on the graphed path: the per-kernel probe step is an eager one of the same class
+        graphed._eager_step()
     prof = ops.profile_end()
     kern = {k: round(sum(v), 3) for k, v in sorted(prof.items(), key=lambda kv: -sum(kv[1]))}
     # dominant kernel pair of the step: attention backward (attn_dq_kernel + attn_dkv_kernel, one "attention_bwd" probe each).
@@ -219,11 +248,15 @@ def training_leg(args, dev, rank, world):
     return {
         "workload": "BASELINE configs[4]: GRL-Base x4 SR training, 64x64 LQ synthetic pairs, L1 loss, FusedAdamW(lr 2e-4, wd 1e-4)",
         "batch_per_gpu": bsz, "steps": args.train_steps, "ms_per_step": round(dt / args.train_steps * 1e3, 2),
-        "step_mode": "one captured HIP graph per step (forward + L1 + backward + FusedAdamW), replayed" if graphed is not None else "eager",
+        "step_mode": ("eager" if graphed is None else "one captured HIP graph per step (forward + L1 + backward + FusedAdamW), replayed"
+                      if world == 1 else "two captured HIP graphs per step (forward + L1 + backward + flat gradients | FusedAdamW) around "
+                      "one RCCL all-reduce of the flat fp32 gradient buffer"),
+        "graph_fallback": graph_error,
         "eager_ms_per_step": round(eager_ms, 2) if eager_ms is not None else None,
         "samples_per_s": round(world * bsz * args.train_steps / dt, 2),
         "value": round(world * bsz * side * side * args.train_steps / dt / 1e6, 4), "unit": "LQ megapixels/s (training)",
-        "parallelism": f"DDP x{world} over RCCL, 32 MB gradient buckets" if world > 1 else "single GPU",
+        "parallelism": ("single GPU" if world == 1 else f"data-parallel replicas x{world}, one flat gradient all-reduce per step over RCCL"
+                        if graphed is not None else f"DDP x{world} over RCCL, 32 MB gradient buckets"),
         "hip_kernel_ms_per_step": kern, "roofline": roof, "final_loss": round(float(loss.detach()), 5),
     }
 

@@ -8,7 +8,19 @@ step costs what its kernels cost.  What capture needs from the rest of the packa
   * an optimizer launch that stays correct on replay: the step count lives on the device (FusedAdamW.enable_capture,
     GrlAdamWArgs.bias_corrections_dev);
   * static input buffers: the caller's batches are copied into them before each replay.
-Single process / single GPU (a DDP step with its bucketed RCCL all-reduces is left eager).
+
+Data-parallel replicas (the reference's real training configuration: DistributedDataParallel over 8 GPUs, tools/trainer.py:135-142)
+keep the graph: the step is captured as TWO graphs with the gradient all-reduce between them --
+    graph A: zero_grad, forward, loss, backward, all 1390 gradients gathered into ONE flat fp32 buffer (77 MB for GRL-Base);
+    eager:   one all-reduce of that buffer over the process group (RCCL over xGMI: a single large collective is what the
+             per-link-bound ring wants; optionally bf16 on the wire, ``wire_bf16=True``: half the bytes);
+    graph B: FusedAdamW reading the averaged gradients straight from the flat buffer (``p.grad`` are views of it; the 1 / world
+             factor rides in the kernel's grad_scale).
+The collective is NOT captured: the step does not depend on the communication library's graph support, and the same code runs
+over gloo (tests: two replicas on one GPU).  There is no overlap of the all-reduce with the backward pass -- 2 x 77 MB x 7/8 over
+xGMI is 1-2 ms of a 200 ms step.  A ``DistributedDataParallel`` wrapper must NOT exist around the model (its reducer hooks would
+fire inside the capture): pass the bare module and a process group; the parameters are broadcast from the group's rank 0 first,
+as the wrapper would have done.
 
 What a captured step FREEZES, and what it does not:
   * learning rate and weight decay are NOT frozen: the launch reads them from device memory and ``__call__`` refreshes them from
@@ -23,24 +35,60 @@ What a captured step FREEZES, and what it does not:
 from typing import Callable
 
 import torch
+import torch.distributed as dist
 
 from . import autograd as AG
 
 
 class GraphedTrainStep:
     def __init__(self, model: torch.nn.Module, optimizer, loss_fn: Callable, lq: torch.Tensor, gt: torch.Tensor, warmup: int = 3,
-                 recalibrate_every: int = 0):
+                 recalibrate_every: int = 0, process_group=None, wire_bf16: bool = False):
         """``loss_fn(output, target) -> scalar``; ``lq`` / ``gt``: example batch (shapes are baked into the graph).  Runs ``warmup``
-        eager steps (they DO update the weights), then captures one step."""
+        eager steps (they DO update the weights), then captures one step.
+        ``process_group``: data-parallel replicas (module docstring).  None = the default group when torch.distributed is initialised
+        with more than one rank (a replica that silently skipped the all-reduce would diverge), False = never, or a group."""
         if not hasattr(optimizer, "enable_capture"):
             raise TypeError("GraphedTrainStep needs grl_image_restoration_amd.FusedAdamW (an optimizer whose step() can be captured)")
+        if isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            raise TypeError("GraphedTrainStep owns the gradient all-reduce: pass the bare module and process_group=..., not a "
+                            "DistributedDataParallel wrapper (its reducer hooks cannot run inside a captured step)")
         self.model, self.optimizer, self.loss_fn = model, optimizer, loss_fn
         self.lq, self.gt = lq.detach().clone(), gt.detach().clone()
         self.recalibrate_every = int(recalibrate_every)
         self._params = [p for g in optimizer.param_groups for p in g["params"]]
+        self._group, self._world, self._wire_bf16 = None, 1, bool(wire_bf16)
+        if process_group is not False and dist.is_available() and dist.is_initialized():
+            grp = dist.group.WORLD if process_group is None else process_group
+            if process_group is not None or dist.get_world_size(grp) > 1:
+                self._group, self._world = grp, dist.get_world_size(grp)
+        if self._group is not None:
+            if len(optimizer.param_groups) != 1:
+                raise ValueError("GraphedTrainStep with a process group: one parameter group (the flat gradient buffer is one launch's table)")
+            self._broadcast_replica_state()
+        self.collectives = 0        # gradient all-reduces issued so far (diagnostics / tests)
         model.train()
         self._capture(warmup)
         self.steps = 0
+
+    # ------------------------------------------------------------------ data-parallel plumbing
+    def _broadcast_replica_state(self):
+        """Parameters and floating-point buffers <- the group's rank 0 (what DistributedDataParallel does when it wraps a module)."""
+        src = dist.get_global_rank(self._group, 0) if hasattr(dist, "get_global_rank") else 0
+        with torch.no_grad():
+            ts = [p for p in self.model.parameters()] + [b for b in self.model.buffers() if b.is_floating_point()]
+            for dt in {t.dtype for t in ts}:
+                same = [t for t in ts if t.dtype == dt]
+                flat = torch.cat([t.detach().reshape(-1) for t in same])
+                dist.broadcast(flat, src=src, group=self._group)
+                torch._foreach_copy_([t.detach() for t in same], [v.view_as(t) for v, t in zip(flat.split([t.numel() for t in same]), same)])
+        torch.autograd.graph.increment_version(list(self.model.parameters()))
+
+    def _all_reduce(self, flat):
+        dist.all_reduce(flat, group=self._group)        # SUM; the 1 / world factor rides in FusedAdamW's grad_scale
+        self.collectives += 1
+
+    def _flat_grad_views(self, flat):
+        return [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in self._params]), self._params)]
 
     def _capture(self, warmup):
         model, optimizer, lq = self.model, self.optimizer, self.lq
@@ -57,12 +105,27 @@ class GraphedTrainStep:
         torch.cuda.synchronize(lq.device)
         optimizer.enable_capture()
         optimizer.zero_grad(set_to_none=True)     # the gradients of the captured step come from the graph's own memory pool
-        self.graph = torch.cuda.CUDAGraph()
+        self.graph, self.graph_update = torch.cuda.CUDAGraph(), None
         with AG.frozen_grad_scale(), torch.cuda.graph(self.graph):
             optimizer.zero_grad(set_to_none=True)
             self.loss = self.loss_fn(self.model(self.lq), self.gt)
             self.loss.backward()
-            optimizer.step()
+            if self._group is None:
+                optimizer.step()
+            else:                                 # graph A ends with the gradients gathered into one flat buffer
+                self._flat = torch.cat([p.grad.reshape(-1) for p in self._params])
+                self._wire = self._flat.to(torch.bfloat16) if self._wire_bf16 else self._flat
+        if self._group is not None:
+            # graph B: the optimizer launch reads the (all-reduced) flat buffer -- p.grad become views of it, so its pointer table,
+            # and whoever looks at p.grad after a step, see the averaged gradients.  Same memory pool as graph A.
+            self._raw_grads = [p.grad for p in self._params]          # (graph A's own gradient tensors stay alive: it writes them)
+            for p, v in zip(self._params, self._flat_grad_views(self._flat)):
+                p.grad = v
+            self.graph_update = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+                if self._wire_bf16:
+                    self._flat.copy_(self._wire)
+                optimizer.step(grad_scale=1.0 / self._world)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
         self._scale_at_capture = AG.last_grad_scale() if hasattr(AG, "last_grad_scale") else None
 
@@ -70,7 +133,17 @@ class GraphedTrainStep:
         self.optimizer.zero_grad(set_to_none=True)
         loss = self.loss_fn(self.model(self.lq), self.gt)
         loss.backward()
-        self.optimizer.step()
+        if self._group is None:
+            self.optimizer.step()
+            return loss
+        flat = torch.cat([p.grad.reshape(-1) for p in self._params])
+        wire = flat.to(torch.bfloat16) if self._wire_bf16 else flat
+        self._all_reduce(wire)
+        if self._wire_bf16:
+            flat.copy_(wire)
+        for p, v in zip(self._params, self._flat_grad_views(flat)):
+            p.grad = v
+        self.optimizer.step(grad_scale=1.0 / self._world)
         return loss
 
     def __call__(self, lq: torch.Tensor, gt: torch.Tensor) -> torch.Tensor:
@@ -83,6 +156,9 @@ class GraphedTrainStep:
             self._recalibrate()
         self.optimizer.refresh_capture_hyper()          # lr / weight decay of the captured optimizer launch <- param_groups
         self.graph.replay()
+        if self.graph_update is not None:
+            self._all_reduce(self._wire)
+            self.graph_update.replay()
         self.steps += 1
         # the weights changed behind the Python-side version counters: an eval forward between replays (the inference plan and the
         # fp16 weight cache key on them) must see the update (host-only, ~0.1 ms for the 1390 tensors)
@@ -96,7 +172,12 @@ class GraphedTrainStep:
         self._eager_step()
         new = AG.last_grad_scale() if hasattr(AG, "last_grad_scale") else None
         old = self._scale_at_capture
-        if new and old and (new / old > 16.0 or old / new > 16.0):
+        again = bool(new and old and (new / old > 16.0 or old / new > 16.0))
+        if self._group is not None:                  # the replicas decide together: a re-capture runs collectives
+            flag = torch.tensor([float(again)], device=self.lq.device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self._group)
+            again = bool(flag.item() > 0)
+        if again:
             torch.cuda.synchronize(self.lq.device)
             self._capture(warmup=1)
 

@@ -67,3 +67,31 @@ def test_ddp_step_over_rccl(nccl_world1):
         losses.append(float(loss.detach()))
     assert all(l == l and abs(l) < 10 for l in losses)                                   # (stochastic depth is on: no monotonic claim)
     assert sum(int((a != b.detach()).any()) for a, b in zip(before, m.parameters())) > len(before) // 2   # the update went through
+
+
+def test_graphed_data_parallel_step_over_rccl(nccl_world1):
+    """The two-graph data-parallel training step (train_graph.py) with its all-reduce on RCCL: graph A, ncclAllReduce of the flat
+    77-MB-class gradient buffer on the process group's stream, graph B -- the stream hand-over between a replayed graph and an eager
+    collective is what a world of one can and does exercise.  (Numerics across replicas: tests/test_gpu_train.py, gloo.)"""
+    from grl_image_restoration_amd import GRL, FusedAdamW, GraphedTrainStep, make_config
+
+    cfg = make_config("tiny", "sr_ckpt_df4", upscale=2, img_size=64, drop_path_rate=0.0)
+    g = torch.Generator().manual_seed(3)
+    x, y = torch.rand(2, 3, 64, 64, generator=g).cuda(), torch.rand(2, 3, 128, 128, generator=g).cuda()
+    loss_fn = lambda o, t: (o - t).abs().mean()
+    runs = []
+    for group in (False, dist.group.WORLD):               # the one-graph step and the two-graph step from the same start
+        torch.manual_seed(0)
+        m = GRL(**cfg).cuda().train()
+        opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
+        step = GraphedTrainStep(m, opt, loss_fn, x, y, warmup=1, process_group=group)
+        losses = [float(step(x, y).detach()) for _ in range(3)]
+        step.finish()
+        runs.append((losses, step.collectives, [p.detach().clone() for p in m.parameters()]))
+    (la, ca, pa), (lb, cb, pb) = runs
+    assert ca == 0 and cb == 1 + 3
+    assert all(abs(a - b) <= 2e-3 * abs(a) + 1e-4 for a, b in zip(la, lb)), (la, lb)      # same step up to the atomics' noise
+    n = sum(p.numel() for p in pa)
+    assert sum(float((p - q).abs().sum()) for p, q in zip(pa, pb)) / n < 2e-4             # (lr 2e-4: Adam's first steps move by +-lr)
+    with pytest.raises(TypeError):
+        GraphedTrainStep(torch.nn.parallel.DistributedDataParallel(GRL(**cfg).cuda(), device_ids=[0]), opt, loss_fn, x, y)   # the wrapper is refused
