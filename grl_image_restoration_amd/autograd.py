@@ -286,46 +286,55 @@ def _conv_backward(ctx, dy):
 conv3x3_op.register_autograd(_conv_backward, setup_context=_conv_setup)
 
 
-def _attn_operands(q, k, v, d, prepared):
+def _attn_operands(q, k, v, d, prepared, have=(None, None, None)):
     """fp16 copies of the head planes for the kernels.  ``prepared``: the caller has already put the constants into the pad
-    columns (GRL._to_planes: 1.0 in k's slot 31 and in v's column d) -- otherwise two index fills per call."""
-    q16 = q.detach().to(ops.PLANE_DTYPE)
-    k16 = k.detach().to(ops.PLANE_DTYPE)
-    v16 = v.detach().to(ops.PLANE_DTYPE)
+    columns (GRL._to_planes: 1.0 in k's slot 31 and in v's column d) -- otherwise two index fills per call.  ``have``: copies the
+    caller already made (of prepared planes)."""
+    q16 = have[0] if have[0] is not None else q.detach().to(ops.PLANE_DTYPE)
+    k16 = have[1] if have[1] is not None else k.detach().to(ops.PLANE_DTYPE)
+    v16 = have[2] if have[2] is not None else v.detach().to(ops.PLANE_DTYPE)
     if not prepared:
-        if d <= 30:
+        if d <= 30 and have[1] is None:
             k16[..., 31] = 1.0          # partner of the kernel's running softmax offset (q slot 31)
-        if d < 32:
+        if d < 32 and have[2] is None:
             v16[..., d] = 1.0           # ones column: the softmax denominator falls out of the PV product
     return q16, k16, v16
 
 
 @torch.library.custom_op("grl::attention", mutates_args=())
 def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, floor: torch.Tensor, qgeo: Sequence[int],
-                 kgeo: Sequence[int], B: int, nh: int, d: int, masked: bool,
-                 prepared: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                 kgeo: Sequence[int], B: int, nh: int, d: int, masked: bool, prepared: bool = False,
+                 q16: Optional[torch.Tensor] = None, k16: Optional[torch.Tensor] = None,
+                 v16: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """softmax(q k^T + bias (+ mask)) v over every window (grl_attention_fwd); operands are fp32 head planes [nh, tokens, 32]
     (fp16 in the kernel): q = normalised * scale * log2e, k normalised, v raw; ``table`` from tables.kernel_table; ``floor`` from
     tables.lazy_floor; qgeo / kgeo = (Himg, Wimg, wh, ww, shy, shx).  Returns (fp32 planes [nh, q_tokens, 32], log2-sum-exp2,
-    and the fp16 operand planes the kernel ran on -- kept for the backward pass instead of converting them again)."""
-    q16, k16, v16 = _attn_operands(q, k, v, d, prepared)
+    and the fp16 operand planes the kernel ran on -- kept for the backward pass instead of converting them again).
+    ``q16`` / ``k16`` / ``v16``: fp16 copies of (prepared) q / k / v the caller already has -- GRL._block_train converts the planes of
+    a whole block in one launch instead of three per attention call; the matching outputs are empty then (an op's outputs must not
+    alias its inputs) and the backward takes the operands from the inputs."""
+    have = (q16, k16, v16)
+    q16, k16, v16 = _attn_operands(q, k, v, d, prepared, have)
     o = torch.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
     lse = torch.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
     TG = ops.TokenGrid
     ops.attention(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), B=B, nh=nh, table=table.detach().contiguous(),
                   masked=masked, ones_col=d if d < 32 else -1, head_dim=d, k_one31=d <= 30, lazy_floor=floor if d <= 30 else None, lse=lse)
-    return o, lse, q16, k16, v16
+    ret = lambda h, t: t if h is None else t.new_empty(0)
+    return o, lse, ret(have[0], q16), ret(have[1], k16), ret(have[2], v16)
 
 
 @attention_op.register_fake
-def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared=False):
-    h = lambda t: t.new_empty(t.shape, dtype=ops.PLANE_DTYPE)
-    return q.new_empty(nh, q.shape[1], 32, dtype=torch.float32), q.new_empty(nh, q.shape[1], dtype=torch.float32), h(q), h(k), h(v)
+def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared=False, q16=None, k16=None, v16=None):
+    h = lambda t, g: t.new_empty(t.shape if g is None else (0,), dtype=ops.PLANE_DTYPE)
+    return (q.new_empty(nh, q.shape[1], 32, dtype=torch.float32), q.new_empty(nh, q.shape[1], dtype=torch.float32),
+            h(q, q16), h(k, k16), h(v, v16))
 
 
 def _attn_setup(ctx, inputs, output):
-    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared = inputs
+    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared, q16_in, k16_in, v16_in = inputs
     o, lse, q16, k16, v16 = output
+    q16, k16, v16 = (i if i is not None else t for i, t in zip((q16_in, k16_in, v16_in), (q16, k16, v16)))
     ctx.save_for_backward(q16, k16, v16, table, o, lse)
     ctx.geo = (tuple(qgeo), tuple(kgeo), B, nh, d, masked)
 
@@ -337,7 +346,7 @@ def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
     dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o.float().contiguous(),
                                          lse, B=B, nh=nh, table=table.detach().contiguous(), masked=masked, ones_col=d if d < 32 else -1,
                                          head_dim=d, g_scale=grad_scale(d_o.device))
-    return dq, dk, dv, dtab, None, None, None, None, None, None, None, None
+    return dq, dk, dv, dtab, None, None, None, None, None, None, None, None, None, None, None
 
 
 attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
@@ -351,8 +360,9 @@ class AttentionFn:
     def apply(q, k, v, table, geo):
         if not q.is_cuda:
             return composite.attention(q, k, v, table, list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]))
+        q16, k16, v16 = geo.get("f16", (None, None, None))
         return attention_op(q, k, v, table, geo["floor"], list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]),
-                            bool(geo.get("prepared", False)))[0]
+                            bool(geo.get("prepared", False)), q16, k16, v16)[0]
 
 
 def linear(x, w, b=None):

@@ -885,6 +885,34 @@ class GRL(nn.Module):
             cache[key] = blk
         return torch.cat([t.permute(1, 0, 2), blk], dim=2)
 
+    def _block_planes(self, x, scales, one_cols):
+        """All head planes of a block's projection in ONE chain: ``x`` [tokens, S, nh, d] (S slots: q / k / v of the window branch and of
+        the stripe branch; or the anchors, used twice) -> fp32 planes [S, nh, tokens, 32] plus their fp16 copy (the kernels' operands).
+        ``scales[j]``: None = slot j is taken as it is (values), a tensor [nh] = L2-normalise over d and multiply (q: the clamped
+        logit scale * log2e, k: ones); ``one_cols[j]``: plane column of slot j that holds 1.0 (-1: none).  The per-slot chain of
+        round 4 (normalize, scale, permute + cat, fp16 copy -- and in the backward a strided [tokens, nh, d] -> [nh] reduction per
+        logit scale) was ~35 launches forward and ~80 backward per block; here the scale rides on the per-token inverse norm
+        (a tensor 1/d the size, so its gradient is a last-dim reduction plus a small column sum): 6 + ~12 launches."""
+        T, S, nh, d = x.shape
+        dev = x.device
+        cache = self.__dict__.setdefault("_coords_cache", {})
+        key = ("planes_const", T, S, nh, d, tuple(s is None for s in scales), tuple(one_cols), str(dev))
+        const = cache.get(key)
+        if const is None:
+            blk = torch.zeros(S, nh, T, 32 - d, dtype=torch.float32, device=dev)
+            for j, c in enumerate(one_cols):
+                if c >= d:
+                    blk[j, :, :, c - d] = 1.0
+            raw = torch.tensor([s is None for s in scales], device=dev).view(1, S, 1, 1)
+            const = cache[key] = (blk, raw, torch.ones(nh, dtype=torch.float32, device=dev))
+        blk, raw, ones = const
+        sc = torch.stack([ones if s is None else s for s in scales]).view(1, S, nh, 1)
+        nrm = torch.linalg.vector_norm(x, dim=-1, keepdim=True)                      # F.normalize: v / max(|v|, 1e-12)
+        inv = torch.where(raw, ones.view(1, 1, nh, 1), sc / nrm.clamp_min(1e-12))
+        y = x * inv
+        planes = torch.cat([y.permute(1, 2, 0, 3), blk], dim=3) if d < 32 else y.permute(1, 2, 0, 3).contiguous()
+        return planes.unbind(0), planes.detach().to(ops.PLANE_DTYPE).unbind(0)
+
     def _attn_table(self, m: _Affine, win, df, dev):
         key = (tuple(win), df, str(dev))
         cache = self.__dict__.setdefault("_coords_cache", {})      # constant per geometry: a dozen tiny launches per call otherwise
@@ -919,6 +947,10 @@ class GRL(nn.Module):
         qkv = AG.linear(r, a.qkv.body.weight, a.qkv.body.bias)                                 # QKVProjection (mixed_attn_block.py:669-676)
         pooled = r.view(B, Ha, df, Wa, df, C).mean(dim=(2, 4)).reshape(B * Ha * Wa, C)          # AnchorLinear avg-pool (:727-736)
         anc = AG.linear(pooled, a.anchor.body[0].reduction.weight, a.anchor.body[0].reduction.bias).view(-1, nh_s, d_s)
+        same = (nh_w, d_w) == (nh_s, d_s) and os.environ.get("GRL_TRAIN_BATCHED_PLANES", "1") != "0"
+        if same:
+            att = self._attention_train_batched(qkv, anc, a, geo, B, H, W)
+            return self._block_train_tail(r, att, blk, B, H, W, dp)
         if (nh_w, d_w) == (nh_s, d_s):   # one view, one unbind: the backward is a single stack instead of two slice-backwards (zeros + copy) and an add
             qw, kw, vw, qs, ks, vs = qkv.view(M, 6, nh_w, d_w).unbind(1)
         else:
@@ -965,6 +997,61 @@ class GRL(nn.Module):
             att = torch.cat([ow, os_], dim=0).permute(1, 0, 2)[..., :d_w].reshape(M, C)
         else:
             att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
+        return self._block_train_tail(r, att, blk, B, H, W, dp)
+
+    def _attention_train_batched(self, qkv, anc, a, geo: BlockGeo, B, H, W):
+        """The three attention calls of a block (as in _block_train) with all head planes built by two _block_planes chains."""
+        C = self.embed_dim
+        M = B * H * W
+        nh, df = geo.nh_w, geo.df
+        d = C // 2 // nh
+        Ha, Wa = H // df, W // df
+        dev = qkv.device
+        k1, v1 = (31 if d <= 30 else -1), (d if d < 32 else -1)
+        tw, t1, t2 = a.window_attn.attn_transform, a.stripe_attn.attn_transform1, a.stripe_attn.attn_transform2
+        # the three clamped logit scales (efficient.py:39) and their lazy-offset floors in one chain each instead of three
+        scales = torch.clamp(torch.stack([tw.logit_scale.reshape(-1), t1.logit_scale.reshape(-1), t2.logit_scale.reshape(-1)]),
+                             max=math.log(1.0 / 0.01)).exp() * LOG2E
+        sw, s1, s2 = scales.unbind(0)
+        fw, f1, f2 = (-1.0 - torch.ceil(scales.detach())).unbind(0)          # tables.lazy_floor from the already scaled values
+        cache = self.__dict__.setdefault("_coords_cache", {})
+        ones = cache.get(("ones_nh", nh, str(dev)))
+        if ones is None:
+            ones = cache[("ones_nh", nh, str(dev))] = torch.ones(nh, dtype=torch.float32, device=dev)
+        # slots of the projection: q k v (window branch), q k v (stripe branch); the anchors serve as queries (scaled) and as keys
+        (qw, kw, vw, qs, ks, vs), (qw16, kw16, vw16, qs16, ks16, vs16) = self._block_planes(
+            qkv.view(M, 6, nh, d), (sw, ones, None, s2, ones, None), (-1, k1, v1, -1, k1, v1))
+        (aq, ak), (aq16, ak16) = self._block_planes(anc.view(-1, 1, nh, d).expand(-1, 2, nh, d), (s1, ones), (-1, k1))
+
+        ws, sh = geo.window, geo.window_shift
+        st, ss = geo.stripe, geo.stripe_shift_size
+        ast, ass = geo.anchor_stripe, geo.anchor_shift_size
+        g_tok_w = (H, W, ws[0], ws[1], sh, sh)
+        g_tok_s = (H, W, st[0], st[1], ss[0], ss[1])
+        g_anc = (Ha, Wa, ast[0], ast[1], ass[0], ass[1])
+        ow = AG.AttentionFn.apply(qw, kw, vw, self._attn_table(tw, geo.window, 1, dev),
+                                  dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh, d=d, masked=sh > 0, floor=fw, prepared=True,
+                                       f16=(qw16, kw16, vw16)))
+        y = AG.AttentionFn.apply(aq, ks, vs, self._attn_table(t1, geo.stripe, df, dev),
+                                 dict(q=g_anc, k=g_tok_s, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f1, prepared=True,
+                                      f16=(aq16, ks16, vs16)))
+        dmask = cache.get(("dmask", d, str(dev)))
+        if dmask is None:
+            dmask = cache[("dmask", d, str(dev))] = (torch.arange(32, device=dev) < d).float()
+        onev = cache.get(("onev", d, str(dev)))
+        if onev is None:
+            onev = cache[("onev", d, str(dev))] = (torch.arange(32, device=dev) == v1).float()
+        yv = torch.addcmul(onev, y, dmask)                              # real head dims only, and the constant 1.0 in column d again
+        os_ = AG.AttentionFn.apply(qs, ak, yv, self._attn_table(t2, geo.stripe, df, dev),
+                                   dict(q=g_tok_s, k=g_anc, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f2, prepared=True,
+                                        f16=(qs16, ak16, None)))
+        return torch.cat([ow, os_], dim=0).permute(1, 0, 2)[..., :d].reshape(M, C)
+
+    def _block_train_tail(self, r, att, blk: _Block, B, H, W, dp: float):
+        """proj + norm1 + residual, CAB, MLP + norm2 + residual of a block (efficient.py:543-556) on token matrices."""
+        C = self.embed_dim
+        M = B * H * W
+        a = blk.attn
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
         x1 = r + self.res_scale * self._drop_path(F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp, self.training)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
