@@ -913,6 +913,54 @@ class GRL(nn.Module):
         planes = torch.cat([y.permute(1, 2, 0, 3), blk], dim=3) if d < 32 else y.permute(1, 2, 0, 3).contiguous()
         return planes.unbind(0), planes.detach().to(ops.PLANE_DTYPE).unbind(0)
 
+    def _train_tables(self, sched, dev):
+        """The relative-position bias tables and clamped logit scales of EVERY block in a few batched chains (training path).
+        The tables depend on the CPB-MLP weights only, not on activations, so nothing forces them to be built block by block:
+        per geometry class (same coordinate table and head count) the 2 -> 512 -> nh MLPs of all blocks run as one broadcast
+        layer and one bmm -- per block they were 3 x (7 launches forward, ~12 backward) with a K = 2 GEMM that the BLAS library
+        takes 45-50 us for (16 ms of a 182 ms step).  Returns {(stage, block): ((table_w, table_a2w, table_w2a), scales [3, nh],
+        floors [3, nh])}; only for blocks whose two branches have the same head count (the batched plane path)."""
+        cache = self.__dict__.setdefault("_coords_cache", {})
+        groups, blocks = {}, []
+        for si, stage in enumerate(self.layers):
+            for bi, blk in enumerate(stage.blocks):
+                geo, a = sched[si][bi], blk.attn
+                if geo.nh_w != geo.nh_s:
+                    continue
+                ts = (a.window_attn.attn_transform, a.stripe_attn.attn_transform1, a.stripe_attn.attn_transform2)
+                blocks.append(((si, bi), ts))
+                for slot, (m, win, df) in enumerate(zip(ts, (geo.window, geo.stripe, geo.stripe), (1, geo.df, geo.df))):
+                    key = (tuple(win), df, tuple(m.cpb_mlp[2].weight.shape))
+                    groups.setdefault(key, []).append(((si, bi, slot), m))
+        tabs = {}
+        for (win, df, _), items in groups.items():
+            ck = (win, df, str(dev))
+            coords = cache.get(ck)
+            if coords is None:
+                coords = cache[ck] = tables.coords_table(win, df, device=dev)
+            rows = coords.shape[0]
+            idx = cache.get(("revidx", rows, str(dev)))
+            if idx is None:
+                idx = cache[("revidx", rows, str(dev))] = torch.cat([torch.arange(rows - 1, -1, -1, device=dev),
+                                                                       torch.zeros((-rows) % 4, dtype=torch.long, device=dev)])
+            W1 = torch.stack([m.cpb_mlp[0].weight for _, m in items])            # [G, 512, 2]
+            b1 = torch.stack([m.cpb_mlp[0].bias for _, m in items])              # [G, 512]
+            W2 = torch.stack([m.cpb_mlp[2].weight for _, m in items])            # [G, nh, 512]
+            # layer 1 has K = 2: two broadcast multiply-adds instead of a GEMM;  h [G, rows, 512]
+            h = F.relu(torch.addcmul(torch.addcmul(b1.unsqueeze(1), coords[:, 0].view(1, rows, 1), W1[:, :, 0].unsqueeze(1)),
+                                     coords[:, 1].view(1, rows, 1), W1[:, :, 1].unsqueeze(1)))
+            t = torch.sigmoid(torch.bmm(W2, h.transpose(1, 2))).index_select(2, idx) * (16.0 * LOG2E)   # [G, nh, rows4], see _attn_table
+            for (key, _), tt in zip(items, t.unbind(0)):
+                tabs[key] = tt
+        out = {}
+        if blocks:
+            ls = torch.stack([m.logit_scale.reshape(-1) for _, ts in blocks for m in ts]).view(len(blocks), 3, -1)
+            scales = torch.clamp(ls, max=math.log(1.0 / 0.01)).exp() * LOG2E      # efficient.py:39, exp2 domain
+            floors = -1.0 - torch.ceil(scales.detach())                           # tables.lazy_floor
+            for (key, _), sc, fl in zip(blocks, scales.unbind(0), floors.unbind(0)):
+                out[key] = (tuple(tabs[key + (slot,)] for slot in range(3)), sc, fl)
+        return out
+
     def _attn_table(self, m: _Affine, win, df, dev):
         key = (tuple(win), df, str(dev))
         cache = self.__dict__.setdefault("_coords_cache", {})      # constant per geometry: a dozen tiny launches per call otherwise
@@ -935,7 +983,7 @@ class GRL(nn.Module):
         """exp(min(logit_scale, ln 100)) * log2e per head (efficient.py:39), differentiable below the clamp."""
         return torch.clamp(m.logit_scale.reshape(-1), max=math.log(1.0 / 0.01)).exp() * LOG2E
 
-    def _block_train(self, r, blk: _Block, geo: BlockGeo, B, H, W, dp: float):
+    def _block_train(self, r, blk: _Block, geo: BlockGeo, B, H, W, dp: float, pre=None):
         """EfficientMixAttnTransformerBlock.forward (efficient.py:539-556) on the token matrix r [B*H*W, C] with autograd."""
         C = self.embed_dim
         M = B * H * W
@@ -949,7 +997,7 @@ class GRL(nn.Module):
         anc = AG.linear(pooled, a.anchor.body[0].reduction.weight, a.anchor.body[0].reduction.bias).view(-1, nh_s, d_s)
         same = (nh_w, d_w) == (nh_s, d_s) and os.environ.get("GRL_TRAIN_BATCHED_PLANES", "1") != "0"
         if same:
-            att = self._attention_train_batched(qkv, anc, a, geo, B, H, W)
+            att = self._attention_train_batched(qkv, anc, a, geo, B, H, W, pre)
             return self._block_train_tail(r, att, blk, B, H, W, dp)
         if (nh_w, d_w) == (nh_s, d_s):   # one view, one unbind: the backward is a single stack instead of two slice-backwards (zeros + copy) and an add
             qw, kw, vw, qs, ks, vs = qkv.view(M, 6, nh_w, d_w).unbind(1)
@@ -999,7 +1047,7 @@ class GRL(nn.Module):
             att = torch.cat([ow.permute(1, 0, 2)[..., :d_w].reshape(M, C // 2), os_.permute(1, 0, 2)[..., :d_s].reshape(M, C // 2)], dim=1)
         return self._block_train_tail(r, att, blk, B, H, W, dp)
 
-    def _attention_train_batched(self, qkv, anc, a, geo: BlockGeo, B, H, W):
+    def _attention_train_batched(self, qkv, anc, a, geo: BlockGeo, B, H, W, pre=None):
         """The three attention calls of a block (as in _block_train) with all head planes built by two _block_planes chains."""
         C = self.embed_dim
         M = B * H * W
@@ -1010,10 +1058,16 @@ class GRL(nn.Module):
         k1, v1 = (31 if d <= 30 else -1), (d if d < 32 else -1)
         tw, t1, t2 = a.window_attn.attn_transform, a.stripe_attn.attn_transform1, a.stripe_attn.attn_transform2
         # the three clamped logit scales (efficient.py:39) and their lazy-offset floors in one chain each instead of three
-        scales = torch.clamp(torch.stack([tw.logit_scale.reshape(-1), t1.logit_scale.reshape(-1), t2.logit_scale.reshape(-1)]),
-                             max=math.log(1.0 / 0.01)).exp() * LOG2E
+        if pre is None:
+            scales = torch.clamp(torch.stack([tw.logit_scale.reshape(-1), t1.logit_scale.reshape(-1), t2.logit_scale.reshape(-1)]),
+                                 max=math.log(1.0 / 0.01)).exp() * LOG2E
+            floors = -1.0 - torch.ceil(scales.detach())                      # tables.lazy_floor from the already scaled values
+            tabs = (self._attn_table(tw, geo.window, 1, dev), self._attn_table(t1, geo.stripe, df, dev),
+                    self._attn_table(t2, geo.stripe, df, dev))
+        else:                                                                # (built for all blocks at once: _train_tables)
+            tabs, scales, floors = pre
         sw, s1, s2 = scales.unbind(0)
-        fw, f1, f2 = (-1.0 - torch.ceil(scales.detach())).unbind(0)          # tables.lazy_floor from the already scaled values
+        fw, f1, f2 = floors.unbind(0)
         cache = self.__dict__.setdefault("_coords_cache", {})
         ones = cache.get(("ones_nh", nh, str(dev)))
         if ones is None:
@@ -1029,10 +1083,10 @@ class GRL(nn.Module):
         g_tok_w = (H, W, ws[0], ws[1], sh, sh)
         g_tok_s = (H, W, st[0], st[1], ss[0], ss[1])
         g_anc = (Ha, Wa, ast[0], ast[1], ass[0], ass[1])
-        ow = AG.AttentionFn.apply(qw, kw, vw, self._attn_table(tw, geo.window, 1, dev),
+        ow = AG.AttentionFn.apply(qw, kw, vw, tabs[0],
                                   dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh, d=d, masked=sh > 0, floor=fw, prepared=True,
                                        f16=(qw16, kw16, vw16)))
-        y = AG.AttentionFn.apply(aq, ks, vs, self._attn_table(t1, geo.stripe, df, dev),
+        y = AG.AttentionFn.apply(aq, ks, vs, tabs[1],
                                  dict(q=g_anc, k=g_tok_s, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f1, prepared=True,
                                       f16=(aq16, ks16, vs16)))
         dmask = cache.get(("dmask", d, str(dev)))
@@ -1042,7 +1096,7 @@ class GRL(nn.Module):
         if onev is None:
             onev = cache[("onev", d, str(dev))] = (torch.arange(32, device=dev) == v1).float()
         yv = torch.addcmul(onev, y, dmask)                              # real head dims only, and the constant 1.0 in column d again
-        os_ = AG.AttentionFn.apply(qs, ak, yv, self._attn_table(t2, geo.stripe, df, dev),
+        os_ = AG.AttentionFn.apply(qs, ak, yv, tabs[2],
                                    dict(q=g_tok_s, k=g_anc, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f2, prepared=True,
                                         f16=(qs16, ak16, None)))
         return torch.cat([ow, os_], dim=0).permute(1, 0, 2)[..., :d].reshape(M, C)
@@ -1090,11 +1144,12 @@ class GRL(nn.Module):
 
         f = conv(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin), self.conv_first)
         z = F.layer_norm(f, (C,), self.norm_start.weight, self.norm_start.bias, 1e-5)
+        pre = self._train_tables(sched, x.device) if os.environ.get("GRL_TRAIN_BATCHED_PLANES", "1") != "0" else {}
         j = 0
         for si, stage in enumerate(self.layers):
             r = z
             for bi, blk in enumerate(stage.blocks):
-                r = self._block_train(r, blk, sched[si][bi], B, H, W, self._dpr[j])
+                r = self._block_train(r, blk, sched[si][bi], B, H, W, self._dpr[j], pre.get((si, bi)))
                 j += 1
             z = conv(r, stage.conv) + z
         z = F.layer_norm(z, (C,), self.norm_end.weight, self.norm_end.bias, 1e-5)
