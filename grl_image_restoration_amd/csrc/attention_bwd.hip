@@ -22,6 +22,7 @@
 // dO is multiplied by g_scale on its way to fp16 (gradients of an L1 loss are ~1e-6: below the fp16 normal range); all
 // outputs are un-scaled on store.
 #include "common.h"
+#include <stdlib.h>
 #include <type_traits>
 #include "grl_hip_internal.h"
 #include "attn_common.h"
@@ -80,6 +81,13 @@ __device__ __forceinline__ void store_cols(float* base, const GrlTokenGrid& g, i
         *(float4*)(dst + 8 * q) = float4{a[4 * q + 0] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale};
 }
 
+// the same as an accumulation (split launches: several workgroups hold partial sums of one token's row; the destination was zeroed)
+__device__ __forceinline__ void add_cols(float* base, const GrlTokenGrid& g, int64_t row, int head, int half, const f32x16& a, float scale) {
+    float* dst = base + row * g.ld + g.col0 + head * g.hstride + 4 * half;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dst + 8 * (r >> 2) + (r & 3), a[r] * scale);
+}
+
 // wave_rol:1 -- lane i takes the value of lane (i + 1) mod 64
 __device__ __forceinline__ float wave_rol1(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x134, 0xf, 0xf, true));
@@ -127,7 +135,10 @@ __device__ __forceinline__ void diag_ring(const f32x16& dS, int lane, float* dta
 // GHIST: the bias-table gradient goes straight to global memory with atomics (tables whose two LDS copies would not fit:
 // 64x128 stripes with /2 anchors = 73 KB per copy); otherwise an LDS histogram flushed once per workgroup.
 template <bool GHIST>
-__global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
+// ``splits`` > 1: the key loop is cut into that many parts, one workgroup each, and dQ is accumulated with atomics into a zeroed
+// destination -- for launches with fewer workgroups than CUs (anchors -> stripe tokens at training batch sizes: 96 workgroups
+// streaming 4096 keys each).
+__global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int splits) {
     const GrlAttnArgs& p = a.fwd;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -136,6 +147,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     const int qblk = (nthreads >> 6) * (QT * 32);
     const int nqs = (Nq + qblk - 1) / qblk;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int sp = bid % splits; bid /= splits;
     const int qs = bid % nqs; bid /= nqs;
     const int head = bid % p.nh; bid /= p.nh;
     const int wx = bid % p.nwx; bid /= p.nwx;
@@ -203,7 +215,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     }
 
     const int nchunks = (Nk + KC - 1) / KC;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = sp * nchunks / splits; ch < (sp + 1) * nchunks / splits; ++ch) {
         const int k0 = ch * KC;
         const int klen = min(KC, Nk - k0);
         const int ntiles = (klen + 31) >> 5;
@@ -310,7 +322,10 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
     const float inv = 1.0f / a.g_scale;
 #pragma unroll
     for (int t = 0; t < QT; ++t)
-        if (qvalid[t]) store_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
+        if (qvalid[t]) {
+            if (splits > 1) add_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
+            else store_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
+        }
     if constexpr (!GHIST) {
         __syncthreads();
         for (int i = tid; i < p.trows; i += nthreads) {
@@ -323,7 +338,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a) {
 // ------------------------------------------------------------------------------------------------
 // dk + dv
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a) {
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int splits) {
     const GrlAttnArgs& p = a.fwd;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -332,6 +347,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a) {
     const int kblk = (nthreads >> 6) * (QT * 32);
     const int nks = (Nk + kblk - 1) / kblk;
     int bid = xcd_remap(blockIdx.x, gridDim.x);
+    const int sp = bid % splits; bid /= splits;
     const int ks = bid % nks; bid /= nks;
     const int head = bid % p.nh; bid /= p.nh;
     const int wx = bid % p.nwx; bid /= p.nwx;
@@ -383,7 +399,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a) {
     }
 
     const int nchunks = (Nq + KC - 1) / KC;
-    for (int ch = 0; ch < nchunks; ++ch) {
+    for (int ch = sp * nchunks / splits; ch < (sp + 1) * nchunks / splits; ++ch) {
         const int q0 = ch * KC;
         const int qlen = min(KC, Nq - q0);
         const int ntiles = (qlen + 31) >> 5;
@@ -507,8 +523,13 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a) {
 #pragma unroll
     for (int t = 0; t < QT; ++t)
         if (kvalid[t]) {
-            store_cols(a.d_k, p.k, krow[t], head, half, dK[t], inv);
-            store_cols(a.d_v, p.v, krow[t], head, half, dV[t], inv);
+            if (splits > 1) {
+                add_cols(a.d_k, p.k, krow[t], head, half, dK[t], inv);
+                add_cols(a.d_v, p.v, krow[t], head, half, dV[t], inv);
+            } else {
+                store_cols(a.d_k, p.k, krow[t], head, half, dK[t], inv);
+                store_cols(a.d_v, p.v, krow[t], head, half, dV[t], inv);
+            }
         }
 }
 
@@ -529,10 +550,40 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     const size_t tpad = (size_t)((p.trows + 3) & ~3) * 4;
+    // Split launches (see attn_dq_kernel): when a launch has fewer workgroups than the chip has CUs and a long streamed dimension,
+    // cut that dimension over several workgroups that accumulate with atomics.  Needs a destination this function can zero: dense
+    // head planes [nh][tokens][32] (what the training path passes).  GRL_ATTN_BWD_SPLITS=1 disables, =n forces n parts on every launch, =-n caps the automatic choice at n (timing experiments).
+    const char* fs = getenv("GRL_ATTN_BWD_SPLITS");       // (read per call: the tests switch it)
+    const int force_splits = fs ? atoi(fs) : 0;
+    auto dense = [&](const GrlTokenGrid& g) {
+        return g.ld == 32 && g.col0 == 0 && g.hstride == (int64_t)p.B * g.Himg * g.Wimg * 32;
+    };
+    auto pick_splits = [&](int64_t grid, int streamed, bool ok) {
+        const int nchunks = (streamed + KC - 1) / KC;
+        if (!ok || force_splits == 1) return 1;
+        int s = 1;
+        if (force_splits > 1) s = force_splits;
+        else {
+            // measured (GRL-Base training step, batch 8 x 64x64, same box): no split 169.1 ms, 2 parts 162.1, 4 parts 165.0, 8 parts
+            // 164.9 -- the 16 atomic adds per lane and tile cost more than the extra workgroups bring beyond two-way sharing
+            const int cap = force_splits < 0 ? -force_splits : 2;
+            while (grid * s < 256 && nchunks / (2 * s) >= 4 && 2 * s <= cap) s *= 2;      // >= 4 chunks per workgroup stay
+        }
+        return s < nchunks ? (s < 1 ? 1 : s) : (nchunks > 0 ? nchunks : 1);
+    };
+    auto zero = [&](float* ptr, const GrlTokenGrid& g) {
+        return hipMemsetAsync(ptr, 0, (size_t)p.nh * p.B * g.Himg * g.Wimg * 32 * sizeof(float), st);
+    };
     {
         const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
         const int blk = waves * QT * 32;
-        const int64_t grid = (int64_t)((Nq + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
+        int64_t grid = (int64_t)((Nq + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
+        const int splits = pick_splits(grid, Nk, dense(p.q));
+        if (splits > 1) {
+            hipError_t e = zero(a.d_q, p.q);
+            if (e != hipSuccess) return (int)e;
+            grid *= splits;
+        }
         const size_t rest = 2 * (size_t)KC * 64 + 32 * (size_t)TROW + KC * 4 + KC;
         const bool ghist = 2 * tpad + rest > 160 * 1024;
         const size_t lds = (ghist ? 1 : 2) * tpad + rest;
@@ -540,18 +591,25 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         auto kfn = ghist ? attn_dq_kernel<true> : attn_dq_kernel<false>;
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(waves * 64), lds, st, a);
+        hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(waves * 64), lds, st, a, splits);
         GRL_CHECK_LAUNCH();
     }
     {
         const int waves = min(4, (Nk + QT * 32 - 1) / (QT * 32));
         const int blk = waves * QT * 32;
-        const int64_t grid = (int64_t)((Nk + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
+        int64_t grid = (int64_t)((Nk + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
+        const int splits = pick_splits(grid, Nq, dense(p.k) && dense(p.v));
+        if (splits > 1) {
+            hipError_t e = zero(a.d_k, p.k);
+            if (e == hipSuccess) e = zero(a.d_v, p.v);
+            if (e != hipSuccess) return (int)e;
+            grid *= splits;
+        }
         const size_t lds = tpad + 2 * (size_t)KC * 64 + 2 * 32 * (size_t)TROW + KC * 4 * 3 + KC;
         if (grid > 0x7fffffff || lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
         hipError_t e = hipFuncSetAttribute((const void*)attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(attn_dkv_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a);
+        hipLaunchKernelGGL(attn_dkv_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a, splits);
         GRL_CHECK_LAUNCH();
     }
     return 0;

@@ -86,6 +86,10 @@ ATT_CASES = [
 ]
 
 
+# (cases for test_attention_backward_split_launches: streamed dimension >= 3 chunks of 128 in one or both kernels)
+ATT_SPLIT_CASES = ("win32_shift", "a2w_64_df2", "w2a_64_df2", "a2w_48x96_df4", "a2w_64x128_df2_bigtable", "win12_ragged")
+
+
 @pytest.mark.parametrize("case", ATT_CASES, ids=[c[0] for c in ATT_CASES])
 def test_attention_fn_gradients(case):
     """AttentionFn (grl_attention_fwd + grl_attention_bwd) inside the same torch glue the model uses (normalise, scale, table)
@@ -148,6 +152,16 @@ def test_attention_fn_gradients(case):
     errs = dict(dq=_rel(qd.grad, dq_r), dk=_rel(kd.grad, dk_r), dv=_rel(vd.grad, dv_r), dscale=_rel(sd.grad, dsc_r), dbias=_rel(bd.grad, dbias_r))
     print(name, {k_: f"{v_:.2e}" for k_, v_ in errs.items()})
     assert max(errs.values()) < 1e-2, errs
+
+
+@pytest.mark.parametrize("splits", ["2", "3"])
+@pytest.mark.parametrize("case", [c for c in ATT_CASES if c[0] in ATT_SPLIT_CASES], ids=[c[0] for c in ATT_CASES if c[0] in ATT_SPLIT_CASES])
+def test_attention_backward_split_launches(case, splits, monkeypatch):
+    """grl_attention_bwd cuts the streamed dimension over several workgroups (atomic accumulation into a zeroed destination) when
+    a launch has fewer workgroups than the chip has CUs -- the anchors -> stripe-token launches at training batch sizes.  Forced
+    here (GRL_ATTN_BWD_SPLITS) on geometries with at least that many 128-row chunks; the bar is the unsplit test's."""
+    monkeypatch.setenv("GRL_ATTN_BWD_SPLITS", splits)
+    test_attention_fn_gradients(case)
 
 
 def test_gemm_tn_matches_torch():
