@@ -1107,15 +1107,25 @@ class GRL(nn.Module):
         M = B * H * W
         a = blk.attn
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
-        x1 = r + self.res_scale * self._drop_path(F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp, self.training)
+        x1 = self._residual(r, F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
             c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention
             u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
             pool = u.view(B, H * W, C).mean(dim=1)
             gate = torch.sigmoid(F.linear(F.relu(F.linear(pool, se[1].weight.flatten(1), se[1].bias)), se[3].weight.flatten(1), se[3].bias))
-            x1 = x1 + (u.view(B, H * W, C) * gate.unsqueeze(1)).view(M, C)
+            x1 = torch.addcmul(x1.view(B, H * W, C), u.view(B, H * W, C), gate.unsqueeze(1)).view(M, C)      # x1 + u * gate in one launch
         m = AG.linear(F.gelu(AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        return x1 + self.res_scale * self._drop_path(F.layer_norm(m, (C,), blk.norm2.weight, blk.norm2.bias, 1e-5), H * W, dp, self.training)
+        return self._residual(x1, F.layer_norm(m, (C,), blk.norm2.weight, blk.norm2.bias, 1e-5), H * W, dp)
+
+    def _residual(self, r, t, rows_per_image: int, p: float):
+        """r + res_scale * DropPath(t) (efficient.py:543-556, timm DropPath with scale_by_keep: one Bernoulli draw per image) in ONE
+        launch: the residual scale and the keep mask ride in an addcmul / add-with-alpha instead of a multiply each."""
+        if p == 0.0 or not self.training:
+            return torch.add(r, t, alpha=self.res_scale)
+        keep = 1.0 - p
+        m = t.new_empty(t.shape[0] // rows_per_image, 1, 1).bernoulli_(keep)
+        return torch.addcmul(r.view(-1, rows_per_image, r.shape[1]), t.view(-1, rows_per_image, t.shape[1]), m,
+                             value=self.res_scale / keep).view_as(r)
 
     def _forward_train(self, x):
         """GRL.forward (grl.py:506-551) as a differentiable graph over the HIP kernels (autograd.py)."""
