@@ -81,11 +81,28 @@ __device__ __forceinline__ void store_cols(float* base, const GrlTokenGrid& g, i
         *(float4*)(dst + 8 * q) = float4{a[4 * q + 0] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale};
 }
 
-// the same as an accumulation (split launches: several workgroups hold partial sums of one token's row; the destination was zeroed)
-__device__ __forceinline__ void add_cols(float* base, const GrlTokenGrid& g, int64_t row, int head, int half, const f32x16& a, float scale) {
-    float* dst = base + row * g.ld + g.col0 + head * g.hstride + 4 * half;
+// Accumulation instead of a store (split launches: several workgroups hold partial sums of one token's row; the destination was
+// zeroed) through a wave-private LDS tile, so that one atomic instruction covers two 128-byte rows instead of 64 different cache lines
+// (with lane = token, rows 128 bytes apart, splitting the 384-workgroup launches in two cost +30 ms per training step).  ``off``: element offset of this lane's token row in the destination, -1 = no such token; ``w``: XWAVE bytes of LDS.
+constexpr int XROW = 36;                               // floats per staged row: 16-byte aligned, rows 4 banks apart
+constexpr int XWAVE = 32 * XROW * 4 + 32 * 8;          // tile + row offsets
+__device__ __forceinline__ void add_cols_lds(float* base, int64_t off, int lane, const f32x16& a, float scale, char* w) {
+    const int half = lane >> 5, l31 = lane & 31;
+    float* tile = (float*)w;
+    int64_t* rows = (int64_t*)(w + 32 * XROW * 4);
+    if (half == 0) rows[l31] = off;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) unsafeAtomicAdd(dst + 8 * (r >> 2) + (r & 3), a[r] * scale);
+    for (int q = 0; q < 4; ++q)
+        *(float4*)(tile + l31 * XROW + 8 * q + 4 * half) = float4{a[4 * q + 0] * scale, a[4 * q + 1] * scale, a[4 * q + 2] * scale, a[4 * q + 3] * scale};
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");     // (a wave's LDS operations execute in order; this keeps the compiler from moving them)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int tok = 2 * i + half;
+        const float v = tile[tok * XROW + l31];
+        const int64_t o = rows[tok];
+        if (o >= 0) unsafeAtomicAdd(base + o + l31, v);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 }
 
 // wave_rol:1 -- lane i takes the value of lane (i + 1) mod 64
@@ -322,10 +339,13 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
     const float inv = 1.0f / a.g_scale;
 #pragma unroll
     for (int t = 0; t < QT; ++t)
-        if (qvalid[t]) {
-            if (splits > 1) add_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
-            else store_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
-        }
+        if (splits == 1 && qvalid[t]) store_cols(a.d_q, p.q, qrow[t], head, half, dQ[t], inv);
+    if (splits > 1) {          // (uniform) partial sums of a split launch: the K / V chunk buffers are free now
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < QT; ++t)
+            add_cols_lds(a.d_q, qvalid[t] ? qrow[t] * p.q.ld + p.q.col0 + (int64_t)head * p.q.hstride : -1, lane, dQ[t], inv, Ks + wave * XWAVE);
+    }
     if constexpr (!GHIST) {
         __syncthreads();
         for (int i = tid; i < p.trows; i += nthreads) {
@@ -523,14 +543,19 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
 #pragma unroll
     for (int t = 0; t < QT; ++t)
         if (kvalid[t]) {
-            if (splits > 1) {
-                add_cols(a.d_k, p.k, krow[t], head, half, dK[t], inv);
-                add_cols(a.d_v, p.v, krow[t], head, half, dV[t], inv);
-            } else {
+            if (splits == 1) {
                 store_cols(a.d_k, p.k, krow[t], head, half, dK[t], inv);
                 store_cols(a.d_v, p.v, krow[t], head, half, dV[t], inv);
             }
         }
+    if (splits > 1) {          // (uniform) see attn_dq_kernel
+        __syncthreads();
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            add_cols_lds(a.d_k, kvalid[t] ? krow[t] * p.k.ld + p.k.col0 + (int64_t)head * p.k.hstride : -1, lane, dK[t], inv, Qs + wave * XWAVE);
+            add_cols_lds(a.d_v, kvalid[t] ? krow[t] * p.v.ld + p.v.col0 + (int64_t)head * p.v.hstride : -1, lane, dV[t], inv, Qs + wave * XWAVE);
+        }
+    }
 }
 
 }  // namespace
@@ -564,9 +589,11 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         int s = 1;
         if (force_splits > 1) s = force_splits;
         else {
-            // measured (GRL-Base training step, batch 8 x 64x64, same box): no split 169.1 ms, 2 parts 162.1, 4 parts 165.0, 8 parts
-            // 164.9 -- the 16 atomic adds per lane and tile cost more than the extra workgroups bring beyond two-way sharing
-            const int cap = force_splits < 0 ? -force_splits : 2;
+            // measured (GRL-Base training step, batch 8 x 64x64, same box): no split 156.5 ms; the 96-workgroup launches in 2 parts
+            // 152.9, in 4 parts 151.5, in 8 parts 151.5; ALSO splitting the 384-workgroup launches 154.5 (they are bound by their
+            // VALU work, not by parallelism).  With per-lane atomics (lane = token, 64 cache lines per instruction) instead of
+            // add_cols_lds the same experiments read 162.1 / 165.0 / 164.9 / 187.4 against 169.1.
+            const int cap = force_splits < 0 ? -force_splits : 4;
             while (grid * s < 256 && nchunks / (2 * s) >= 4 && 2 * s <= cap) s *= 2;      // >= 4 chunks per workgroup stay
         }
         return s < nchunks ? (s < 1 ? 1 : s) : (nchunks > 0 ? nchunks : 1);

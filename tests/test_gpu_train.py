@@ -513,6 +513,13 @@ def test_training_gradients_other_geometries_vs_oracle_autograd(model, geom, up,
     assert ex < 5e-2 and med < 1e-2 and srt[0][1] < 6e-2, srt[:4]
 
 
+def test_training_gradients_per_slot_plane_path(monkeypatch):
+    """The per-slot chain of head planes / bias tables (round 4; still what a block whose two branches have different head counts
+    takes) against the same oracle gradients as the batched chains that are the default since round 5."""
+    monkeypatch.setenv("GRL_TRAIN_BATCHED_PLANES", "0")
+    test_training_gradients_other_geometries_vs_oracle_autograd("base", "deblur", 1, (48, 96), "deblur")
+
+
 @pytest.mark.gpu
 def test_graphed_train_step_matches_eager_steps():
     """train_graph.GraphedTrainStep: forward + L1 + backward + FusedAdamW captured once as a HIP graph and replayed follows the
