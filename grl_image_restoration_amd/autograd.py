@@ -129,26 +129,37 @@ _REGISTERED = weakref.WeakKeyDictionary()   # module -> storage addresses of its
 
 
 def forget_parameters(module: torch.nn.Module) -> None:
-    """Drops the cached padded fp16 copies of ``module``'s weights (GRL.invalidate_plan: weights changed behind autograd's back).
-    The parameters may have been REPLACED by new tensors: the copies under the addresses the module was registered with go as
-    well (those addresses are free for other tensors now), and a registered module is registered again under its current ones."""
+    """Invalidates the cached padded fp16 copies of ``module``'s weights (GRL.invalidate_plan: weights changed behind autograd's back).
+    Parameters that are still where they were keep their BUFFERS -- the entry is only marked stale and refreshed in place at its next
+    use: a captured training step (train_graph.py) holds the addresses of those buffers and rewrites them on every replay, so
+    returning them to the allocator would let a replay scribble over whatever tensor received the memory next (round 5: an eval forward
+    between two replays did exactly that through invalidate_plan -- an order-dependent failure of the LR-schedule test).  Parameters that
+    were REPLACED by new tensors: the copies under the addresses the module was registered with go (those addresses are free for other
+    tensors now), and a registered module is registered again under its current ones."""
     old = _REGISTERED.get(module)
+    cur = frozenset(p.data_ptr() for p in module.parameters())
     for ptr in old or ():
-        _WEIGHTS.pop(ptr, None)
-    for p in module.parameters():
-        _WEIGHTS.pop(p.data_ptr(), None)
+        if ptr not in cur:
+            _WEIGHTS.pop(ptr, None)
+    for ptr in cur:
+        ent = _WEIGHTS.get(ptr)
+        if isinstance(ent, list):
+            ent[0], ent[3] = None, None          # no version matches: the next _padded_weight copies into the same buffer again
+        elif ent is not None:
+            _WEIGHTS.pop(ptr, None)
     if old is not None:
-        register_parameters(module)
+        register_parameters(module, _keep=cur)
 
 
-def register_parameters(module: torch.nn.Module) -> None:
+def register_parameters(module: torch.nn.Module, _keep: frozenset = frozenset()) -> None:
     """Allow the padded fp16 copies of this module's weights to be kept between the forward and the backward of a step (and
     across steps until the optimizer changes them).  Only registered parameters are cached: a temporary tensor's address can be
     reused by another tensor with the same shape and version, a parameter's cannot while its module lives (the registration
     goes away with the module)."""
     ptrs = frozenset(p.data_ptr() for p in module.parameters())
     for ptr in ptrs:                       # a previous owner of the same addresses (a deleted model) may have left copies behind
-        _WEIGHTS.pop(ptr, None)
+        if ptr not in _keep:               # (forget_parameters: entries of this module it has just marked stale)
+            _WEIGHTS.pop(ptr, None)
     _REGISTERED[module] = ptrs
 
 

@@ -391,6 +391,31 @@ def test_forget_parameters_follows_replaced_tensors():
     assert m2 not in AG._REGISTERED
 
 
+def test_forget_parameters_keeps_the_buffers_a_captured_step_points_at():
+    """A captured training step rewrites the padded fp16 weight copies through their ADDRESSES on every replay.  invalidate_plan ->
+    forget_parameters (an eval forward between replays gets there through the version stamp) must therefore only mark the copies of
+    parameters that stayed in place stale -- freeing them let a replay write into whatever tensor the allocator handed the memory to
+    next (round 5)."""
+    import torch
+
+    from grl_image_restoration_amd import autograd as AG
+
+    lin = torch.nn.Linear(180, 100)
+    AG.register_parameters(lin)
+    w = lin.weight
+    a = AG._padded_weight(w, 128, 192)
+    at = AG._padded_weight(w, 128, 192, transposed=True)
+    with torch.no_grad():
+        w.data.mul_(2.0)                                      # a change the version counter does not see
+    AG.forget_parameters(lin)
+    assert w.data_ptr() in AG._WEIGHTS and AG._is_registered(w.data_ptr())
+    b = AG._padded_weight(w, 128, 192)
+    assert b is a and b.data_ptr() == a.data_ptr()            # the same buffer, refreshed in place
+    assert torch.equal(b[:100, :180], w.detach().half())
+    assert torch.equal(AG._padded_weight(w, 128, 192, transposed=True), b.t())
+    del lin, at
+
+
 def test_transposed_view_is_the_same_attention_on_the_oracle():
     """GrlTokenGrid.transposed + ops.transpose_table (round 4): launching a (query window, key window) pair on the transposed view
     of its grids with the transposed bias table is the SAME attention.  Checked on the oracle's own index arithmetic
