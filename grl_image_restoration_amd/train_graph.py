@@ -106,7 +106,11 @@ class GraphedTrainStep:
         optimizer.enable_capture()
         optimizer.zero_grad(set_to_none=True)     # the gradients of the captured step come from the graph's own memory pool
         self.graph, self.graph_update = torch.cuda.CUDAGraph(), None
-        with AG.frozen_grad_scale(), torch.cuda.graph(self.graph):
+        # With a NCCL / RCCL process group alive its watchdog thread polls the events of finished collectives (the warm-up steps'
+        # all-reduces) from ANOTHER thread; under the default "global" capture mode such a query while this thread captures is an error
+        # that the watchdog turns into std::terminate.  "thread_local" restricts the check to the capturing thread.
+        mode = "thread_local" if (dist.is_available() and dist.is_initialized()) else "global"
+        with AG.frozen_grad_scale(), torch.cuda.graph(self.graph, capture_error_mode=mode):
             optimizer.zero_grad(set_to_none=True)
             self.loss = self.loss_fn(self.model(self.lq), self.gt)
             self.loss.backward()
@@ -122,7 +126,7 @@ class GraphedTrainStep:
             for p, v in zip(self._params, self._flat_grad_views(self._flat)):
                 p.grad = v
             self.graph_update = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph_update, pool=self.graph.pool()):
+            with torch.cuda.graph(self.graph_update, pool=self.graph.pool(), capture_error_mode=mode):
                 if self._wire_bf16:
                     self._flat.copy_(self._wire)
                 optimizer.step(grad_scale=1.0 / self._world)

@@ -388,91 +388,6 @@ def test_ddp_two_replicas_on_the_gpu():
     assert worst < 5e-3       # fp32 atomics in the weight-gradient / table reductions and per-pass gradient scales differ
 
 
-def _graphed_ddp_worker(rank, world, port, ret, wire_bf16):
-    """A replica of the two-graph data-parallel step (train_graph.py) on the one GPU of the box, gloo between the replicas."""
-    import os
-
-    import torch.distributed as dist
-
-    from grl_image_restoration_amd import GRL, FusedAdamW, GraphedTrainStep, make_config
-
-    os.environ["MASTER_ADDR"] = "127.0.0.1"
-    os.environ["MASTER_PORT"] = str(port)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    dev = torch.device("cuda", 0)
-    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[1, 1], num_heads_window=[3, 3], num_heads_stripe=[3, 3],
-                      drop_path_rate=0.0)
-    torch.manual_seed(rank)                   # the replicas start DIFFERENT: the constructor's broadcast has to make them equal
-    m = GRL(**cfg)
-    if rank == 0:
-        m.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0), strict=True)
-    m = m.to(dev).train()
-    lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=4, seed=21)
-    per = lq.shape[0] // world
-    x, y = lq[rank * per : (rank + 1) * per].to(dev), gt[rank * per : (rank + 1) * per].to(dev)
-    opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
-    step = GraphedTrainStep(m, opt, lambda o, t: (o - t).abs().mean(), x, y, warmup=1, wire_bf16=wire_bf16)    # default group
-    losses = [float(step(x, y).detach()) for _ in range(3)]
-    step.finish()
-    grads_are_views = all(p.grad is not None and p.grad.data_ptr() >= step._flat.data_ptr() and
-                          p.grad.data_ptr() < step._flat.data_ptr() + step._flat.numel() * 4 for p in m.parameters())
-    ret[rank] = ({k: p.detach().cpu().clone() for k, p in m.named_parameters()}, losses, step.collectives,
-                 opt.state[next(iter(m.parameters()))]["step"], grads_are_views)
-    dist.barrier()
-    dist.destroy_process_group()
-
-
-@pytest.mark.parametrize("wire_bf16", [False, True])
-def test_graphed_step_data_parallel_two_replicas(wire_bf16):
-    """The captured training step under data parallelism (VERDICT r4 missing #2): graph A (forward, loss, backward, flat gradient
-    buffer) -> ONE eager all-reduce -> graph B (FusedAdamW on the averaged gradients).  Two half-batch replicas stay bit-identical
-    to each other and follow the single-process full-batch EAGER steps as closely as the replica test above allows."""
-    import socket
-
-    import torch.multiprocessing as mp
-
-    from grl_image_restoration_amd import GRL, FusedAdamW, make_config
-
-    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
-    ret = mp.Manager().dict()
-    mp.spawn(_graphed_ddp_worker, args=(2, port, ret, wire_bf16), nprocs=2, join=True)
-    (p0, l0, c0, n0, v0), (p1, l1, c1, n1, v1) = ret[0], ret[1]
-    assert c0 == c1 == 1 + 3 and n0 == n1 == 1 + 3 and v0 and v1          # one collective per step (warm-up + 3 replays)
-    for k in p0:
-        assert torch.equal(p0[k], p1[k]), k                                # same averaged gradients -> same weights, bit for bit
-    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[1, 1], num_heads_window=[3, 3], num_heads_stripe=[3, 3],
-                      drop_path_rate=0.0)
-
-    def single():
-        m = GRL(**cfg)
-        m.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0), strict=True)
-        m = m.cuda().train()
-        opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
-        lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=4, seed=21)
-        lq, gt = lq.cuda(), gt.cuda()
-        out = []
-        for _ in range(1 + 3):
-            opt.zero_grad(set_to_none=True)
-            loss = (m(lq) - gt).abs().mean()
-            loss.backward()
-            opt.step()
-            out.append(float(loss.detach()))
-        return {k: p.detach().cpu() for k, p in m.named_parameters()}, out[1:]
-
-    (pa, la), (pb, lb) = single(), single()                                # two eager runs: the yardstick (atomics, Adam's first steps)
-    n = sum(v.numel() for v in pa.values())
-    d_ee = sum(float((pa[k] - pb[k]).abs().sum()) for k in pa) / n
-    d_eg = sum(float((pa[k] - p0[k]).abs().sum()) for k in pa) / n
-    lg = [0.5 * (a + b) for a, b in zip(l0, l1)]                           # mean of the half-batch losses = the full-batch loss
-    l_ee = max(abs(a - b) for a, b in zip(la, lb))
-    l_eg = max(abs(a - b) for a, b in zip(la, lg))
-    print(f"wire_bf16={wire_bf16}: losses eager {la} | replicas {lg}; mean |dp| eager-eager {d_ee:.3e}, eager-replicas {d_eg:.3e}; "
-          f"max |dloss| {l_ee:.3e} / {l_eg:.3e}")
-    slack = 4.0 if not wire_bf16 else 40.0                                 # bf16 on the wire: 3 significant digits per gradient
-    assert d_eg <= slack * d_ee + 2e-6 and l_eg <= slack * l_ee + 1e-4
-    assert lg[-1] < lg[0]
-
-
 @pytest.mark.parametrize("model,geom,up,hw,task", [
     ("tiny", "yaml", 2, (32, 32), "sr"),            # stripe_groups geometry, head_dim 16, pixelshuffledirect tail, no CAB
     ("small", "dn_df4", 1, (64, 128), "dn"),        # head_dim 32 (generic attention kernels), window 16, stripes 64x128 / anchors 16x32
@@ -636,3 +551,89 @@ def test_graphed_train_step_follows_lr_schedule_and_resume():
     torch.cuda.synchronize()
     assert float(opt.state[p0]["exp_avg"].abs().max()) > 0.0   # the replay wrote the (re-started) moments, not stale buffers
     step.finish()
+
+
+# (last in the file: these tests run replicas in spawned processes on the same GPU)
+def _graphed_ddp_worker(rank, world, port, ret, wire_bf16):
+    """A replica of the two-graph data-parallel step (train_graph.py) on the one GPU of the box, gloo between the replicas."""
+    import os
+
+    import torch.distributed as dist
+
+    from grl_image_restoration_amd import GRL, FusedAdamW, GraphedTrainStep, make_config
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[1, 1], num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+                      drop_path_rate=0.0)
+    torch.manual_seed(rank)                   # the replicas start DIFFERENT: the constructor's broadcast has to make them equal
+    m = GRL(**cfg)
+    if rank == 0:
+        m.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0), strict=True)
+    m = m.to(dev).train()
+    lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=4, seed=21)
+    per = lq.shape[0] // world
+    x, y = lq[rank * per : (rank + 1) * per].to(dev), gt[rank * per : (rank + 1) * per].to(dev)
+    opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
+    step = GraphedTrainStep(m, opt, lambda o, t: (o - t).abs().mean(), x, y, warmup=1, wire_bf16=wire_bf16)    # default group
+    losses = [float(step(x, y).detach()) for _ in range(3)]
+    step.finish()
+    grads_are_views = all(p.grad is not None and p.grad.data_ptr() >= step._flat.data_ptr() and
+                          p.grad.data_ptr() < step._flat.data_ptr() + step._flat.numel() * 4 for p in m.parameters())
+    ret[rank] = ({k: p.detach().cpu().clone() for k, p in m.named_parameters()}, losses, step.collectives,
+                 opt.state[next(iter(m.parameters()))]["step"], grads_are_views)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("wire_bf16", [False, True])
+def test_graphed_step_data_parallel_two_replicas(wire_bf16):
+    """The captured training step under data parallelism (VERDICT r4 missing #2): graph A (forward, loss, backward, flat gradient
+    buffer) -> ONE eager all-reduce -> graph B (FusedAdamW on the averaged gradients).  Two half-batch replicas stay bit-identical
+    to each other and follow the single-process full-batch EAGER steps as closely as the replica test above allows."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from grl_image_restoration_amd import GRL, FusedAdamW, make_config
+
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_graphed_ddp_worker, args=(2, port, ret, wire_bf16), nprocs=2, join=True)
+    (p0, l0, c0, n0, v0), (p1, l1, c1, n1, v1) = ret[0], ret[1]
+    assert c0 == c1 == 1 + 3 and n0 == n1 == 1 + 3 and v0 and v1          # one collective per step (warm-up + 3 replays)
+    for k in p0:
+        assert torch.equal(p0[k], p1[k]), k                                # same averaged gradients -> same weights, bit for bit
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[1, 1], num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+                      drop_path_rate=0.0)
+
+    def single():
+        m = GRL(**cfg)
+        m.load_state_dict(O.seeded_state_dict({k: tuple(v.shape) for k, v in m.state_dict().items()}, 0), strict=True)
+        m = m.cuda().train()
+        opt = FusedAdamW(m.parameters(), lr=2e-4, weight_decay=1e-4)
+        lq, gt = O.synthetic_pair("sr", (64, 64), 4, batch=4, seed=21)
+        lq, gt = lq.cuda(), gt.cuda()
+        out = []
+        for _ in range(1 + 3):
+            opt.zero_grad(set_to_none=True)
+            loss = (m(lq) - gt).abs().mean()
+            loss.backward()
+            opt.step()
+            out.append(float(loss.detach()))
+        return {k: p.detach().cpu() for k, p in m.named_parameters()}, out[1:]
+
+    (pa, la), (pb, lb) = single(), single()                                # two eager runs: the yardstick (atomics, Adam's first steps)
+    n = sum(v.numel() for v in pa.values())
+    d_ee = sum(float((pa[k] - pb[k]).abs().sum()) for k in pa) / n
+    d_eg = sum(float((pa[k] - p0[k]).abs().sum()) for k in pa) / n
+    lg = [0.5 * (a + b) for a, b in zip(l0, l1)]                           # mean of the half-batch losses = the full-batch loss
+    l_ee = max(abs(a - b) for a, b in zip(la, lb))
+    l_eg = max(abs(a - b) for a, b in zip(la, lg))
+    print(f"wire_bf16={wire_bf16}: losses eager {la} | replicas {lg}; mean |dp| eager-eager {d_ee:.3e}, eager-replicas {d_eg:.3e}; "
+          f"max |dloss| {l_ee:.3e} / {l_eg:.3e}")
+    slack = 4.0 if not wire_bf16 else 40.0                                 # bf16 on the wire: 3 significant digits per gradient
+    assert d_eg <= slack * d_ee + 2e-6 and l_eg <= slack * l_ee + 1e-4
+    assert lg[-1] < lg[0]
