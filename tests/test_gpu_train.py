@@ -534,6 +534,7 @@ def test_graphed_train_step_follows_lr_schedule_and_resume():
     opt.param_groups[0]["lr"] = 2e-4
     step(lq, gt)
     w2 = snap()
+    assert bool(torch.isfinite(w2).all()), "non-finite weights after a replay"
     assert float((w2 - w0).abs().max()) > 1e-5
     with torch.no_grad():
         y_b = m.eval()(lq)                                # no finish() in between: the plan must have been rebuilt from the new weights
