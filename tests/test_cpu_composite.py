@@ -44,3 +44,41 @@ def test_cpu_path_is_differentiable_and_announced():
     assert x.grad is not None and torch.isfinite(x.grad).all()
     g = m.layers[0].blocks[0].attn.window_attn.attn_transform.logit_scale.grad
     assert g is not None and torch.isfinite(g).all()
+
+
+def test_batched_plane_and_table_chains_equal_the_per_slot_chains(monkeypatch):
+    """Round 5 builds the head planes of a block, and the bias tables / logit scales of all blocks, in batched chains
+    (GRL._block_planes / _train_tables / _residual).  Same loss and same gradients as the per-slot chains of round 4
+    (GRL_TRAIN_BATCHED_PLANES=0), here through the composite contractions on CPU at a checkpoint-like spread of logit scales, with
+    DropPath on (both paths draw the same masks)."""
+    from grl_image_restoration_amd import GRL, make_config
+
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64, depths=[2, 1], num_heads_window=[3, 3], num_heads_stripe=[3, 3],
+                      drop_path_rate=0.2)
+
+    def run(flag):
+        monkeypatch.setenv("GRL_TRAIN_BATCHED_PLANES", flag)
+        torch.manual_seed(0)
+        m = GRL(**cfg).train()
+        with torch.no_grad():
+            for n, p in m.named_parameters():
+                if "logit_scale" in n:
+                    p.add_(torch.randn_like(p) * 0.5 + 1.0)
+        g = torch.Generator().manual_seed(1)
+        x, y = torch.rand(2, 3, 64, 64, generator=g), torch.rand(2, 3, 256, 256, generator=g)
+        torch.manual_seed(7)                      # the DropPath draws
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            loss = (m(x) - y).abs().mean()
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in m.named_parameters()}
+
+    l0, g0 = run("0")
+    l1, g1 = run("1")
+    assert abs(l0 - l1) < 1e-6, (l0, l1)
+    rel = {k: ((g0[k] - g1[k]).abs().max() / (g0[k].abs().max() + 1e-30)).item() for k in g0}
+    big = {k: v for k, v in rel.items() if "cpb_mlp" not in k and "logit_scale" not in k}
+    worst = max(rel, key=rel.get)
+    print(f"loss {l0:.7f} / {l1:.7f}; worst relative gradient difference {rel[worst]:.2e} ({worst}); without the CPB-MLP / scales {max(big.values()):.2e}")
+    # fp32 sums in a different order (measured: 4e-6 worst, 1.5e-6 without the tiny CPB-MLP / logit-scale gradients)
+    assert max(big.values()) < 1e-4 and rel[worst] < 1e-3
