@@ -359,7 +359,10 @@ def run(args, rank, world, local_rank):
     if not args.no_train and args.config == 3:
         del model, x, y
         torch.cuda.empty_cache()
-        training = training_leg(args, dev, rank, world)
+        try:      # a secondary leg: its failure is reported in the line, it does not take the headline measurement down with it
+            training = training_leg(args, dev, rank, world)
+        except Exception as e:      # noqa: BLE001
+            training = {"error": f"{type(e).__name__}: {e}"[:400]}
 
     if rank == 0:
         mp = world * args.tiles * side * side * args.steps / dt / 1e6
