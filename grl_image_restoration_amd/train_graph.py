@@ -20,7 +20,8 @@ The collective is NOT captured: the step does not depend on the communication li
 over gloo (tests: two replicas on one GPU).  There is no overlap of the all-reduce with the backward pass -- 2 x 77 MB x 7/8 over
 xGMI is 1-2 ms of a 200 ms step.  A ``DistributedDataParallel`` wrapper must NOT exist around the model (its reducer hooks would
 fire inside the capture): pass the bare module and a process group; the parameters are broadcast from the group's rank 0 first,
-as the wrapper would have done.
+as the wrapper would have done.  The returned loss is the replica's own (as under DistributedDataParallel).  While a process group is
+alive the graphs are captured in "thread_local" error mode: RCCL's watchdog thread queries events from outside the capturing thread.
 
 What a captured step FREEZES, and what it does not:
   * learning rate and weight decay are NOT frozen: the launch reads them from device memory and ``__call__`` refreshes them from
