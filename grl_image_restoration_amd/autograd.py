@@ -354,8 +354,8 @@ def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch
     alias its inputs) and the backward takes the operands from the inputs."""
     have = (q16, k16, v16)
     q16, k16, v16 = _attn_operands(q, k, v, d, prepared, have)
-    o = torch.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
-    lse = torch.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
+    o = ops.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
+    lse = ops.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
     TG = ops.TokenGrid
     ops.attention(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), B=B, nh=nh, table=table.detach().contiguous(),
                   masked=masked, ones_col=d if d < 32 else -1, head_dim=d, k_one31=d <= 30, lazy_floor=floor if d <= 30 else None, lse=lse)

@@ -211,21 +211,24 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
         // slot 31 of q carries the forward kernel's running offset in registers only: in memory it is a pad column (0)
         dof[t][0] = load_f32x8_as_f16(a.d_o, p.o, qrow[t], head, half, a.g_scale);
         dof[t][1] = load_f32x8_as_f16(a.d_o, p.o, qrow[t], head, 2 + half, a.g_scale);
-        // D_i = sum_c dO_ic O_ic (scaled like dO): this lane holds 16 of the 32 columns
+        // D_i = sum_c dO_ic O_ic (scaled like dO): this lane holds 16 of the 32 columns.  Taken from the SAME fp16-rounded dO the
+        // MFMA contracts with v: dS = P (dO.v_j - D_i) is a small difference of two nearly equal numbers wherever the values of a
+        // window resemble each other (stripe tokens -> anchors: v is the anchors' aggregate), and with D from the unrounded dO the
+        // rounding error of dO -- the same for every key j of the row -- did not cancel: round 5 measured 13-32 % run-to-run
+        // noise in dQ of those launches (an upstream 1e-7 flips fp16 roundings) and the bias-table gradient error above the bar.
         float d = 0.f;
         {
             const float* op = (const float*)p.o.ptr + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride;
-            const float* gp = a.d_o + qrow[t] * p.o.ld + p.o.col0 + head * p.o.hstride;
 #pragma unroll
             for (int s = 0; s < 2; ++s)
 #pragma unroll
                 for (int e = 0; e < 8; ++e) {
                     const int c = 16 * s + 8 * half + e;
-                    if (c < p.head_dim) d += op[c] * gp[c];
+                    if (c < p.head_dim) d += op[c] * (float)dof[t][s][e];
                 }
         }
         d += xhalf(d);
-        Dq[t] = d * a.g_scale;
+        Dq[t] = d;
         lse[t] = p.lse[(int64_t)head * p.lse_stride + qrow[t]];
 #pragma unroll
         for (int r = 0; r < 16; ++r) dQ[t][r] = 0.f;
@@ -436,10 +439,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
                 qv = load_f16x8(p.q, row, head, seg);
                 gv = load_f32x8_as_f16(a.d_o, p.o, row, head, seg, a.g_scale);
                 const float* op = (const float*)p.o.ptr + row * p.o.ld + p.o.col0 + head * p.o.hstride + seg * 8;
-                const float* gp = a.d_o + row * p.o.ld + p.o.col0 + head * p.o.hstride + seg * 8;
 #pragma unroll
-                for (int e = 0; e < 8; ++e)
-                    if (seg * 8 + e < p.head_dim) dpart += op[e] * gp[e];
+                for (int e = 0; e < 8; ++e)                              // (from the rounded dO: see attn_dq_kernel)
+                    if (seg * 8 + e < p.head_dim) dpart += op[e] * (float)gv[e];
             }
             // D_i: the four segment owners of a query are four consecutive lanes
             dpart += dpp_move<DPP_QUAD_XOR1>(dpart);
@@ -457,7 +459,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
                 qoff[qq] = hq * D + wq;
                 qreg[qq] = valid ? (unsigned char)rid : (unsigned char)255;
                 qlse[qq] = valid ? p.lse[(int64_t)head * p.lse_stride + row] : 1.0e30f;   // invalid query: weight 0
-                qD[qq] = dpart * a.g_scale;
+                qD[qq] = dpart;
             }
         }
         __syncthreads();

@@ -660,7 +660,7 @@ class GRL(nn.Module):
         gate; the gate is applied inside the proj+norm1 epilogue.  fast: fp16 intermediates; high: fp32 + split operands."""
         hi = self.precision == "high" and not self._high_cab_fp16()
         sp, dt = (3, torch.float32) if hi else (1, ops.GEMM_DTYPE)
-        mid = torch.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
+        mid = ops.empty(B * H * W, pk["cab_mid"], dtype=dt, device=r.device)  # fast: pad channels zero-filled by the conv store
         ops.conv3x3(r, pk["cab0_w"], pk["cab0_b"], B, H, W, act=1, out=mid, x_split=pk["cab0_split"])
         # (GRL_SE_FOLD=1: conv2 + pool + squeeze-excite gate in one launch, the gate by the last workgroup of each image.  Measured
         # SLOWER in the two-stream bench, 88.1 against 82.6 ms/step: the serial tail of one workgroup per image holds the whole
@@ -683,9 +683,9 @@ class GRL(nn.Module):
         nh_w, nh_s, df = geo.nh_w, geo.nh_s, geo.df
         d_w, d_s = C // 2 // nh_w, C // 2 // nh_s
         Ha, Wa = H // df, W // df
-        y = torch.empty(nh_s, B * Ha * Wa, 32, dtype=ops.PLANE_DTYPE, device=att.device)
+        y = ops.empty(nh_s, B * Ha * Wa, 32, dtype=ops.PLANE_DTYPE, device=att.device)
         split = qkv_lo is not None
-        y_lo = torch.empty_like(y) if split else None
+        y_lo = ops.empty_like(y) if split else None
 
         ws, sh = geo.window, geo.window_shift
         TG = ops.TokenGrid
@@ -738,7 +738,7 @@ class GRL(nn.Module):
             else:
                 qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True)
             anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(df, H, W), planes=True)
-        att = torch.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
+        att = ops.empty(M, (nh_w + nh_s) * 32, dtype=ops.GEMM_DTYPE, device=dev)  # operand of the proj GEMM
         self._attention(qkv, anc, att, pk, geo, B, H, W)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
         if "proj_blob" in pk and "mlp_blob" in pk and H * W >= 128 and os.environ.get("GRL_FUSED_TAIL", "1") != "0":
@@ -766,8 +766,8 @@ class GRL(nn.Module):
         f32 = torch.float32
         G = pk["qkv_w"].shape[0] // 32
         Ma = M // (geo.df * geo.df)
-        qkv_lo = torch.empty(G, M, 32, dtype=ops.PLANE_DTYPE, device=r.device)
-        anc_lo = torch.empty(geo.nh_s, Ma, 32, dtype=ops.PLANE_DTYPE, device=r.device)
+        qkv_lo = ops.empty(G, M, 32, dtype=ops.PLANE_DTYPE, device=r.device)
+        anc_lo = ops.empty(geo.nh_s, Ma, 32, dtype=ops.PLANE_DTYPE, device=r.device)
         qkv = ops.linear(r, pk["qkv_w"], pk["qkv_b"], epi=L.EPI_GROUPNORM, gscale=pk["qkv_gs"], planes=True, a_split=3, out_lo=qkv_lo, w_regs=pk.get("qkv_wr"))
         if pk.get("anc_wr") is not None and Ma % 32 == 0:
             # AnchorLinear's avg-pool (mixed_attn_block.py:727-736) as a reduction of its own, then the weights-stationary kernel on
@@ -778,7 +778,7 @@ class GRL(nn.Module):
         else:
             anc = ops.linear(r, pk["anc_w"], pk["anc_b"], epi=L.EPI_GROUPNORM, gscale=pk["anc_gs"], pool=(geo.df, H, W), planes=True,
                              a_split=3, out_lo=anc_lo)
-        att = torch.empty(M, (geo.nh_w + geo.nh_s) * 32, dtype=f32, device=r.device)
+        att = ops.empty(M, (geo.nh_w + geo.nh_s) * 32, dtype=f32, device=r.device)
         # attention on split operands too: q, k, v (and the anchor-side values) as fp16 hi + lo planes -> generic kernel
         self._attention(qkv, anc, att, pk, geo, B, H, W, qkv_lo=qkv_lo, anc_lo=anc_lo)
         cab, gate = self._cab(r, pk, B, H, W, CP) if self.local_connection else (None, None)
@@ -850,7 +850,7 @@ class GRL(nn.Module):
             for g in range(n):
                 with torch.cuda.stream(pool[g]):
                     parts[g] = ops.conv3x3(r[g], st["conv_w"], st["conv_b"], Bg, H, W, resid=parts[g], x_split=plan["xs"]["stage_conv"])
-        out = torch.empty_like(t)
+        out = ops.empty_like(t)
         for g in range(n):
             with torch.cuda.stream(pool[g]):
                 ops.layernorm(parts[g], plan["ne_g"], plan["ne_b"], self.embed_dim, out=out[g * Mg : (g + 1) * Mg])

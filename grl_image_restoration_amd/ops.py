@@ -18,6 +18,40 @@ PLANE_DTYPE = torch.float16  # q / k / v / anchor head planes (attention operand
 _KIND = {torch.float32: L.DT_F32, torch.float16: L.DT_F16}
 
 
+# ---- uninitialised workspace ------------------------------------------------------------------------------------------
+# Every output / workspace tensor of the C-ABI wrappers (and of autograd.py / model.py) comes from here.  GRL_POISON=1 fills it with
+# NaN (floating types) or 0x7f bytes first: a kernel that reads an element neither it nor a predecessor wrote turns up as a NaN
+# in the parity tests instead of depending on what the allocator handed out (zeros in a fresh process, another process's leftovers
+# in memory the driver recycled -- round 5's order-dependent failure of the captured training step).  The fill is an ordinary
+# launch on the current stream, so it is captured into a HIP graph with the step and re-poisons the buffer on every replay.
+_POISON = os.environ.get("GRL_POISON", "0") == "1"
+
+
+def set_poison(flag: bool) -> bool:
+    """Switch the poison mode at run time (tests); returns the previous setting."""
+    global _POISON
+    prev, _POISON = _POISON, bool(flag)
+    return prev
+
+
+def _poison(t: torch.Tensor) -> torch.Tensor:
+    if _POISON and t.numel():
+        if t.dtype.is_floating_point:
+            t.fill_(float("nan"))
+        else:
+            t.view(torch.uint8).fill_(0x7F)
+    return t
+
+
+def empty(*shape, dtype, device) -> torch.Tensor:
+    return _poison(torch.empty(*shape, dtype=dtype, device=device))
+
+
+def empty_like(t: torch.Tensor) -> torch.Tensor:
+    return _poison(torch.empty_like(t))
+
+
+
 def split3_weight(w: torch.Tensor) -> torch.Tensor:
     """fp32 [N, K] -> fp16 [N, 3K] = [hi | hi | lo] (hi = fp16(w), lo = fp16(w - hi)): the weight side of the
     split-precision operands (``a_split`` / ``x_split`` = 3; the kernels stage activations as [hi | lo | hi])."""
@@ -156,12 +190,12 @@ def linear(
     if planes:
         # head-plane layout [Npad/32, M, 32] (fp16): what the attention kernel stages fastest
         if out is None:
-            out = torch.empty(Npad // 32, M, 32, dtype=PLANE_DTYPE, device=a.device)
+            out = empty(Npad // 32, M, 32, dtype=PLANE_DTYPE, device=a.device)
         assert out.dtype == PLANE_DTYPE and out.is_contiguous() and out.shape == (Npad // 32, M, 32)
         ldo, plane_stride = 32, M * 32
     else:
         if out is None:
-            out = torch.empty(M, Npad, dtype=out_dtype, device=a.device)
+            out = empty(M, Npad, dtype=out_dtype, device=a.device)
         assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= Npad
         ldo, plane_stride = out.stride(0), 0
     args = L.GrlLinearArgs(
@@ -257,7 +291,7 @@ def qkv(x: torch.Tensor, blob: torch.Tensor, nslots: int, out: Optional[torch.Te
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and blob.dtype == torch.uint8 and blob.is_contiguous()
     M, Cpad = x.shape
     if out is None:
-        out = torch.empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
+        out = empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
     assert out.dtype == PLANE_DTYPE and out.is_contiguous() and out.shape == (nslots, M, 32)
     args = L.GrlQkvArgs(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), M=M, Cpad=Cpad, nslots=nslots, out=_ptr(out),
                         out_plane_stride=M * 32)
@@ -334,8 +368,8 @@ def qkv_anchor(x: torch.Tensor, blob: torch.Tensor, nslots: int, nanc: int, B: i
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == torch.float32 and blob.dtype == torch.uint8 and blob.is_contiguous()
     M, Cpad = x.shape
     assert M == B * H * W and H % 2 == 0 and W % 64 == 0
-    out = torch.empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
-    anc = torch.empty(max(nanc, 1), M // 4, 32, dtype=PLANE_DTYPE, device=x.device)
+    out = empty(nslots, M, 32, dtype=PLANE_DTYPE, device=x.device)
+    anc = empty(max(nanc, 1), M // 4, 32, dtype=PLANE_DTYPE, device=x.device)
     args = L.GrlQkvAnchorArgs(x=_ptr(x), ldx=x.stride(0), B=B, H=H, W=W, Cpad=Cpad, blob=_ptr(blob), nslots=nslots, nanc=nanc,
                               out=_ptr(out), out_plane_stride=M * 32, anc=_ptr(anc), anc_plane_stride=(M // 4) * 32, lo_blob=_ptr(lo_blob))
     with _timed("qkv_anchor"):
@@ -403,7 +437,7 @@ def block_tail(att: torch.Tensor, x: torch.Tensor, cab: torch.Tensor, gate: torc
     assert cab.dtype == GEMM_DTYPE and cab.stride(1) == 1 and cab.shape[0] == M and gate.dtype == torch.float32 and gate.is_contiguous()
     assert gate.shape[1] == Cpad and att.shape[1] >= Cpad and cab.shape[1] >= Cpad
     if out is None:
-        out = torch.empty(M, Cpad, dtype=torch.float32, device=x.device)
+        out = empty(M, Cpad, dtype=torch.float32, device=x.device)
     assert out.dtype == torch.float32 and out.stride(1) == 1 and out.data_ptr() != x.data_ptr()
     args = L.GrlTailArgs(att=_ptr(att), ldatt=att.stride(0), x=_ptr(x), ldx=x.stride(0), cab=_ptr(cab), ldcab=cab.stride(0),
                          gate=_ptr(gate), rows_per_image=rows_per_image, pblob=_ptr(pblob), pb=_ptr(pb), n1_g=_ptr(n1_g),
@@ -422,7 +456,7 @@ def mlp(x: torch.Tensor, blob: torch.Tensor, b2: torch.Tensor, ln_g: torch.Tenso
     M, Cpad = x.shape
     assert blob.dtype == torch.uint8 and blob.is_contiguous() and b2.numel() == Cpad and ln_g.numel() == Cpad and ln_b.numel() == Cpad
     if out is None:
-        out = torch.empty(M, Cpad, dtype=torch.float32, device=x.device)
+        out = empty(M, Cpad, dtype=torch.float32, device=x.device)
     assert out.dtype == torch.float32 and out.stride(1) == 1 and out.shape == (M, Cpad) and out.data_ptr() != x.data_ptr()
     args = L.GrlMlpArgs(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), M=M, Cpad=Cpad, Hpad=Hpad, b2=_ptr(b2), ln_g=_ptr(ln_g),
                         ln_b=_ptr(ln_b), n_real=n_real, ln_eps=ln_eps, res_scale=res_scale, out=_ptr(out), ldo=out.stride(0))
@@ -531,7 +565,7 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, n_real: 
     _dev_check(x, gamma, beta, out)
     assert x.dim() == 2 and x.dtype == torch.float32 and x.stride(1) == 1
     if out is None:
-        out = torch.empty_like(x)
+        out = empty_like(x)
     L.check(
         L.lib().grl_layernorm_fwd(L.stream_ptr(), _ptr(x), x.stride(0), _ptr(out), out.stride(0), _ptr(gamma),
                                   _ptr(beta), x.shape[0], n_real, x.shape[1], eps),
@@ -548,7 +582,7 @@ def layernorm_res(x: torch.Tensor, resid: torch.Tensor, gamma: torch.Tensor, bet
     assert x.dim() == 2 and x.dtype == torch.float32 and resid.dtype == torch.float32 and x.stride(1) == 1 and resid.stride(1) == 1
     n_pad = gamma.numel()
     assert x.shape[1] >= n_pad and resid.shape[1] >= n_pad and beta.numel() == n_pad
-    out = torch.empty(x.shape[0], n_pad, dtype=torch.float32, device=x.device)
+    out = empty(x.shape[0], n_pad, dtype=torch.float32, device=x.device)
     args = L.GrlLnResArgs(x=_ptr(x), ldx=x.stride(0), resid=_ptr(resid), ldr=resid.stride(0), gamma=_ptr(gamma), beta=_ptr(beta),
                           add2=_ptr(add2), add2_dtype=_KIND[add2.dtype] if add2 is not None else 0,
                           ldadd2=add2.stride(0) if add2 is not None else 0, add2_scale=_ptr(add2_scale),
@@ -613,12 +647,12 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     else:
         rows, cols = B * H * W, CoutP
     if out is None:
-        out = torch.empty(rows, cols, dtype=out_dtype, device=x.device)
+        out = empty(rows, cols, dtype=out_dtype, device=x.device)
     pool = None
     lib = L.lib()
     if want_pool:
         nwg = lib.grl_conv3x3_num_workgroups(B, H, W)
-        pool = torch.empty(nwg, CoutP, dtype=torch.float32, device=x.device)
+        pool = empty(nwg, CoutP, dtype=torch.float32, device=x.device)
     # at most 192 output channels per launch; larger layers are split on the channel axis
     step = CoutP
     # Short-K layers (CAB conv2: 64 -> 192 channels, 9 tap steps in all) are epilogue/store dominated with one 104 KB-LDS
@@ -670,10 +704,10 @@ def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H
     the squeeze-excite gate [B, 192] is computed by the kernel's last workgroup per image and returned instead of the sums."""
     _dev_check(x, blob, bias)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype == GEMM_DTYPE and x.shape[0] == B * H * W and x.shape[1] >= 56
-    out = torch.empty(B * H * W, 192, dtype=GEMM_DTYPE, device=x.device)
+    out = empty(B * H * W, 192, dtype=GEMM_DTYPE, device=x.device)
     tiles = ((H + 7) // 8) * ((W + 31) // 32)
     wgs = max(1, min(tiles, 256 // B))
-    pool = torch.empty(B * wgs, 192, dtype=torch.float32, device=x.device)
+    pool = empty(B * wgs, 192, dtype=torch.float32, device=x.device)
     args = L.GrlCabConv2Args(x=_ptr(x), ldx=x.stride(0), blob=_ptr(blob), bias=_ptr(bias), B=B, H=H, W=W, wgs_per_image=wgs,
                              out=_ptr(out), ldo=192, pool_partial=_ptr(pool), pool_stride=192)
     gate = None
@@ -687,7 +721,7 @@ def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H
                 raise RuntimeError("cab_conv2(se=...): run one eager forward on this stream before capturing it in a graph")
             cnt = _SE_COUNTERS[key] = torch.zeros(max(B, 64), dtype=torch.int32, device=x.device)
         cnt[:B].zero_()   # explicit: an aborted launch must not leave arrivals behind (the kernel also returns them to zero)
-        gate = torch.empty(B, 192, dtype=torch.float32, device=x.device)
+        gate = empty(B, 192, dtype=torch.float32, device=x.device)
         args.gate, args.se_counter = _ptr(gate), _ptr(cnt)
         args.se_w1, args.se_b1, args.se_w2, args.se_b2 = _ptr(w1), _ptr(b1), _ptr(w2), _ptr(b2)
         args.se_c, args.se_mid, args.inv_hw = C_, w1.shape[0], 1.0 / (H * W)
@@ -699,7 +733,7 @@ def cab_conv2(x: torch.Tensor, blob: torch.Tensor, bias: torch.Tensor, B: int, H
 def se_scale(pool: torch.Tensor, B: int, CP: int, C_: int, HW: int, w1, b1, w2, b2) -> torch.Tensor:
     """scale[B, CP] = sigmoid(W2 relu(W1 mean + b1) + b2) from the conv kernel's partial channel sums."""
     _dev_check(pool, w1, b1, w2, b2)
-    scale = torch.empty(B, CP, dtype=torch.float32, device=pool.device)
+    scale = empty(B, CP, dtype=torch.float32, device=pool.device)
     L.check(
         L.lib().grl_se_scale_fwd(L.stream_ptr(), _ptr(pool), B, pool.shape[0] // B, CP, C_, w1.shape[0], HW, _ptr(w1),
                                  _ptr(b1), _ptr(w2), _ptr(b2), _ptr(scale)),
@@ -744,9 +778,9 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     assert o.t.dtype == torch.float32 and d_o.dtype == torch.float32 and d_o.shape == o.t.shape and d_o.is_contiguous() and o.t.is_contiguous()
     assert q.t.is_contiguous() and k.t.is_contiguous() and v.t.is_contiguous() and q.slot == 0 and k.slot == 0 and v.slot == 0 and o.slot == 0
     # every token of q / k / v belongs to exactly one window of the launch: the kernels write all 32 columns of every row
-    d_q = torch.empty(q.t.shape, dtype=torch.float32, device=q.t.device)
-    d_k = torch.empty(k.t.shape, dtype=torch.float32, device=q.t.device)
-    d_v = torch.empty(v.t.shape, dtype=torch.float32, device=q.t.device)
+    d_q = empty(q.t.shape, dtype=torch.float32, device=q.t.device)
+    d_k = empty(k.t.shape, dtype=torch.float32, device=q.t.device)
+    d_v = empty(v.t.shape, dtype=torch.float32, device=q.t.device)
     d_table = torch.zeros_like(table)
     fwd = _attn_args(q, k, v, o, B, nh, table, masked, ones_col, head_dim, False, None, lse)
     args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale)
