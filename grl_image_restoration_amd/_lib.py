@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 20
+ABI_VERSION = 21
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -40,6 +40,7 @@ EXPORTS = [
     "grl_gemm_tn",
     "grl_attention_bwd",
     "grl_adamw_step",
+    "grl_debug_dirty_lds",
     "grl_abi_version",
     "grl_build_info",
 ]
@@ -430,6 +431,8 @@ def lib():
     L.grl_attention_bwd.restype = C.c_int
     L.grl_adamw_step.argtypes = [C.c_void_p, C.POINTER(GrlAdamWArgs)]
     L.grl_adamw_step.restype = C.c_int
+    L.grl_debug_dirty_lds.argtypes = [C.c_void_p]
+    L.grl_debug_dirty_lds.restype = C.c_int
     _lib = L
     return L
 
@@ -440,7 +443,16 @@ def check(code: int, what: str):
         raise RuntimeError(f"libgrl_hip: {what} failed: {kind}")
 
 
+_DIRTY_LDS = os.environ.get("GRL_DIRTY_LDS", "0") == "1"
+
+
 def stream_ptr():
+    """The current torch HIP stream as the `stream` argument of a C-ABI launch (every wrapper evaluates this right before its
+    call).  GRL_DIRTY_LDS=1 (debug): first fills the LDS of every CU with NaN bytes on that stream, so that the kernel about to be
+    launched cannot profit from what its predecessor left there (grl_debug_dirty_lds)."""
     import torch
 
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    s = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    if _DIRTY_LDS:
+        check(lib().grl_debug_dirty_lds(s), "grl_debug_dirty_lds")
+    return s

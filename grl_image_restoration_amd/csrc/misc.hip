@@ -114,5 +114,27 @@ extern "C" int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, floa
     return 0;
 }
 
+// Debug aid (GRL_DIRTY_LDS=1 in the Python wrappers calls it before every C-ABI launch): overwrites the LDS of every CU with
+// 0xFF bytes (fp32 / fp16 NaN).  LDS is not cleared between workgroups, so a kernel that reads a location it has not written sees
+// whatever the previous workgroup on that CU left there -- zeros or finite numbers most of the time, which hides the bug and makes
+// it depend on what ran before.  After this launch such a read yields NaN in the parity tests.
+namespace {
+__global__ __launch_bounds__(256) void dirty_lds_kernel(int words) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    volatile uint32_t* s = (volatile uint32_t*)smem;
+    for (int i = threadIdx.x; i < words; i += blockDim.x) s[i] = 0xFFFFFFFFu;
+    __syncthreads();
+}
+}  // namespace
+
+extern "C" int grl_debug_dirty_lds(void* stream) {
+    const int bytes = 160 * 1024;          // the whole LDS of a CU: one workgroup per CU at a time
+    hipError_t e = hipFuncSetAttribute((const void*)dirty_lds_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(dirty_lds_kernel, dim3(2048), dim3(256), bytes, (hipStream_t)stream, bytes / 4);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
 extern "C" int grl_abi_version(void) { return GRL_ABI_VERSION; }
 extern "C" const char* grl_build_info(void) { return "grl_hip gfx950 (MI355X) " __DATE__ " " __TIME__; }

@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 20
+#define GRL_ABI_VERSION 21
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -492,6 +492,11 @@ typedef struct GrlAdamWArgs {
 } GrlAdamWArgs;
 
 int grl_adamw_step(void* stream, const GrlAdamWArgs* args);
+
+/* Debug aid (ABI 21; no reference counterpart): fills the LDS of every CU with 0xFF bytes (fp32 / fp16 NaN) by a launch on
+ * `stream`.  LDS keeps what the previous workgroup left in it; a kernel that reads LDS it has not written is otherwise right or
+ * wrong depending on what ran before it.  The Python wrappers call this before every launch when GRL_DIRTY_LDS=1 (tests). */
+int grl_debug_dirty_lds(void* stream);
 
 /* Library self-description (used by the loader to refuse a stale build). */
 int grl_abi_version(void);

@@ -163,6 +163,11 @@ SEED_CASES = [   # tag, model, geometry, upscale, (h, w), task -- tests/test_gpu
     ("base_deblur", "base", "deblur", 1, (96, 192), "deblur"),
 ]
 SEED_PAIRS = [(11, 21), (12, 22)]
+# round 6: three more weight / data draws of the headline configuration, and one draw at the 256x256 bench shape
+EXTRA_SEED_CASES = [
+    (("base_sr4", "base", "sr_ckpt_df2", 4, (64, 64), "sr"), [(13, 23), (14, 24), (15, 25)]),
+    (("base_sr4_256", "base", "sr_ckpt_df2", 4, (256, 256), "sr"), [(11, 21)]),
+]
 
 
 def main_seeds():
@@ -172,8 +177,11 @@ def main_seeds():
     out_dir = os.path.join(ROOT, "tests", "golden", "seeds")
     os.makedirs(out_dir, exist_ok=True)
     from tests.util import product_shapes
-    for tag, model, geom, up, hw, task in SEED_CASES:
-        for wseed, dseed in SEED_PAIRS:
+    todo = [(c, SEED_PAIRS) for c in SEED_CASES] + EXTRA_SEED_CASES
+    for (tag, model, geom, up, hw, task), pairs in todo:
+        for wseed, dseed in pairs:
+            if os.path.isfile(os.path.join(out_dir, f"{tag}_{wseed}_{dseed}.npz")) and "--force" not in sys.argv:
+                continue
             cfg = make_config(model, geom, upscale=up, img_size=hw[0])
             sd = O.seeded_state_dict(product_shapes(cfg), wseed, logit_scale_mean=LN100)
             lq, _ = O.synthetic_pair(task, hw, up, batch=1, seed=dseed)

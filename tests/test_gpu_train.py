@@ -534,7 +534,12 @@ def test_graphed_train_step_follows_lr_schedule_and_resume():
     opt.param_groups[0]["lr"] = 2e-4
     step(lq, gt)
     w2 = snap()
-    assert bool(torch.isfinite(w2).all()), "non-finite weights after a replay"
+    if not bool(torch.isfinite(w2).all()):                # (diagnosis of round 5's order-dependent failure: say WHERE)
+        bad = lambda f: [k for k, p in m.named_parameters() if f(p) is not None and not bool(torch.isfinite(f(p)).all())]
+        bw, bg = bad(lambda p: p), bad(lambda p: p.grad)
+        bm = bad(lambda p: opt.state[p]["exp_avg"])
+        pytest.fail(f"non-finite weights after a replay: loss {float(step.loss)}; {len(bw)} weights, {len(bg)} gradients, {len(bm)} first moments; "
+                    f"gradients (forward order) first {bg[:5]} last {bg[-5:]}; weights first {bw[:5]}")
     assert float((w2 - w0).abs().max()) > 1e-5
     with torch.no_grad():
         y_b = m.eval()(lq)                                # no finish() in between: the plan must have been rebuilt from the new weights
