@@ -560,6 +560,17 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
     }
 }
 
+// Zero fill of a split launch's destination -- a KERNEL, not hipMemsetAsync: on this ROCm (7.0.2 runtime) a hipMemsetAsync captured
+// into a HIP graph is wrong from the second replay on (every 4th float keeps its old value: tools/probes/graph_memset_probe3.py,
+// profiles/r06_graph_memset_probe.txt; the kernel-only control is always right).  Round 5's split launches zeroed with the
+// memset, so a CAPTURED training step accumulated dQ / dK / dV onto stale values in a quarter of the entries -- finite most of
+// the time, NaN when the graph's private pool had received another process's leftovers: the order-dependent failure of
+// test_graphed_train_step_follows_lr_schedule_and_resume.
+__global__ __launch_bounds__(256) void zero_f32x4_kernel(float4* dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = float4{0.f, 0.f, 0.f, 0.f};
+}
+
 }  // namespace
 
 extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
@@ -600,8 +611,16 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         }
         return s < nchunks ? (s < 1 ? 1 : s) : (nchunks > 0 ? nchunks : 1);
     };
-    auto zero = [&](float* ptr, const GrlTokenGrid& g) {
-        return hipMemsetAsync(ptr, 0, (size_t)p.nh * p.B * g.Himg * g.Wimg * 32 * sizeof(float), st);
+    // (GRL_ZERO_MEMSET=1 restores round 5's hipMemsetAsync -- only so that tools/probes/attn_bwd_graph_memset.py can show the failure
+    // this replaced on the installed runtime; nothing else sets it)
+    const char* zm = getenv("GRL_ZERO_MEMSET");
+    const bool zero_by_memset = zm && zm[0] == '1';
+    auto zero = [&](float* ptr, const GrlTokenGrid& g) {          // (dense planes: 32 floats per token, 16-byte aligned rows)
+        const int64_t n4 = (int64_t)p.nh * p.B * g.Himg * g.Wimg * 8;
+        if (zero_by_memset) return hipMemsetAsync(ptr, 0, (size_t)n4 * 16, st);
+        if (((uintptr_t)ptr & 15) != 0) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(zero_f32x4_kernel, dim3((unsigned)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048)), dim3(256), 0, st, (float4*)ptr, n4);
+        return hipGetLastError();
     };
     {
         const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
