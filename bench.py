@@ -297,6 +297,13 @@ def run(args, rank, world, local_rank):
     dt, y = timed_steps(model, x, args.steps, world)
     assert torch.isfinite(y).all()
     precision_mode = model.precision   # (of the timed leg: `auto` is resolved per weight set, the other leg may differ)
+    cal = getattr(model, "calibration", None)
+    calibration = None
+    if cal:     # precision `auto` on the wide SR models: per-block choice by measurement (GRL._calibrated_plan)
+        calibration = {k: (float(f"{v:.3g}") if isinstance(v, float) else v) for k, v in cal.items() if k != "split_blocks"}
+        calibration["rule"] = ("a fixed smooth probe image through the all-split network and through the fp16-operand one; blocks move to split "
+                               "operands, costliest first, until max <= bar_max and rms <= bar_rms on the probe (tests: five weight draws of "
+                               "this configuration + one at this tile size hold 1e-3 against the float64 reference in this mode)")
 
     # ---- untimed passes (rank 0 measures; every rank runs the same launches so that the barriers match) ----
     groups = model.stream_groups(args.tiles)   # tile groups advancing on separate HIP streams (one launch = one group)
@@ -341,6 +348,32 @@ def run(args, rank, world, local_rank):
                  "logit_scales": "as initialised by the reference constructor (10 for every head)" if trained_regime else
                                  "exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at the clamp"}
 
+    # what the other precision modes cost on the timed leg's weights (same tiles, fewer steps): every contraction on split operands
+    # (`high`: 5e-6 from the float64 reference) and, when the calibration moved blocks, plain fp16 operands everywhere
+    precision_legs = None
+    if not args.no_precision_legs and args.config == 3 and world == 1:
+        with torch.no_grad():                      # the timed leg's logit scales again (the leg above swapped them)
+            gs = torch.Generator().manual_seed(7)
+            for (_, p_), v in zip(scale_params, init_scales):
+                p_.copy_((math.log(100.0) + 0.3 * torch.randn(p_.shape, generator=gs)).to(dev) if trained_regime else v)
+        precision_legs = {}
+        n_leg = max(2, min(args.steps, 6))
+        for name, env, arg in (("high", {}, "high"), ("fp16_operands_uncalibrated", {"GRL_CALIBRATE": "0"}, "auto")):
+            if name != "high" and not (cal and cal.get("split", 0) > 0):
+                continue
+            os.environ.update(env)
+            m2 = GRL(**cfg, precision=arg).eval().to(dev)
+            m2.load_state_dict(model.state_dict(), strict=True)
+            with torch.no_grad():
+                m2(x)
+            dt2, _ = timed_steps(m2, x, n_leg, 1)
+            precision_legs[name] = {"ms_per_step": round(dt2 / n_leg * 1e3, 3), "ratio_to_timed_leg": round(dt2 / n_leg / (dt / args.steps), 3),
+                                    "precision_mode": m2.precision, "steps": n_leg}
+            for k_ in env:
+                os.environ.pop(k_, None)
+            del m2
+        torch.cuda.empty_cache()
+
     # strong-scaling leg: one fixed tile list sharded over the ranks, stitched through the RCCL all-gather
     tiled = None
     if world > 1 and not args.no_tiled:
@@ -383,6 +416,7 @@ def run(args, rank, world, local_rank):
             "hr_megapixels_per_s": round(mp * scale * scale, 2),
             "parallelism": f"tile-sharded x{world}, no data-path collective",
             "precision_mode": precision_mode,
+            "precision_calibration": calibration,
         }
         if gflop_tile:
             conf.update(gflop_per_tile=gflop_tile, model_tflops=round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12, 2))
@@ -396,14 +430,17 @@ def run(args, rank, world, local_rank):
             "kernel": "attn_rows_kernel (cosine window / anchored-stripe attention, csrc/attention_rows.hip)" if args.config == 3 else
                       "attn_kernel (generic cosine window / anchored-stripe attention, csrc/attention.hip)",
             "bound": "mfma",
-            "achieved": excl.get("exclusive_achieved", round(ach, 2)),
+            # `achieved` / `frac`: the kernel's mean launch duration measured live in the step's own schedule (HIP events on the
+            # launching streams of a repeat of the timed region) -- with two tile groups on two streams a launch shares the GPU with
+            # the other group's kernels; `exclusive_*` below: the kernel alone on the GPU; `whole_network_frac`: the step's FLOPs
+            "whole_network_frac": round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4) if gflop_tile else None,
+            "achieved": round(ach, 2),
             "peak": PEAK_F16_TFLOPS,
             "unit": "TFLOP/s",
-            "frac": excl.get("exclusive_frac", round(ach / PEAK_F16_TFLOPS, 4)),
-            "frac_is": "exclusive (kernel alone on the GPU)" if excl else "concurrent (no exclusive pass: one stream group)",
+            "frac": round(ach / PEAK_F16_TFLOPS, 4),
+            "frac_is": "in the timed schedule (two tile groups on two HIP streams share the GPU)" if groups > 1 else "in the timed schedule (one stream)",
             "concurrent_achieved": round(ach, 2),
             "concurrent_frac": round(ach / PEAK_F16_TFLOPS, 4),
-            "whole_network_frac": round(gflop_tile * 1e9 * world * args.tiles * args.steps / dt / 1e12 / PEAK_F16_TFLOPS, 4) if gflop_tile else None,
             "logit_scale_regime": "checkpoint-like" if trained_regime else "random-init",
             "traffic": traffic,
             "traffic_source": "profiles/attention_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the round, "
@@ -437,6 +474,8 @@ def run(args, rank, world, local_rank):
         }
         if other:
             line["random_init_scales" if trained_regime else "trained_scales"] = other
+        if precision_legs:
+            line["precision_legs"] = precision_legs
         if tiled:
             line["tiled"] = tiled
         if training:
@@ -469,6 +508,7 @@ def main():
     ap.add_argument("--no-other-scales", "--no-trained-scales", dest="no_other_scales", action="store_true", help="skip the leg on the other logit-scale regime")
     ap.add_argument("--no-train-graph", action="store_true", help="training leg: eager steps instead of the captured HIP graph")
     ap.add_argument("--no-tiled", action="store_true")
+    ap.add_argument("--no-precision-legs", action="store_true", help="skip timing the other precision modes on the timed leg's weights")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-batch", type=int, default=8, help="64x64 LQ patches per GPU per training step")

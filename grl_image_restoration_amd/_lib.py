@@ -321,6 +321,7 @@ class GrlGemmTnArgs(_Strict):
         ("c", C.c_void_p),
         ("ldc", C.c_int64),
         ("c_tap_stride", C.c_int64),
+        ("c_fix", C.c_void_p),
     ]
 
 
@@ -333,6 +334,7 @@ class GrlAttnBwdArgs(_Strict):
         ("d_v", C.c_void_p),
         ("d_table", C.c_void_p),
         ("g_scale", C.c_float),
+        ("d_table_fix", C.c_void_p),
     ]
 
 

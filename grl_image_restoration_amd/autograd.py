@@ -205,9 +205,13 @@ def _leave_operand(x, xp):
 
 def _take_operand(x):
     slot, _HANDOVER.slot = getattr(_HANDOVER, "slot", None), None
-    if slot is not None and slot[:3] == (x.data_ptr(), x._version, tuple(x.shape)):
-        return slot[3]
-    return None
+    if slot is None:
+        return None
+    try:                                   # (fake / meta tensors -- torch.compile tracing -- have no storage address)
+        key = (x.data_ptr(), x._version, tuple(x.shape))
+    except (RuntimeError, NotImplementedError):
+        return None
+    return slot[3] if slot[:3] == key else None
 
 
 def _linear_operands(x, w, b):
@@ -237,18 +241,20 @@ def _(x, w, b):
 
 def _linear_setup(ctx, inputs, output):
     x, w, b = inputs
-    ctx.xp = _take_operand(x)
-    ctx.save_for_backward(x, w)
+    xp = _take_operand(x)
+    # the padded operand [x | 1 | 0] of the forward launch is all the backward needs of x: saved INSTEAD of x (both were
+    # kept, doubling the saved activation of every layer whose width is not a kernel width -- C = 180 in all GRL-Base blocks)
+    ctx.save_for_backward(xp if xp is not None else x, w)
+    ctx.x_shape, ctx.padded = tuple(x.shape), xp is not None
     ctx.has_b = b is not None
 
 
 def _linear_backward(ctx, dy):
-    x, w = ctx.saved_tensors
-    M, K = x.shape
+    xs, w = ctx.saved_tensors
+    M, K = ctx.x_shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
-    xp = ctx.xp if ctx.xp is not None else _padded(x.detach().float(), Kp, ones=True)
-    ctx.xp = None
+    xp = xs if ctx.padded else _padded(xs.detach().float(), Kp, ones=True)
     s = grad_scale(dy.device)
     dyp = _padded(dy.float(), Np)
     dx = dw = db = None
@@ -288,13 +294,14 @@ def _(x, w, b, B, H, W):
 
 def _conv_setup(ctx, inputs, output):
     x, w, b, B, H, W = inputs
-    ctx.xp = _take_operand(x)
-    ctx.save_for_backward(x, w)
+    xp = _take_operand(x)
+    ctx.save_for_backward(xp if xp is not None else x, w)      # (see _linear_setup)
+    ctx.padded = xp is not None
     ctx.bhw = (B, H, W)
 
 
 def _conv_backward(ctx, dy):
-    x, w = ctx.saved_tensors
+    xs, w = ctx.saved_tensors
     B, H, W = ctx.bhw
     Cout, Cin = w.shape[:2]
     CinP = (Cin + 31) // 32 * 32
@@ -310,8 +317,7 @@ def _conv_backward(ctx, dy):
     if ctx.needs_input_grad[1] or (want_b and CinP > Cin):
         n8 = (Cout + 7) // 8 * 8
         dyp = _padded(dy.float(), n8)
-        xp = ctx.xp if ctx.xp is not None else _padded(x.detach().float(), CinP, ones=True)
-        ctx.xp = None
+        xp = xs if ctx.padded else _padded(xs.detach().float(), CinP, ones=True)
         c = ops.gemm_tn(dyp, xp, n8, CinP, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s)      # [9, n8, CinP]
         if ctx.needs_input_grad[1]:
             dw = c[:, :Cout, :Cin].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()

@@ -117,8 +117,13 @@ __device__ __forceinline__ float wave_rol1(float v) {
 // the query one to the left; what leaves lane 0 re-enters at lane 63, and after 31 steps the spill has reached lane 33)
 // and add the next row.  Lane p ends with the whole diagonal  key - query = -p  (p < 32)  or  64 - p  (p > 32): one
 // conflict-free ds_add per tile instead of 16 two-way conflicting ones.
+// deterministic mode: a value of the g_scale-d domain added as 64-bit fixed point (integer atomics commute)
+__device__ __forceinline__ void fix_add(int64_t* dst, float v) {
+    atomicAdd((unsigned long long*)dst, (unsigned long long)(long long)__float2ll_rn(v * 4294967296.0f));
+}
+
 template <bool GHIST>
-__device__ __forceinline__ void diag_ring(const f32x16& dS, int lane, float* dtab, float* gtab, int ebase, float inv_g) {
+__device__ __forceinline__ void diag_ring(const f32x16& dS, int lane, float* dtab, float* gtab, int64_t* ftab, int ebase, float inv_g) {
     float z = 0.f;
 #pragma unroll
     for (int g = 3; g >= 0; --g) {
@@ -141,8 +146,10 @@ __device__ __forceinline__ void diag_ring(const f32x16& dS, int lane, float* dta
     }
     const int e = ebase - (lane < 32 ? lane : lane - 64);
     if (lane != 32) {
-        if constexpr (GHIST) unsafeAtomicAdd(gtab + e, z * inv_g);
-        else atomicAdd(&dtab[e], z);
+        if constexpr (GHIST) {
+            if (ftab) fix_add(ftab + e, z);
+            else unsafeAtomicAdd(gtab + e, z * inv_g);
+        } else atomicAdd(&dtab[e], z);
     }
 }
 
@@ -185,6 +192,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
     if constexpr (!GHIST)
         for (int i = tid; i < tpad; i += nthreads) dtab[i] = 0.f;
     float* gtab = a.d_table + (int64_t)head * p.tstride;
+    int64_t* ftab = a.d_table_fix ? a.d_table_fix + (int64_t)head * p.tstride : nullptr;
     const float inv_g = 1.0f / a.g_scale;
 
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
@@ -313,8 +321,10 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
                             const float pr = __builtin_amdgcn_exp2f(s - lse[t]);
                             dS[r] = LN2_F * pr * (dP[r] - Dq[t]);
                             if (!toeplitz && qvalid[t] && idk != 255) {
-                                if constexpr (GHIST) unsafeAtomicAdd(gtab + U[t] + kofs[r], dS[r] * inv_g);
-                                else atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
+                                if constexpr (GHIST) {
+                                    if (ftab) fix_add(ftab + U[t] + kofs[r], dS[r]);
+                                    else unsafeAtomicAdd(gtab + U[t] + kofs[r], dS[r] * inv_g);
+                                } else atomicAdd(&dtab[U[t] + kofs[r]], dS[r]);
                             }
                         } else {
                             if constexpr (MODE == 2) s += (r < 8 ? id_lo : id_hi) != idq[t] ? MASK_L2 : 0.f;
@@ -330,7 +340,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
                     // Nq % 64 == 32: the last wave's second tile repeats query Nq - 1 -- must not reach the table gradient
                     // (qvalid is wave-uniform per tile here: query tiles are whole 32-wide row segments)
                     if (toeplitz && __builtin_amdgcn_readfirstlane((int)qvalid[t]))
-                        diag_ring<GHIST>(dS, lane, dtab, gtab, __builtin_amdgcn_readfirstlane(U[t]) + kbase, inv_g);
+                        diag_ring<GHIST>(dS, lane, dtab, gtab, ftab, __builtin_amdgcn_readfirstlane(U[t]) + kbase, inv_g);
                 }
             };
             if (toeplitz && !border) tile(std::integral_constant<int, 1>{});
@@ -353,7 +363,10 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
         __syncthreads();
         for (int i = tid; i < p.trows; i += nthreads) {
             const float v = dtab[i];
-            if (v != 0.f) unsafeAtomicAdd(gtab + i, v * inv);
+            if (v != 0.f) {
+                if (ftab) fix_add(ftab + i, v);
+                else unsafeAtomicAdd(gtab + i, v * inv);
+            }
         }
     }
 }
@@ -598,7 +611,7 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
     };
     auto pick_splits = [&](int64_t grid, int streamed, bool ok) {
         const int nchunks = (streamed + KC - 1) / KC;
-        if (!ok || force_splits == 1) return 1;
+        if (!ok || force_splits == 1 || a.d_table_fix != nullptr) return 1;
         int s = 1;
         if (force_splits > 1) s = force_splits;
         else {
@@ -623,7 +636,8 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         return hipGetLastError();
     };
     {
-        const int waves = min(4, (Nq + QT * 32 - 1) / (QT * 32));
+        // (deterministic mode: one wave per workgroup -- the LDS histogram of the table gradient is then filled in program order)
+        const int waves = a.d_table_fix ? 1 : min(4, (Nq + QT * 32 - 1) / (QT * 32));
         const int blk = waves * QT * 32;
         int64_t grid = (int64_t)((Nq + blk - 1) / blk) * p.nh * p.nwx * p.nwy * p.B;
         const int splits = pick_splits(grid, Nk, dense(p.q));

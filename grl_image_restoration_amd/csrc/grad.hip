@@ -111,7 +111,13 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
         const int n = n0 + 32 * wn + mfma32_row(r, half);
-        if (n < p.N && k < p.K) unsafeAtomicAdd(c + (int64_t)n * p.ldc + k, acc[r] * p.out_scale);
+        if (n < p.N && k < p.K) {
+            if (p.c_fix != nullptr)     // deterministic: 64-bit fixed point, integer atomics (any order gives the same sum)
+                atomicAdd((unsigned long long*)(p.c_fix + (int64_t)tap * p.c_tap_stride + (int64_t)n * p.ldc + k),
+                          (unsigned long long)(long long)__float2ll_rn(acc[r] * 1073741824.0f));
+            else
+                unsafeAtomicAdd(c + (int64_t)n * p.ldc + k, acc[r] * p.out_scale);
+        }
     }
 }
 
@@ -158,7 +164,7 @@ extern "C" int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args) {
     if (p.b_dtype != GRL_DT_F32 && p.b_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
     if (p.taps != 1 && p.taps != 9) return GRL_ERR_BAD_ARG;
     if (p.taps == 9 && (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W) != 0)) return GRL_ERR_BAD_ARG;
-    if (p.splits <= 0 || p.splits * p.taps > 65535) return GRL_ERR_BAD_ARG;
+    if (p.splits <= 0 || p.splits * p.taps > 65535 || (p.c == nullptr && p.c_fix == nullptr)) return GRL_ERR_BAD_ARG;
     const dim3 grid((p.N + GT - 1) / GT, (p.K + GT - 1) / GT, p.splits * p.taps);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GRL_CHECK_LAUNCH();

@@ -43,6 +43,14 @@ def _poison(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def deterministic() -> bool:
+    """GRL_DETERMINISTIC=1: bit-identical training gradients run to run.  The cross-workgroup reductions of the backward pass --
+    the M slabs of the weight-gradient GEMM, the bias-table gradient of the attention backward -- are accumulated as 64-bit fixed
+    point with integer atomics (integer addition commutes, fp32 addition does not), and the attention backward does not split
+    its launches (grl_hip.h: GrlGemmTnArgs.c_fix, GrlAttnBwdArgs.d_table_fix).  Slower; read per call."""
+    return os.environ.get("GRL_DETERMINISTIC", "0") == "1"
+
+
 def empty(*shape, dtype, device) -> torch.Tensor:
     return _poison(torch.empty(*shape, dtype=dtype, device=device))
 
@@ -752,13 +760,17 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, 
     assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0] and a.shape[1] >= N and b.shape[1] >= K
     M = a.shape[0]
     H, W = hw if hw is not None else (0, 0)
-    c = torch.zeros(taps, N, K, dtype=torch.float32, device=a.device)
+    det = deterministic()
+    c = torch.zeros(taps, N, K, dtype=torch.int64 if det else torch.float32, device=a.device)
     tiles = ((N + 63) // 64) * ((K + 63) // 64) * taps
     splits = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))   # >= ~1000 workgroups, >= 256 rows each
     args = L.GrlGemmTnArgs(a=_ptr(a), lda=a.stride(0), b=_ptr(b), b_dtype=_KIND[b.dtype], ldb=b.stride(0), M=M, N=N, K=K, taps=taps,
-                           H=H, W=W, splits=splits, a_scale=a_scale, out_scale=out_scale, c=_ptr(c), ldc=K, c_tap_stride=N * K)
+                           H=H, W=W, splits=splits, a_scale=a_scale, out_scale=out_scale, c=None if det else _ptr(c), ldc=K,
+                           c_tap_stride=N * K, c_fix=_ptr(c) if det else None)
     with _timed("gemm_tn"):
         L.check(L.lib().grl_gemm_tn(L.stream_ptr(), C.byref(args)), "grl_gemm_tn")
+    if det:
+        return (c.double() * (out_scale * 2.0 ** -30)).float()
     return c
 
 
@@ -782,8 +794,12 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     d_k = empty(k.t.shape, dtype=torch.float32, device=q.t.device)
     d_v = empty(v.t.shape, dtype=torch.float32, device=q.t.device)
     d_table = torch.zeros_like(table)
+    fix = torch.zeros(table.shape, dtype=torch.int64, device=table.device) if deterministic() else None
     fwd = _attn_args(q, k, v, o, B, nh, table, masked, ones_col, head_dim, False, None, lse)
-    args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale)
+    args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale,
+                            d_table_fix=_ptr(fix))
     with _timed("attention_bwd"):
         L.check(L.lib().grl_attention_bwd(L.stream_ptr(), C.byref(args)), "grl_attention_bwd")
+    if fix is not None:
+        d_table = (fix.double() * (2.0 ** -32 / g_scale)).float()
     return d_q, d_k, d_v, d_table

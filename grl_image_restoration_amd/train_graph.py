@@ -88,6 +88,16 @@ class GraphedTrainStep:
         dist.all_reduce(flat, group=self._group)        # SUM; the 1 / world factor rides in FusedAdamW's grad_scale
         self.collectives += 1
 
+    def _grad_of(self, p):
+        """The flat gradient buffer of the data-parallel step is split by the optimizer's parameter list: every one of them must
+        have received a gradient (what DistributedDataParallel(find_unused_parameters=False), the reference's setting, requires
+        as well -- tools/trainer.py:135-142).  A frozen or unused parameter is named instead of failing on None."""
+        if p.grad is None:
+            name = next((k for k, q in self.model.named_parameters() if q is p), "<unnamed>")
+            raise RuntimeError(f"GraphedTrainStep (data parallel): parameter {name} received no gradient; pass the optimizer only "
+                               "parameters that take part in the step (requires_grad=False ones excluded)")
+        return p.grad
+
     def _flat_grad_views(self, flat):
         return [v.view_as(p) for v, p in zip(flat.split([p.numel() for p in self._params]), self._params)]
 
@@ -100,7 +110,7 @@ class GraphedTrainStep:
         side = torch.cuda.Stream(lq.device)
         side.wait_stream(cur)
         with torch.cuda.stream(side):             # (warm-up on a side stream, as torch.cuda.graph's recipe asks)
-            for _ in range(max(1, warmup)):
+            for _ in range(max(0, warmup)):       # (0: the caller has just run an eager step of its own -- _recalibrate)
                 self._eager_step()
         cur.wait_stream(side)
         torch.cuda.synchronize(lq.device)
@@ -118,7 +128,7 @@ class GraphedTrainStep:
             if self._group is None:
                 optimizer.step()
             else:                                 # graph A ends with the gradients gathered into one flat buffer
-                self._flat = torch.cat([p.grad.reshape(-1) for p in self._params])
+                self._flat = torch.cat([self._grad_of(p).reshape(-1) for p in self._params])
                 self._wire = self._flat.to(torch.bfloat16) if self._wire_bf16 else self._flat
         if self._group is not None:
             # graph B: the optimizer launch reads the (all-reduced) flat buffer -- p.grad become views of it, so its pointer table,
@@ -133,6 +143,7 @@ class GraphedTrainStep:
                 optimizer.step(grad_scale=1.0 / self._world)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(True)
         self._scale_at_capture = AG.last_grad_scale() if hasattr(AG, "last_grad_scale") else None
+        self._graph_grads = [p.grad for p in self._params]      # what replays write / the captured optimizer launch reads
 
     def _eager_step(self):
         self.optimizer.zero_grad(set_to_none=True)
@@ -141,7 +152,7 @@ class GraphedTrainStep:
         if self._group is None:
             self.optimizer.step()
             return loss
-        flat = torch.cat([p.grad.reshape(-1) for p in self._params])
+        flat = torch.cat([self._grad_of(p).reshape(-1) for p in self._params])
         wire = flat.to(torch.bfloat16) if self._wire_bf16 else flat
         self._all_reduce(wire)
         if self._wire_bf16:
@@ -158,7 +169,12 @@ class GraphedTrainStep:
         if gt.data_ptr() != self.gt.data_ptr():
             self.gt.copy_(gt, non_blocking=True)
         if self.recalibrate_every and self.steps and self.steps % self.recalibrate_every == 0:
-            self._recalibrate()
+            # the re-calibration step IS this batch's step (it used to be followed by a replay on the same batch -- two or
+            # three optimizer updates, and Adam's step count advanced as often, for one batch)
+            loss = self._recalibrate()
+            self.steps += 1
+            torch.autograd.graph.increment_version(self._params)
+            return loss
         self.optimizer.refresh_capture_hyper()          # lr / weight decay of the captured optimizer launch <- param_groups
         self.graph.replay()
         if self.graph_update is not None:
@@ -171,10 +187,11 @@ class GraphedTrainStep:
         return self.loss
 
     def _recalibrate(self):
-        """One eager step on the current batch measures the gradient operand scale afresh; when it moved by more than 2^4 from
-        the frozen one the step is captured again."""
+        """One EAGER step on the current batch -- it is that batch's optimizer step, its loss is returned -- measures the gradient
+        operand scale afresh; when it moved by more than 2^4 from the frozen one the step is captured again (without further
+        warm-up steps: nothing else updates the weights)."""
         self.optimizer.sync_step_from_device()
-        self._eager_step()
+        loss = self._eager_step().detach()
         new = AG.last_grad_scale() if hasattr(AG, "last_grad_scale") else None
         old = self._scale_at_capture
         again = bool(new and old and (new / old > 16.0 or old / new > 16.0))
@@ -184,7 +201,11 @@ class GraphedTrainStep:
             again = bool(flag.item() > 0)
         if again:
             torch.cuda.synchronize(self.lq.device)
-            self._capture(warmup=1)
+            self._capture(warmup=0)
+        else:                                        # replays keep writing the graph's own gradient tensors: p.grad shows those again
+            for p, g in zip(self._params, self._graph_grads):
+                p.grad = g
+        return loss
 
     def finish(self):
         """Brings the host-side optimizer state (step counts) up to date, e.g. before state_dict()."""

@@ -442,6 +442,10 @@ typedef struct GrlGemmTnArgs {
     float a_scale, out_scale;
     float* c;               /* [taps][N][ldc] fp32                                                  */
     int64_t ldc, c_tap_stride;
+    int64_t* c_fix;         /* optional (ABI 21): deterministic accumulation.  The slabs' partial tiles are added as 64-bit  */
+                            /* fixed point (2^30 x the a_scale-d sums; integer atomics commute, fp32 atomics do not) into     */
+                            /* this zeroed [taps][N][ldc] array instead of `c`; the caller converts:                          */
+                            /* c = c_fix * 2^-30 * out_scale.  Bit-identical results run to run.                              */
 } GrlGemmTnArgs;
 
 int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args);
@@ -461,6 +465,11 @@ typedef struct GrlAttnBwdArgs {
     float* d_v;
     float* d_table;
     float g_scale;
+    int64_t* d_table_fix;   /* optional (ABI 21): deterministic mode.  Non-null: no split launches (their partial dQ / dK / dV  */
+                            /* meet in fp32 atomics), the dq kernel runs one wave per workgroup (its LDS histogram is then      */
+                            /* filled in program order) and the workgroups' tables are added as 64-bit fixed point (2^32 x the   */
+                            /* g_scale-d sums) into this zeroed [nh, tstride] array instead of `d_table`; the caller converts:   */
+                            /* d_table = d_table_fix * 2^-32 / g_scale.  Bit-identical gradients run to run.                     */
 } GrlAttnBwdArgs;
 
 int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args);

@@ -54,7 +54,10 @@ def test_hip_forward_matches_reference_golden(name):
         allow = max(TOL_MAXABS, 2.0 * m64["max_abs_ref32_minus_fp64"])
         print(f"{name}: max|hip - reference_fp64| = {e64:.3e}  (reference fp32 vs fp64: {m64['max_abs_ref32_minus_fp64']:.3e}; allowance {allow:.1e})")
         assert e64 < allow, (e64, allow)
-        if m64["max_abs_ref32_minus_fp64"] > 1e-4:      # the fp32 reference output itself is only defined to this much
+        if m64["max_abs_ref32_minus_fp64"] > 1e-4:      # the fp32 reference output itself is only defined to this much:
+            # the full-resolution comparison with it stays, at the bar plus what the reference's own arithmetic contributes
+            # (this branch used to return after the strided lattice)
+            assert err < TOL_MAXABS + 2.0 * m64["max_abs_ref32_minus_fp64"], (err, m64["max_abs_ref32_minus_fp64"])
             return
     assert err < TOL_MAXABS, err
 
@@ -241,33 +244,42 @@ def test_graph_owns_its_plan_across_shapes_and_weight_updates():
         assert (yb - ya - 0.25).abs().max().item() < 1e-5
 
 
-# measured bars of the default precision (`auto`) at checkpoint-like scales on weight sets the policy was NOT tuned on
+# bars of the default precision (`auto`) at checkpoint-like scales on weight sets the policy was NOT tuned on
 SEED_BARS = {
-    # GRL-Base SR stays on fp16 operands (+ split conv_first / q-k-anchor projection) at every scale: 16-bit operands sit AT the 1e-3
-    # bar there, seed by seed -- 7.7e-4 (seed 0, the fixtures), 5.9e-4 (seed 12), 1.9e-3 (seed 11; rms 3.4e-4 against 1.5e-4; the CPU
-    # emulation of every rounding point gives 1.7e-3 with no dominant site: q.k 38 % of the variance, fc1 17 %, CAB conv2 11 %, fc2 9 %).
-    # `auto` is therefore asserted at 2.5e-3 max-abs / 4e-4 rms / 0.01 dB PSNR-Y for this model, and precision='high' (every
-    # contraction on split operands, x1.7 in time) at the full 1e-3 bar on the same weights -- README "Precision".
-    "base_sr4": dict(auto_max=2.5e-3, auto_rms=4e-4, also_high=True),
+    # GRL-Base SR: fp16 operands sit AT the 1e-3 bar at these scales, weight draw by weight draw (round 5: 7.7e-4 / 5.9e-4 / 1.9e-3;
+    # round 6, six draws: 7.3e-4, 1.6e-3, 6.3e-4, 5.5e-4, 8.3e-4, 1.2e-3).  Since round 6 `auto` MEASURES the weights it holds
+    # (GRL._calibrated_plan: a probe image through the all-split network and through the fp16-operand one) and moves the blocks whose
+    # fp16 rounding costs the most to split operands until the probe passes: 0-11 of 40 blocks on these draws, 3.6e-4 .. 8.0e-4
+    # against the float64 truth -- asserted at the north_star's 1e-3 like every fixture (the bar was 2.5e-3).
+    "base_sr4": dict(auto_max=1e-3, auto_rms=2e-4, also_high=True),
+    "base_sr4_256": dict(auto_max=1e-3, auto_rms=2e-4, also_high=False),   # the bench shape: one 256x256 tile, 3 M outputs
     "small_dn": dict(auto_max=1e-3, auto_rms=1e-3, also_high=False),       # (`auto` already resolves to `high` at these scales)
     "base_deblur": dict(auto_max=1e-3, auto_rms=1e-3, also_high=False),
 }
 
 
-@pytest.mark.parametrize("tag,model,geom,up,hw,task", [
-    ("base_sr4", "base", "sr_ckpt_df2", 4, (64, 64), "sr"),          # BASELINE configs[2] geometry
-    ("small_dn", "small", "dn_df4", 1, (128, 128), "dn"),            # BASELINE configs[1]
-    ("base_deblur", "base", "deblur", 1, (96, 192), "deblur"),       # BASELINE configs[3] geometry (window 12, stripes 48x96, anchors /4)
-], ids=["base_sr4", "small_dn", "base_deblur"])
-@pytest.mark.parametrize("seeds", [(11, 21), (12, 22)], ids=["seeds11", "seeds12"])
-def test_second_seeds_at_clamp_scales_vs_pinned_oracle(tag, model, geom, up, hw, task, seeds):
-    """VERDICT r4 #4b: every fixture uses weight seed 0 / data seed 1 and the precision policy was tuned on them.  Two further
-    (weight, data) seed pairs per BASELINE configuration, logit scales drawn around ln 100 (about half of the heads at the clamp),
-    against the pinned CPU oracle (pinned to the unmodified reference within 1.2e-6 in fp32; run in float64 here)."""
+_SEED_CASES = {
+    "base_sr4": ("base", "sr_ckpt_df2", 4, (64, 64), "sr"),          # BASELINE configs[2] geometry
+    "base_sr4_256": ("base", "sr_ckpt_df2", 4, (256, 256), "sr"),    # ... at the bench's tile size
+    "small_dn": ("small", "dn_df4", 1, (128, 128), "dn"),            # BASELINE configs[1]
+    "base_deblur": ("base", "deblur", 1, (96, 192), "deblur"),       # BASELINE configs[3] geometry (window 12, stripes 48x96, anchors /4)
+}
+_SEED_RUNS = ([("base_sr4", (w, w + 10)) for w in (11, 12, 13, 14, 15)] + [("base_sr4_256", (11, 21))] +
+              [(t, sd) for t in ("small_dn", "base_deblur") for sd in ((11, 21), (12, 22))])
+
+
+@pytest.mark.parametrize("tag,seeds", _SEED_RUNS, ids=[f"{t}-seeds{sd[0]}" for t, sd in _SEED_RUNS])
+def test_second_seeds_at_clamp_scales_vs_pinned_oracle(tag, seeds):
+    """VERDICT r4 #4b / r5 #3: every fixture uses weight seed 0 / data seed 1 and the precision policy was tuned on them.  Further
+    (weight, data) seed pairs per BASELINE configuration -- five for the headline one, GRL-Base x4 SR, plus one of them at the
+    256x256 bench shape -- with logit scales drawn around ln 100 (about half of the heads at the clamp), against the pinned CPU
+    oracle (pinned to the unmodified reference within 1.2e-6 in fp32; run in float64 here).  All at the north_star's 1e-3, in the
+    default mode (`auto`) -- the mode bench.py times."""
     import math
 
     from grl_image_restoration_amd import GRL, make_config
 
+    model, geom, up, hw, task = _SEED_CASES[tag]
     wseed, dseed = seeds
     bars = SEED_BARS[tag]
     cfg = make_config(model, geom, upscale=up, img_size=hw[0])
@@ -292,7 +304,10 @@ def test_second_seeds_at_clamp_scales_vs_pinned_oracle(tag, model, geom, up, hw,
         got = m(lq.to("cuda:0")).double().cpu()
     err = (got - want).abs().max().item()
     rms = (got - want).pow(2).mean().sqrt().item()
-    print(f"{model} {geom} seeds {seeds} [{m.precision}]: max|hip - oracle_fp64| = {err:.3e}  rms = {rms:.3e}")
+    cal = getattr(m, "calibration", None) or {}
+    print(f"{model} {geom} {hw} seeds {seeds} [{m.precision}]: max|hip - oracle_fp64| = {err:.3e}  rms = {rms:.3e}"
+          + (f"  (calibration: fp16 operands alone {cal['fast_max']:.2e} / rms {cal['fast_rms']:.2e} on the probe; "
+             f"{cal['split']} of {cal['blocks']} blocks split -> {cal.get('probe_max', 0):.2e} / {cal.get('probe_rms', 0):.2e})" if "fast_max" in cal else ""))
     assert err < bars["auto_max"] and rms < bars["auto_rms"], (err, rms)
     if up > 1:
         gt = gt[..., : hw[0] * up, : hw[1] * up]
