@@ -29,6 +29,12 @@
 
 namespace {
 
+// kernel argument block: GrlAttnBwdArgs + what the host derives per launch
+struct GrlAttnBwdLaunch : GrlAttnBwdArgs {
+    int32_t tab_window;      // floats of a table window in attn_dq_kernel's LDS (table and histogram)
+    int32_t tab_window_kv;   // ... in attn_dkv_kernel's
+};
+
 constexpr int QT = 2;            // tiles (32 queries resp. keys) per wave
 constexpr int KC = 128;          // streamed rows per LDS chunk
 constexpr int TROW = KC * 2 + 8; // transposed staging: row stride in bytes
@@ -117,6 +123,31 @@ __device__ __forceinline__ float wave_rol1(float v) {
 // the query one to the left; what leaves lane 0 re-enters at lane 63, and after 31 steps the spill has reached lane 33)
 // and add the next row.  Lane p ends with the whole diagonal  key - query = -p  (p < 32)  or  64 - p  (p > 32): one
 // conflict-free ds_add per tile instead of 16 two-way conflicting ones.
+// First (4-aligned) reversed table entry the queries n0..n1 of a window can touch (attn_dq_kernel), and the same for the keys
+// n0..n1 in attn_dkv_kernel; window_floats: an upper bound of the entries from there, for rows_spanned query (key) rows.
+__host__ __device__ inline int dq_window_lo(const GrlAttnArgs& p, int n0, int n1, int D) {
+    const int hqb = n1 / p.q.ww;
+    (void)n0;
+    const int lo = p.trows - 1 - ((hqb + p.k.wh - 1) * D + (p.q.ww - 1) + (p.k.ww - 1));
+    return lo < 0 ? 0 : lo & ~3;
+}
+__host__ __device__ inline int dkv_window_lo(const GrlAttnArgs& p, int n0, int n1, int D) {
+    const int hka = n0 / p.k.ww;
+    (void)n1;
+    const int lo = p.trows - 1 - ((p.k.wh - 1 - hka) * D + (p.k.ww - 1)) - ((p.q.wh - 1) * D + (p.q.ww - 1));
+    return lo < 0 ? 0 : lo & ~3;
+}
+// floats of LDS that hold any workgroup's window: `blk` consecutive tokens of a window `ww` wide span at most
+// (blk - 1) / ww + 2 rows (one less when rows divide the block), against `other_h` rows of the other side
+inline int window_floats(int blk, int n, int ww, int wh, int other_h, int D, int trows) {
+    int rows = (blk % ww == 0) ? blk / ww : (blk - 1) / ww + 2;
+    if (rows > wh) rows = wh;
+    (void)n;
+    const int w = ((rows + other_h - 1) * D + D + 3 + 3) & ~3;
+    const int full = (trows + 3) & ~3;
+    return w < full ? w : full;
+}
+
 // deterministic mode: a value of the g_scale-d domain added as 64-bit fixed point (integer atomics commute)
 __device__ __forceinline__ void fix_add(int64_t* dst, float v) {
     atomicAdd((unsigned long long*)dst, (unsigned long long)(long long)__float2ll_rn(v * 4294967296.0f));
@@ -162,7 +193,7 @@ template <bool GHIST>
 // ``splits`` > 1: the key loop is cut into that many parts, one workgroup each, and dQ is accumulated with atomics into a zeroed
 // destination -- for launches with fewer workgroups than CUs (anchors -> stripe tokens at training batch sizes: 96 workgroups
 // streaming 4096 keys each).
-__global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int splits) {
+__global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdLaunch a, int splits) {
     const GrlAttnArgs& p = a.fwd;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -178,7 +209,13 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
     const int wy = bid % p.nwy;
     const int b = bid / p.nwy;
     const int D = p.q.ww + p.k.ww - 1;
-    const int tpad = (p.trows + 3) & ~3;
+    // Table WINDOW of this workgroup (round 6): its queries span the rows hqa..hqb of the query window, so the (reversed) entries it
+    // can touch -- trows-1 - [(hq - hk + KH-1) * D + (wq - wk + KW-1)] over all keys -- are the contiguous range
+    // [trows-1 - (hqb + KH-1) * D - (QW + KW - 2), trows-1 - hqa * D]: (hqb - hqa + KH) * D entries instead of the whole table
+    // (stripe tokens -> anchors at 64x64 / 32x32: 3 325 of 9 025).  Table and histogram in LDS shrink from 2 x 36 KB to 2 x 13 KB:
+    // three workgroups per CU instead of one.
+    const int wlo = dq_window_lo(p, qs * qblk, min(Nq, (qs + 1) * qblk) - 1, D);
+    const int tpad = a.tab_window;                     // floats per LDS copy (host: the largest window of the launch, multiple of 4)
 
     float* tab = (float*)smem;                         // tpad
     float* dtab = tab + tpad;                          // tpad (histogram; absent with GHIST)
@@ -188,11 +225,12 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
     int* koff = (int*)(Kt + 32 * TROW);                // KC
     unsigned char* kreg = (unsigned char*)(koff + KC); // KC
 
-    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
+    const int wn = min(tpad, ((p.trows + 3) & ~3) - wlo);              // entries of the window that exist (wlo is a multiple of 4)
+    load_table(tab, p.table + (int64_t)head * p.tstride + wlo, wn, tid, nthreads);
     if constexpr (!GHIST)
         for (int i = tid; i < tpad; i += nthreads) dtab[i] = 0.f;
-    float* gtab = a.d_table + (int64_t)head * p.tstride;
-    int64_t* ftab = a.d_table_fix ? a.d_table_fix + (int64_t)head * p.tstride : nullptr;
+    float* gtab = a.d_table + (int64_t)head * p.tstride + wlo;         // (window-relative like tab / dtab)
+    int64_t* ftab = a.d_table_fix ? a.d_table_fix + (int64_t)head * p.tstride + wlo : nullptr;
     const float inv_g = 1.0f / a.g_scale;
 
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
@@ -213,7 +251,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
         if (!qvalid[t]) n = Nq - 1;
         locate(p.q, b, wy, wx, n, qrow[t], idq[t]);
         const int hq = n / p.q.ww, wq = n - hq * p.q.ww;
-        U[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1));
+        U[t] = p.trows - 1 - (hq * D + wq + (p.k.wh - 1) * D + (p.k.ww - 1)) - wlo;     // window-relative
         qf[t][0] = load_f16x8(p.q, qrow[t], head, half);
         qf[t][1] = load_f16x8(p.q, qrow[t], head, 2 + half);
         // slot 31 of q carries the forward kernel's running offset in registers only: in memory it is a pad column (0)
@@ -361,7 +399,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
     }
     if constexpr (!GHIST) {
         __syncthreads();
-        for (int i = tid; i < p.trows; i += nthreads) {
+        for (int i = tid; i < wn; i += nthreads) {
             const float v = dtab[i];
             if (v != 0.f) {
                 if (ftab) fix_add(ftab + i, v);
@@ -374,7 +412,7 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdArgs a, int spli
 // ------------------------------------------------------------------------------------------------
 // dk + dv
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int splits) {
+__global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdLaunch a, int splits) {
     const GrlAttnArgs& p = a.fwd;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x;
@@ -390,7 +428,9 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
     const int wy = bid % p.nwy;
     const int b = bid / p.nwy;
     const int D = p.q.ww + p.k.ww - 1;
-    const int tpad = (p.trows + 3) & ~3;
+    // table window of this workgroup's keys (see attn_dq_kernel): entries Uk - (hq * D + wq) over all queries
+    const int wlo = dkv_window_lo(p, ks * kblk, min(Nk, (ks + 1) * kblk) - 1, D);
+    const int tpad = a.tab_window_kv;
 
     float* tab = (float*)smem;                         // tpad
     char* Qs = (char*)(tab + tpad);                    // KC x 64 B   (rows = queries)
@@ -402,7 +442,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
     int* qoff = (int*)(qD + KC);                       // KC
     unsigned char* qreg = (unsigned char*)(qoff + KC); // KC
 
-    load_table(tab, p.table + (int64_t)head * p.tstride, p.trows, tid, nthreads);
+    load_table(tab, p.table + (int64_t)head * p.tstride + wlo, min(tpad, ((p.trows + 3) & ~3) - wlo), tid, nthreads);
 
     const bool border = p.masked && ((p.q.shy > 0 && wy == p.nwy - 1) || (p.q.shx > 0 && wx == p.nwx - 1));
 
@@ -424,7 +464,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdArgs a, int 
         locate(p.k, b, wy, wx, n, krow[t], idk[t]);
         const int hk = n / p.k.ww, wk = n - hk * p.k.ww;
         // reversed table entry of (query (hq, wq), key (hk, wk)) = trows-1 - [(hq-hk+KH-1)*D + (wq-wk+KW-1)] = Uk - (hq*D + wq)
-        Uk[t] = p.trows - 1 - ((p.k.wh - 1 - hk) * D + (p.k.ww - 1 - wk));
+        Uk[t] = p.trows - 1 - ((p.k.wh - 1 - hk) * D + (p.k.ww - 1 - wk)) - wlo;       // window-relative
         kfb[t][0] = load_f16x8(p.k, krow[t], head, half);
         kfb[t][1] = load_f16x8(p.k, krow[t], head, 2 + half);
         if (half && p.head_dim <= 30) kfb[t][1][7] = (f16)0.f;   // slot 31 of k holds 1.0 for the forward kernel's offset: not part of the logit
@@ -600,7 +640,10 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         (p.o.col0 % 8) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 8))
         return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
-    const size_t tpad = (size_t)((p.trows + 3) & ~3) * 4;
+    GrlAttnBwdLaunch a_l;                               // the caller's arguments + the table-window sizes of the two launches
+    a_l.fwd = a.fwd; a_l.d_o = a.d_o; a_l.d_q = a.d_q; a_l.d_k = a.d_k; a_l.d_v = a.d_v; a_l.d_table = a.d_table; a_l.g_scale = a.g_scale;
+    a_l.d_table_fix = a.d_table_fix; a_l.tab_window = 0; a_l.tab_window_kv = 0;
+    const int Dw = p.q.ww + p.k.ww - 1;
     // Split launches (see attn_dq_kernel): when a launch has fewer workgroups than the chip has CUs and a long streamed dimension,
     // cut that dimension over several workgroups that accumulate with atomics.  Needs a destination this function can zero: dense
     // head planes [nh][tokens][32] (what the training path passes).  GRL_ATTN_BWD_SPLITS=1 disables, =n forces n parts on every launch, =-n caps the automatic choice at n (timing experiments).
@@ -646,6 +689,8 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
             if (e != hipSuccess) return (int)e;
             grid *= splits;
         }
+        a_l.tab_window = window_floats(blk, Nq, p.q.ww, p.q.wh, p.k.wh, Dw, p.trows);
+        const size_t tpad = (size_t)a_l.tab_window * 4;
         const size_t rest = 2 * (size_t)KC * 64 + 32 * (size_t)TROW + KC * 4 + KC;
         const bool ghist = 2 * tpad + rest > 160 * 1024;
         const size_t lds = (ghist ? 1 : 2) * tpad + rest;
@@ -653,7 +698,7 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
         auto kfn = ghist ? attn_dq_kernel<true> : attn_dq_kernel<false>;
         hipError_t e = hipFuncSetAttribute((const void*)kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(waves * 64), lds, st, a, splits);
+        hipLaunchKernelGGL(kfn, dim3((int)grid), dim3(waves * 64), lds, st, a_l, splits);
         GRL_CHECK_LAUNCH();
     }
     {
@@ -667,11 +712,13 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
             if (e != hipSuccess) return (int)e;
             grid *= splits;
         }
+        a_l.tab_window_kv = window_floats(blk, Nk, p.k.ww, p.k.wh, p.q.wh, Dw, p.trows);
+        const size_t tpad = (size_t)a_l.tab_window_kv * 4;
         const size_t lds = tpad + 2 * (size_t)KC * 64 + 2 * 32 * (size_t)TROW + KC * 4 * 3 + KC;
         if (grid > 0x7fffffff || lds > 160 * 1024) return GRL_ERR_UNSUPPORTED;
         hipError_t e = hipFuncSetAttribute((const void*)attn_dkv_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
-        hipLaunchKernelGGL(attn_dkv_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a, splits);
+        hipLaunchKernelGGL(attn_dkv_kernel, dim3((int)grid), dim3(waves * 64), lds, st, a_l, splits);
         GRL_CHECK_LAUNCH();
     }
     return 0;
