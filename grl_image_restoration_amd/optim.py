@@ -4,7 +4,8 @@ The reference trains GRL with ``torch.optim.AdamW`` (config/optimizer/adamw.yaml
 otherwise; built in engines/base.py:451-470) over 1390 parameter tensors; a per-tensor update is host-launch bound.  ``FusedAdamW`` performs the
 identical update (decoupled weight decay, bias correction as in torch.optim.AdamW, no amsgrad) for ALL tensors of a
 parameter group in ONE launch of ``grl_adamw_step`` (csrc/grad.hip): a host-built list of 4096-element chunks, pointer tables
-in device memory.  fp32 parameters on the GPU only -- there is no CPU path.
+in device memory.  fp32 parameters on the GPU; CPU parameters take the same update as plain torch arithmetic (``_step_cpu``: like the
+model's composite path it exists so that a module built without a GPU steps instead of raising -- never reached by GPU tensors).
 """
 import ctypes as C
 from typing import Iterable
@@ -155,6 +156,28 @@ class FusedAdamW(torch.optim.Optimizer):
                     if p in self.state and "step" in self.state[p]:
                         self.state[p]["step"] = n
 
+    def _step_cpu(self, group, plist, grad_scale):
+        """torch.optim.AdamW's single-tensor update on CPU tensors (decoupled weight decay, bias correction), gradients multiplied by
+        ``grad_scale`` first.  Exists for the same reason as the model's composite path (composite.py): a module built without a GPU
+        -- the gloo tests of the data-parallel step, a unit test of a surrounding engine -- steps instead of raising.  Never reached
+        by GPU parameters; nothing here is timed or claimed as MI355X work."""
+        b1, b2 = group["betas"]
+        lr, wd, eps = group["lr"], group["weight_decay"], group["eps"]
+        for p in plist:
+            s = self.state[p]
+            if not s:
+                s["step"] = 0
+                s["exp_avg"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+                s["exp_avg_sq"] = torch.zeros_like(p, memory_format=torch.contiguous_format)
+            s["step"] = int(s["step"]) + 1
+            g = p.grad * grad_scale if grad_scale != 1.0 else p.grad
+            p.mul_(1.0 - lr * wd)
+            s["exp_avg"].lerp_(g, 1.0 - b1)
+            s["exp_avg_sq"].mul_(b2).addcmul_(g, g, value=1.0 - b2)
+            bc1, bc2s = 1.0 - b1 ** s["step"], (1.0 - b2 ** s["step"]) ** 0.5
+            p.addcdiv_(s["exp_avg"], (s["exp_avg_sq"].sqrt() / bc2s).add_(eps), value=-lr / bc1)
+        torch.autograd.graph.increment_version(plist)
+
     @torch.no_grad()
     def step(self, closure=None, grad_scale: float = 1.0):
         loss = None
@@ -166,10 +189,13 @@ class FusedAdamW(torch.optim.Optimizer):
             plist = [p for p in group["params"] if p.grad is not None]
             if not plist:
                 continue
+            if all(not p.is_cuda for p in plist):       # CPU tensors: the same update as plain torch arithmetic (module docstring)
+                self._step_cpu(group, plist, grad_scale)
+                continue
             for p in plist:
                 if (not p.is_cuda or p.dtype != torch.float32 or not p.is_contiguous() or p.grad.dtype != torch.float32
                         or not p.grad.is_contiguous()):
-                    raise RuntimeError("FusedAdamW: fp32 contiguous GPU parameters only (there is no CPU path)")
+                    raise RuntimeError("FusedAdamW: fp32 contiguous GPU parameters only (a group is either all on the GPU or all on the CPU)")
                 s = self.state[p]
                 if not s:
                     s["step"] = 0

@@ -103,6 +103,16 @@ class GraphedTrainStep:
 
     def _capture(self, warmup):
         model, optimizer, lq = self.model, self.optimizer, self.lq
+        if not lq.is_cuda:
+            # CPU tensors: no HIP graph to capture.  The step keeps its SHAPE -- [zero_grad, forward, loss, backward, flat gradient
+            # buffer] -> all-reduce -> [optimizer on the averaged flat buffer] -- and runs eagerly on the model's composite torch
+            # path (composite.py) and FusedAdamW's CPU arithmetic: what the gloo tests of the data-parallel plumbing use
+            # (tests/test_train_graph_gloo.py, world sizes 2 and 8).  Nothing of it is MI355X work.
+            for _ in range(max(0, warmup)):
+                self._eager_step()
+            self.graph = self.graph_update = None
+            self._scale_at_capture, self._graph_grads = None, None
+            return
         # (the warm-up steps run on a side stream, the capture on the graph's own: the AccumulateGrad nodes of the parameters move
         # between streams by design here -- the warning is silenced for the capture only and restored afterwards)
         torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
@@ -168,6 +178,10 @@ class GraphedTrainStep:
             self.lq.copy_(lq, non_blocking=True)
         if gt.data_ptr() != self.gt.data_ptr():
             self.gt.copy_(gt, non_blocking=True)
+        if self.graph is None:                          # CPU tensors (see _capture)
+            self.loss = self._eager_step().detach()
+            self.steps += 1
+            return self.loss
         if self.recalibrate_every and self.steps and self.steps % self.recalibrate_every == 0:
             # the re-calibration step IS this batch's step (it used to be followed by a replay on the same batch -- two or
             # three optimizer updates, and Adam's step count advanced as often, for one batch)
