@@ -120,6 +120,47 @@ def cpu_baseline(cfg, side):
     }
 
 
+def measure_attention_traffic(tiles):
+    """HBM bytes per attention launch from the PMC counters, measured in THIS run: two rocprofv3 passes
+    (--pmc FETCH_SIZE, --pmc WRITE_SIZE: separate passes, --kernel-trace only, as the MI355X guide's HBM section prescribes) over the
+    per-kernel micro-benchmark (tools/bench_kernels.py: the three attention launches of one block on `tiles` tiles of the bench's
+    shape).  Units: KiB; FETCH_SIZE doubled on gfx950 (the guide's correction for 16-B-per-lane streaming loads).  None when
+    rocprofv3 is not on the box or a pass fails -- the caller then quotes the stored figure of profiles/attention_traffic.json."""
+    import shutil
+    import sqlite3
+    import subprocess
+    import tempfile
+
+    if shutil.which("rocprofv3") is None:
+        return None
+    got = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = tempfile.mkdtemp(prefix="grl_pmc_", dir="/tmp")
+            cmd = ["rocprofv3", "--kernel-trace", "--pmc", counter, "-d", d, "-o", "r", "--", sys.executable,
+                   os.path.join(ROOT, "tools", "bench_kernels.py"), "--tiles", str(tiles), "--iters", "2", "--only", "attn_window,attn_a2w,attn_w2a"]
+            subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL,
+                           timeout=240, check=True)
+            dbs = [os.path.join(r, f) for r, _, fs in os.walk(d) for f in fs if f.endswith(".db")]
+            cur = sqlite3.connect(dbs[0]).cursor()
+            tabs = [r[0] for r in cur.execute("select name from sqlite_master where type='table'")]
+            pick = lambda pre: [t for t in tabs if t.startswith(pre)][0]
+            ev, info, kd, ks = pick("rocpd_pmc_event"), pick("rocpd_info_pmc"), pick("rocpd_kernel_dispatch"), pick("rocpd_info_kernel_symbol")
+            cols = [r[1] for r in cur.execute(f"pragma table_info({kd})")]
+            key = "event_id" if "event_id" in cols else "id"
+            rows = cur.execute(
+                f"select s.kernel_name, count(*), avg(v) from (select e.event_id as eid, e.pmc_id as pid, sum(e.value) as v from {ev} e "
+                f"group by e.event_id, e.pmc_id) x join {info} i on x.pid = i.id join {kd} d on d.{key} = x.eid join {ks} s on d.kernel_id = s.id "
+                f"where i.name = '{counter}' and s.kernel_name like '%attn_rows_kernel%' group by s.kernel_name").fetchall()
+            n = sum(r[1] for r in rows)
+            got[counter] = sum(r[1] * r[2] for r in rows) / n
+            shutil.rmtree(d, ignore_errors=True)
+        return {"bytes_per_launch": int((2.0 * got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024), "FETCH_SIZE_KiB_mean": round(got["FETCH_SIZE"], 1),
+                "WRITE_SIZE_KiB_mean": round(got["WRITE_SIZE"], 1), "tiles_per_launch": tiles}
+    except Exception as e:      # noqa: BLE001 -- a missing counter, a changed schema, a timeout: report the stored figure instead
+        return {"error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def timed_steps(model, x, steps, world):
     with torch.no_grad():
         torch.cuda.synchronize()
@@ -403,11 +444,19 @@ def run(args, rank, world, local_rank):
         att_ms = sum(att) / max(len(att), 1)
         fl = attention_flops_per_launch(cfg, args.tiles // groups, (side, side))
         ach = fl / (att_ms * 1e-3) / 1e12 if att_ms > 0 else 0.0
-        traffic = None
+        traffic, traffic_source = None, None
         tpath = os.path.join(ROOT, "profiles", "attention_traffic.json")
-        if args.config == 3 and os.path.isfile(tpath):
+        live = measure_attention_traffic(args.tiles // groups) if (args.config == 3 and world == 1 and not args.no_traffic) else None
+        if live and "bytes_per_launch" in live:
+            traffic = live["bytes_per_launch"]
+            traffic_source = (f"measured in this run: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE (separate passes) over tools/bench_kernels.py, "
+                              f"{live['tiles_per_launch']} tiles per launch, mean of the three attention launches of a block; KiB units, FETCH_SIZE x2 (gfx950): "
+                              f"FETCH {live['FETCH_SIZE_KiB_mean']} KiB, WRITE {live['WRITE_SIZE_KiB_mean']} KiB")
+        elif args.config == 3 and os.path.isfile(tpath):
             traffic = json.load(open(tpath)).get("hbm_bytes_per_tile")  # PMC pass (profiles/), per tile
             traffic = traffic * (args.tiles // groups) if traffic else None
+            traffic_source = ("profiles/attention_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of an earlier profile run, not measured in "
+                              "this run" + (f": {live['error']}" if live and "error" in live else ": rocprofv3 not available or --no-traffic") + ")")
         conf = {
             "workload": label + (", random-init weights with checkpoint-like logit scales exp(min(ln 100 + 0.3 N(0,1), ln 100)): about half of the heads at "
                                  "the clamp, the regime of every released checkpoint" if trained_regime else ", random-init weights and logit scales (10)"),
@@ -443,8 +492,8 @@ def run(args, rank, world, local_rank):
             "concurrent_frac": round(ach / PEAK_F16_TFLOPS, 4),
             "logit_scale_regime": "checkpoint-like" if trained_regime else "random-init",
             "traffic": traffic,
-            "traffic_source": "profiles/attention_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of the round, "
-                              "not measured in this run)" if traffic else None,
+            "traffic_source": traffic_source,
+            "algorithmic_bytes_per_launch": int(37.65e6 * (args.tiles // groups)) if args.config == 3 else None,
             "launches_timed": len(att),
             "mean_launch_ms": round(att_ms, 4),
             "flops_per_launch": fl,
@@ -509,6 +558,7 @@ def main():
     ap.add_argument("--no-train-graph", action="store_true", help="training leg: eager steps instead of the captured HIP graph")
     ap.add_argument("--no-tiled", action="store_true")
     ap.add_argument("--no-precision-legs", action="store_true", help="skip timing the other precision modes on the timed leg's weights")
+    ap.add_argument("--no-traffic", action="store_true", help="do not run the two rocprofv3 --pmc passes that measure roofline.traffic")
     ap.add_argument("--no-train", action="store_true")
     ap.add_argument("--train-steps", type=int, default=3)
     ap.add_argument("--train-batch", type=int, default=8, help="64x64 LQ patches per GPU per training step")

@@ -12,9 +12,9 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p $OUT
 cd /tmp
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-other-scales > $OUT/prof_bench_stdout.txt 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/prof_kt -o r -- python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-other-scales --no-precision-legs --no-traffic > $OUT/prof_bench_stdout.txt 2>&1
 DB=$(find /tmp/prof_kt -name "*.db" | head -1)
-echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-other-scales" > $OUT/kernel_stats.txt
+echo "# rocprofv3 --kernel-trace --stats -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-train --no-other-scales --no-precision-legs --no-traffic" > $OUT/kernel_stats.txt
 tail -1 $OUT/prof_bench_stdout.txt >> $OUT/kernel_stats.txt
 python $ROOT/tools/rocprof_summary.py "$DB" 30 >> $OUT/kernel_stats.txt 2>&1
 KERN=attn_window,attn_a2w,attn_w2a,qkv_anchor,block_tail_regs,cab_conv1,cab_conv2_regs,se,stage_conv
@@ -39,7 +39,7 @@ for c in "8 3" "16 2" "4 4"; do
   set -- $c
   { python tools/step_breakdown.py $1 $2; python tools/step_breakdown.py $1 $2 --trained; } 2>&1 | grep -v amdgpu.ids > $OUT/step_breakdown_config$2.txt
 done
-python bench.py --config 2 --tiles 16 --no-cpu-baseline > $OUT/bench_config2.json 2> $OUT/bench_config2.err
-python bench.py --config 4 --tiles 4 --no-cpu-baseline > $OUT/bench_config4.json 2> $OUT/bench_config4.err
+python bench.py --config 2 --tiles 16 --no-cpu-baseline --no-traffic > $OUT/bench_config2.json 2> $OUT/bench_config2.err
+python bench.py --config 4 --tiles 4 --no-cpu-baseline --no-traffic > $OUT/bench_config4.json 2> $OUT/bench_config4.err
 python bench.py > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
 tail -c 600 $OUT/bench_line.json
