@@ -137,6 +137,20 @@ def _split_sites(spec: str) -> dict:
     return out
 
 
+def predicted_split_count(var_desc, base_var: float, bar_rms: float, margin: float = 0.9) -> int:
+    """How many blocks -- taken from the front of ``var_desc``, the per-block error variances in DESCENDING order -- must move to split
+    operands so that the variance left (``base_var``: what remains with every block split, plus the variances of the blocks that stay on
+    fp16 operands; independent rounding errors add in variance) stays within ``(margin * bar_rms)^2``.  The calibration verifies the
+    prediction on the probe and raises the count until it passes (GRL._calibrated_plan)."""
+    k, acc = len(var_desc), base_var
+    for j in range(len(var_desc) - 1, -1, -1):        # blocks that may stay on fp16 operands, cheapest first
+        if acc + var_desc[j] > (margin * bar_rms) ** 2:
+            break
+        acc += var_desc[j]
+        k = j
+    return k
+
+
 class GRL(nn.Module):
     """MI355X-native GRL.  Constructor signature of models/networks/grl.py:220-256."""
 
@@ -752,12 +766,7 @@ class GRL(nn.Module):
             var = {b: max(err(mixed(every - {b}))[1] ** 2 - e_all[1] ** 2, 0.0) for b in blocks}
             order = sorted(blocks, key=lambda b: -var[b])
             # predicted number of blocks (variances add), then verified by measurement and raised until the probe passes
-            k, acc = len(order), e_all[1] ** 2
-            for j in range(len(order) - 1, -1, -1):       # blocks that may stay fast, cheapest first
-                if acc + var[order[j]] > (0.9 * bar_rms) ** 2:
-                    break
-                acc += var[order[j]]
-                k = j
+            k = predicted_split_count([var[b] for b in order], e_all[1] ** 2, bar_rms)
             while True:
                 e = err(mixed(frozenset(order[:k])))
                 if ok(e) or k >= len(order):

@@ -321,3 +321,37 @@ def test_second_seeds_at_clamp_scales_vs_pinned_oracle(tag, seeds):
         err_h = (got_h - want).abs().max().item()
         print(f"{model} {geom} seeds {seeds} [precision='high']: max|hip - oracle_fp64| = {err_h:.3e}")
         assert err_h < TOL_MAXABS, err_h
+
+
+def test_auto_precision_is_calibrated_once_per_weight_set(monkeypatch):
+    """precision='auto' on a wide SR model with checkpoint-like scales (GRL._calibrated_plan): the choice is made when the plan is
+    built -- a second forward re-uses it, new weights trigger a new measurement, GRL_CALIBRATE=0 keeps the fp16-operand rules of
+    round 5 -- and the numbers it decided on are available to the caller."""
+    import math
+
+    from grl_image_restoration_amd import GRL, make_config
+
+    cfg = make_config("base", "sr_ckpt_df2", upscale=4, img_size=64)
+    m, sd = _product(cfg, 15, logit_scale_mean=math.log(100.0))          # weight draw 15: fp16 operands alone give 1.2e-3
+    m = m.to("cuda:0")
+    lq = O.synthetic_pair("sr", (64, 64), 4, batch=1, seed=25)[0].to("cuda:0")
+    builds = []
+    orig = GRL._build_plan
+    monkeypatch.setattr(GRL, "_build_plan", lambda self, *a, **k: (builds.append(a[2]), orig(self, *a, **k))[1])
+    with torch.no_grad():
+        y1 = m(lq)
+        n1 = len(builds)
+        y2 = m(lq)
+    cal = m.calibration
+    assert m.precision.startswith("mixed(") and 1 <= cal["split"] < cal["blocks"] == 40
+    assert cal["fast_max"] > cal["bar_max"] >= cal["probe_max"] and cal["probe_rms"] <= cal["bar_rms"]
+    assert n1 >= 3 and len(builds) == n1 and torch.equal(y1, y2)          # (fast, all-split reference, split blocks; nothing on the 2nd call)
+    m.load_state_dict(_product(cfg, 13, logit_scale_mean=math.log(100.0))[1], strict=True)    # new weights: measured again
+    with torch.no_grad():
+        m(lq)
+    assert len(builds) > n1 and m.calibration["split"] != cal["split"] or m.calibration["fast_max"] != cal["fast_max"]
+    monkeypatch.setenv("GRL_CALIBRATE", "0")
+    m.invalidate_plan()
+    with torch.no_grad():
+        y3 = m(lq)
+    assert m.precision == "fast" and m.calibration is None and bool(torch.isfinite(y3).all())

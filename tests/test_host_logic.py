@@ -600,3 +600,34 @@ def test_fused_adamw_capture_mode_keeps_addresses_and_follows_schedulers():
     opt.param_groups[0]["betas"] = (0.8, 0.999)
     with pytest.raises(RuntimeError):
         opt.refresh_capture_hyper()
+
+
+def test_calibration_predicts_the_blocks_to_split():
+    """GRL._calibrated_plan's variance bookkeeping (model.predicted_split_count): blocks are sorted by what their fp16 rounding
+    costs, the cheapest stay on fp16 operands while the summed variance fits the bar."""
+    from grl_image_restoration_amd.model import predicted_split_count as psc
+
+    bar = 1.3e-4
+    assert psc([], 0.0, bar) == 0
+    assert psc([1e-10] * 40, 0.0, bar) == 0                                 # 40 x (1e-5)^2 = (6.3e-5)^2: everything stays fast
+    assert psc([(3e-4) ** 2] + [1e-10] * 39, 0.0, bar) == 1                  # one dominant block (weight draw 15 of the tests)
+    assert psc([(1e-4) ** 2] * 4, 0.0, bar) == 3                            # one 1e-4 fits under 0.9 * 1.3e-4 = 1.17e-4, two (1.41e-4) do not
+    assert psc([(1e-4) ** 2] * 4, (1.2e-4) ** 2, bar) == 4                  # the convolutions around the blocks already exceed the margin
+    v = sorted(((i + 1) * 1e-5) ** 2 for i in range(10))[::-1]
+    k = psc(v, (2e-5) ** 2, bar)
+    assert (2e-5) ** 2 + sum(v[k:]) <= (0.9 * bar) ** 2 < (2e-5) ** 2 + sum(v[k - 1:])   # minimal
+
+
+def test_poison_and_deterministic_switches_are_off_by_default():
+    from grl_image_restoration_amd import _lib, ops
+
+    assert not ops._POISON and not ops.deterministic() and not _lib._DIRTY_LDS
+    prev = ops.set_poison(True)
+    try:
+        t = ops.empty(3, 5, dtype=torch.float32, device="cpu")
+        assert bool(torch.isnan(t).all())
+        i = ops.empty(4, dtype=torch.int32, device="cpu")
+        assert bool((i == 0x7F7F7F7F).all())
+    finally:
+        ops.set_poison(prev)
+    assert bool(torch.isfinite(ops.empty(2, dtype=torch.float32, device="cpu").fill_(0)).all())
