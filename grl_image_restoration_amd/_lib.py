@@ -40,6 +40,8 @@ EXPORTS = [
     "grl_gemm_tn",
     "grl_attention_bwd",
     "grl_adamw_step",
+    "grl_cpb_table_fwd",
+    "grl_cpb_table_bwd",
     "grl_debug_dirty_lds",
     "grl_abi_version",
     "grl_build_info",
@@ -362,6 +364,25 @@ class GrlAdamWArgs(_Strict):
     ]
 
 
+class GrlCpbArgs(_Strict):
+    _fields_ = [
+        ("coords", C.c_void_p),
+        ("w1", C.c_void_p),
+        ("b1", C.c_void_p),
+        ("w2", C.c_void_p),
+        ("out", C.c_void_p),
+        ("d_out", C.c_void_p),
+        ("d_w1", C.c_void_p),
+        ("d_b1", C.c_void_p),
+        ("d_w2", C.c_void_p),
+        ("G", C.c_int32),
+        ("rows", C.c_int32),
+        ("rows4", C.c_int32),
+        ("nh", C.c_int32),
+        ("hidden", C.c_int32),
+    ]
+
+
 _lib = None
 
 
@@ -433,6 +454,10 @@ def lib():
     L.grl_attention_bwd.restype = C.c_int
     L.grl_adamw_step.argtypes = [C.c_void_p, C.POINTER(GrlAdamWArgs)]
     L.grl_adamw_step.restype = C.c_int
+    L.grl_cpb_table_fwd.argtypes = [C.c_void_p, C.POINTER(GrlCpbArgs)]
+    L.grl_cpb_table_fwd.restype = C.c_int
+    L.grl_cpb_table_bwd.argtypes = [C.c_void_p, C.POINTER(GrlCpbArgs)]
+    L.grl_cpb_table_bwd.restype = C.c_int
     L.grl_debug_dirty_lds.argtypes = [C.c_void_p]
     L.grl_debug_dirty_lds.restype = C.c_int
     _lib = L

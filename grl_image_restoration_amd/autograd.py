@@ -397,6 +397,35 @@ def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
 attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
 
 
+class CpbTableFn(torch.autograd.Function):
+    """Bias tables of G AffineTransforms (ops.cpb_table / cpb_table_bwd, csrc/cpb.hip): differentiable w.r.t. the CPB-MLP weights,
+    no [G, rows, 512] hidden layer in memory.  ``coords`` is a constant of the geometry."""
+
+    @staticmethod
+    def forward(ctx, coords, w1, b1, w2, rows4):
+        ctx.save_for_backward(coords, w1, b1, w2)
+        return ops.cpb_table(coords, w1, b1, w2, rows4)
+
+    @staticmethod
+    def backward(ctx, d_out):
+        coords, w1, b1, w2 = ctx.saved_tensors
+        d_w1, d_b1, d_w2 = ops.cpb_table_bwd(coords, w1, b1, w2, d_out.float().contiguous())
+        return None, d_w1, d_b1, d_w2, None
+
+
+def cpb_tables(coords, w1, b1, w2, idx):
+    """[G, nh, rows4] kernel-domain bias tables from stacked CPB-MLP weights.  GPU: CpbTableFn; CPU tensors, head counts the kernel is
+    not instantiated for and GRL_DETERMINISTIC=1 (the kernel's cross-workgroup reduction uses fp32 atomics): the torch expression
+    (``idx``: the reversed-row gather with the pad entries pointing at row 0)."""
+    rows = coords.shape[0]
+    if w1.is_cuda and w2.shape[1] in ops.CPB_HEADS and w2.shape[2] == 512 and not ops.deterministic():
+        return CpbTableFn.apply(coords, w1, b1, w2, int(idx.numel()))
+    # layer 1 has K = 2: two broadcast multiply-adds instead of a GEMM;  h [G, rows, 512]
+    h = F.relu(torch.addcmul(torch.addcmul(b1.unsqueeze(1), coords[:, 0].view(1, rows, 1), w1[:, :, 0].unsqueeze(1)),
+                             coords[:, 1].view(1, rows, 1), w1[:, :, 1].unsqueeze(1)))
+    return torch.sigmoid(torch.bmm(w2, h.transpose(1, 2))).index_select(2, idx) * (16.0 * 1.4426950408889634)
+
+
 class AttentionFn:
     """Call-compatible front of torch.ops.grl.attention: ``AttentionFn.apply(q, k, v, table, geo)`` with
     geo = dict(q=(Himg, Wimg, wh, ww, shy, shx), k=(...), B, nh, d, masked, floor)."""

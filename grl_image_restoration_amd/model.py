@@ -1080,10 +1080,9 @@ class GRL(nn.Module):
             W1 = torch.stack([m.cpb_mlp[0].weight for _, m in items])            # [G, 512, 2]
             b1 = torch.stack([m.cpb_mlp[0].bias for _, m in items])              # [G, 512]
             W2 = torch.stack([m.cpb_mlp[2].weight for _, m in items])            # [G, nh, 512]
-            # layer 1 has K = 2: two broadcast multiply-adds instead of a GEMM;  h [G, rows, 512]
-            h = F.relu(torch.addcmul(torch.addcmul(b1.unsqueeze(1), coords[:, 0].view(1, rows, 1), W1[:, :, 0].unsqueeze(1)),
-                                     coords[:, 1].view(1, rows, 1), W1[:, :, 1].unsqueeze(1)))
-            t = torch.sigmoid(torch.bmm(W2, h.transpose(1, 2))).index_select(2, idx) * (16.0 * LOG2E)   # [G, nh, rows4], see _attn_table
+            # round 6: one launch forward, one backward, the [G, rows, 512] hidden layer (1.5 GB for the stripe transforms of GRL-Base)
+            # never in memory (autograd.cpb_tables -> csrc/cpb.hip; CPU tensors: the torch expression)
+            t = AG.cpb_tables(coords, W1, b1, W2, idx)                            # [G, nh, rows4], see _attn_table
             for (key, _), tt in zip(items, t.unbind(0)):
                 tabs[key] = tt
         out = {}
@@ -1101,16 +1100,14 @@ class GRL(nn.Module):
         coords = cache.get(key)
         if coords is None:
             coords = cache[key] = tables.coords_table(win, df, device=dev)
-        h = F.relu(F.linear(coords, m.cpb_mlp[0].weight, m.cpb_mlp[0].bias))
-        # tables.kernel_table(16 * sigmoid(.)) -- transpose, exp2 domain, reversed rows, padded to 4 -- as ONE gather and one scale
-        # (the chain of t / mul / flip / pad and its backward were ~15 launches per attention call, 120 calls per step); the pad
+        # tables.kernel_table(16 * sigmoid(cpb_mlp(coords))) -- transpose, exp2 domain, reversed rows, padded to 4; the pad
         # entries repeat row 0 instead of being zero: no valid (query, key) pair addresses them
         rows = coords.shape[0]
         idx = cache.get(("revidx", rows, str(dev)))
         if idx is None:
             idx = cache[("revidx", rows, str(dev))] = torch.cat([torch.arange(rows - 1, -1, -1, device=dev),
                                                                    torch.zeros((-rows) % 4, dtype=torch.long, device=dev)])
-        return torch.sigmoid(F.linear(h, m.cpb_mlp[2].weight)).t().index_select(1, idx) * (16.0 * LOG2E)     # differentiable w.r.t. the CPB-MLP
+        return AG.cpb_tables(coords, m.cpb_mlp[0].weight.unsqueeze(0), m.cpb_mlp[0].bias.unsqueeze(0), m.cpb_mlp[2].weight.unsqueeze(0), idx)[0]
 
     @staticmethod
     def _scale(m: _Affine):

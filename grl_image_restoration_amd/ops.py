@@ -803,3 +803,36 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     if fix is not None:
         d_table = (fix.double() * (2.0 ** -32 / g_scale)).float()
     return d_q, d_k, d_v, d_table
+
+
+CPB_HEADS = (1, 2, 3, 4, 6, 8)     # head counts csrc/cpb.hip is instantiated for
+
+
+def cpb_table(coords: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, rows4: int) -> torch.Tensor:
+    """Kernel-domain bias tables of G AffineTransforms at once (grl_cpb_table_fwd): coords [rows, 2], w1 [G, 512, 2], b1 [G, 512],
+    w2 [G, nh, 512] -> [G, nh, rows4] = 16 log2(e) sigmoid(cpb_mlp(coords)), rows reversed, pad entries = source row 0."""
+    _dev_check(coords, w1, b1, w2)
+    G, nh, hid = w2.shape
+    rows = coords.shape[0]
+    assert coords.shape == (rows, 2) and w1.shape == (G, hid, 2) and b1.shape == (G, hid) and rows4 >= rows and rows4 % 4 == 0
+    cs, a, b, c = (t.detach().float().contiguous() for t in (coords, w1, b1, w2))
+    out = empty(G, nh, rows4, dtype=torch.float32, device=coords.device)
+    args = L.GrlCpbArgs(coords=_ptr(cs), w1=_ptr(a), b1=_ptr(b), w2=_ptr(c), out=_ptr(out), G=G, rows=rows, rows4=rows4, nh=nh, hidden=hid)
+    with _timed("cpb_table"):
+        L.check(L.lib().grl_cpb_table_fwd(L.stream_ptr(), C.byref(args)), "grl_cpb_table_fwd")
+    return out
+
+
+def cpb_table_bwd(coords: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, d_out: torch.Tensor):
+    """Gradients of cpb_table w.r.t. (w1, b1, w2) given d_out [G, nh, rows4] (grl_cpb_table_bwd; the hidden layer is recomputed)."""
+    _dev_check(coords, w1, b1, w2, d_out)
+    G, nh, hid = w2.shape
+    rows, rows4 = coords.shape[0], d_out.shape[2]
+    assert d_out.shape == (G, nh, rows4) and d_out.dtype == torch.float32
+    cs, a, b, c, g = (t.detach().float().contiguous() for t in (coords, w1, b1, w2, d_out))
+    d_w1, d_b1, d_w2 = torch.zeros_like(a), torch.zeros_like(b), torch.zeros_like(c)
+    args = L.GrlCpbArgs(coords=_ptr(cs), w1=_ptr(a), b1=_ptr(b), w2=_ptr(c), d_out=_ptr(g), d_w1=_ptr(d_w1), d_b1=_ptr(d_b1), d_w2=_ptr(d_w2),
+                        G=G, rows=rows, rows4=rows4, nh=nh, hidden=hid)
+    with _timed("cpb_table_bwd"):
+        L.check(L.lib().grl_cpb_table_bwd(L.stream_ptr(), C.byref(args)), "grl_cpb_table_bwd")
+    return d_w1, d_b1, d_w2

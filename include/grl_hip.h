@@ -502,6 +502,29 @@ typedef struct GrlAdamWArgs {
 
 int grl_adamw_step(void* stream, const GrlAdamWArgs* args);
 
+/* Relative-position bias tables for MANY AffineTransforms at once, forward and backward (ABI 21, training path):
+ *   replaces  16 * sigmoid(cpb_mlp(relative_coords_table))  models/common/mixed_attn_block_efficient.py:23-34,49-58  (cpb_mlp =
+ *   Linear(2, 512, bias) -> ReLU -> Linear(512, nh, no bias)) and autograd through it, without the [G, rows, 512] hidden layer in
+ *   memory (1.5 GB for the 80 stripe transforms of GRL-Base at the checkpoint geometry).
+ * out[g][n][i] = 16 log2(e) sigmoid(pre[g][n][rows-1-i]) for i < rows -- the REVERSED, exp2-domain layout grl_attention_fwd reads --
+ * and the value of source row 0 in the pad entries i = rows .. rows4-1.  Backward: d_w1 / d_b1 / d_w2 must be zeroed by the caller
+ * (accumulated with atomics).  nh in {1, 2, 3, 4, 6, 8}, hidden = 512. */
+typedef struct GrlCpbArgs {
+    const float* coords;    /* [rows, 2]   relative coordinates table (tables.coords_table), shared by all transforms */
+    const float* w1;        /* [G, hidden, 2]   cpb_mlp.0.weight  */
+    const float* b1;        /* [G, hidden]      cpb_mlp.0.bias    */
+    const float* w2;        /* [G, nh, hidden]  cpb_mlp.2.weight  */
+    float* out;             /* [G, nh, rows4]   (forward)         */
+    const float* d_out;     /* [G, nh, rows4]   (backward)        */
+    float* d_w1;            /* [G, hidden, 2], d_b1 [G, hidden], d_w2 [G, nh, hidden]  (backward; zeroed by the caller) */
+    float* d_b1;
+    float* d_w2;
+    int32_t G, rows, rows4, nh, hidden;
+} GrlCpbArgs;
+
+int grl_cpb_table_fwd(void* stream, const GrlCpbArgs* args);
+int grl_cpb_table_bwd(void* stream, const GrlCpbArgs* args);
+
 /* Debug aid (ABI 21; no reference counterpart): fills the LDS of every CU with 0xFF bytes (fp32 / fp16 NaN) by a launch on
  * `stream`.  LDS keeps what the previous workgroup left in it; a kernel that reads LDS it has not written is otherwise right or
  * wrong depending on what ran before it.  The Python wrappers call this before every launch when GRL_DIRTY_LDS=1 (tests). */

@@ -240,3 +240,35 @@ def test_fused_adamw_resumes_from_and_into_torch_adamw():
         both_step(k)
     for a, b in zip(pa, pb):
         assert (a - b).abs().max().item() <= 3e-6 * max(1.0, b.abs().max().item())
+
+
+@pytest.mark.parametrize("G,nh,win,df", [(3, 3, (64, 64), 2), (2, 3, (32, 32), 1), (1, 2, (16, 16), 4), (2, 6, (12, 12), 1)])
+def test_cpb_table_kernels_match_torch(G, nh, win, df):
+    """grl_cpb_table_fwd / _bwd (csrc/cpb.hip: the bias tables of many AffineTransforms without the [G, rows, 512] hidden layer in
+    memory) against the torch expression of mixed_attn_block_efficient.py:49-58 in float64: table values (reversed rows, exp2 domain,
+    pad entries = row 0) and the gradients of both layers."""
+    from grl_image_restoration_amd import autograd as AG, tables
+
+    g = torch.Generator().manual_seed(61)
+    coords = tables.coords_table(win, df, device="cpu")
+    rows = coords.shape[0]
+    rows4 = (rows + 3) // 4 * 4
+    w1 = torch.randn(G, 512, 2, generator=g) * 0.7
+    b1 = torch.randn(G, 512, generator=g) * 0.5
+    w2 = torch.randn(G, nh, 512, generator=g) * 0.1
+    d_out = torch.randn(G, nh, rows4, generator=g) * 1e-6      # (table gradients of an L1 step are this small)
+    # float64 reference
+    a, b, c = (t.double().requires_grad_(True) for t in (w1, b1, w2))
+    h = F.relu(torch.einsum("rk,ghk->grh", coords.double(), a) + b.unsqueeze(1))
+    tab = 16.0 * LOG2E * torch.sigmoid(torch.einsum("gnh,grh->gnr", c, h))            # [G, nh, rows]
+    want = torch.cat([tab.flip(2), tab[:, :, :1].expand(-1, -1, rows4 - rows)], dim=2)
+    (want * d_out.double()).sum().backward()
+    # kernels
+    idx = torch.cat([torch.arange(rows - 1, -1, -1), torch.zeros(rows4 - rows, dtype=torch.long)]).cuda()
+    ad, bd, cd = (t.clone().cuda().requires_grad_(True) for t in (w1, b1, w2))
+    got = AG.cpb_tables(coords.cuda(), ad, bd, cd, idx)
+    assert got.shape == want.shape and (got.double().cpu() - want.detach()).abs().max().item() < 2e-5     # values up to 23
+    got.backward(d_out.cuda())
+    errs = dict(w1=_rel(ad.grad, a.grad), b1=_rel(bd.grad, b.grad), w2=_rel(cd.grad, c.grad))
+    print(f"cpb G={G} nh={nh} rows={rows}: {errs}")
+    assert max(errs.values()) < 2e-5, errs

@@ -515,7 +515,9 @@ def test_training_glue_shortcuts_equal_the_plain_torch_chains():
         gw[:, rows:] = 0                                                                             # nothing reads the pad entries
         g1 = torch.autograd.grad((got * gw).sum(), tr.cpb_mlp[2].weight, retain_graph=True)[0]
         g2 = torch.autograd.grad((want * gw).sum(), tr.cpb_mlp[2].weight)[0]
-        assert torch.allclose(g1, g2, rtol=1e-5, atol=1e-7)
+        # (two fp32 evaluation orders of the same expression -- the K = 2 layer as two multiply-adds + bmm against F.linear: both
+        # are 1.4e-5 from the float64 gradient on entries up to 35, and 4e-6 from each other)
+        assert torch.allclose(g1, g2, rtol=1e-5, atol=2e-5)
 
     t = torch.randn(96, 3, 30, generator=torch.Generator().manual_seed(6), requires_grad=True)
     plain = F.pad(t, (0, 2)).permute(1, 0, 2).contiguous()
