@@ -40,6 +40,8 @@ EXPORTS = [
     "grl_gemm_tn",
     "grl_attention_bwd",
     "grl_adamw_step",
+    "grl_layernorm_train_fwd",
+    "grl_layernorm_bwd",
     "grl_cpb_table_fwd",
     "grl_cpb_table_bwd",
     "grl_debug_dirty_lds",
@@ -364,6 +366,23 @@ class GrlAdamWArgs(_Strict):
     ]
 
 
+class GrlLnTrainArgs(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p), ("ldx", C.c_int64),
+        ("gamma", C.c_void_p),
+        ("beta", C.c_void_p),
+        ("y", C.c_void_p), ("ldy", C.c_int64),
+        ("mean", C.c_void_p),
+        ("rstd", C.c_void_p),
+        ("dy", C.c_void_p), ("lddy", C.c_int64),
+        ("dx", C.c_void_p), ("lddx", C.c_int64),
+        ("dgamma", C.c_void_p),
+        ("dbeta", C.c_void_p),
+        ("M", C.c_int32), ("n", C.c_int32),
+        ("eps", C.c_float),
+    ]
+
+
 class GrlCpbArgs(_Strict):
     _fields_ = [
         ("coords", C.c_void_p),
@@ -454,6 +473,10 @@ def lib():
     L.grl_attention_bwd.restype = C.c_int
     L.grl_adamw_step.argtypes = [C.c_void_p, C.POINTER(GrlAdamWArgs)]
     L.grl_adamw_step.restype = C.c_int
+    L.grl_layernorm_train_fwd.argtypes = [C.c_void_p, C.POINTER(GrlLnTrainArgs)]
+    L.grl_layernorm_train_fwd.restype = C.c_int
+    L.grl_layernorm_bwd.argtypes = [C.c_void_p, C.POINTER(GrlLnTrainArgs)]
+    L.grl_layernorm_bwd.restype = C.c_int
     L.grl_cpb_table_fwd.argtypes = [C.c_void_p, C.POINTER(GrlCpbArgs)]
     L.grl_cpb_table_fwd.restype = C.c_int
     L.grl_cpb_table_bwd.argtypes = [C.c_void_p, C.POINTER(GrlCpbArgs)]

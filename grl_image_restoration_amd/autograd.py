@@ -397,6 +397,32 @@ def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
 attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
 
 
+class LayerNormFn(torch.autograd.Function):
+    """nn.LayerNorm over the last dimension of a token matrix [M, n] (ops.layernorm_train / layernorm_bwd, csrc/ln_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        xc = x.detach().float().contiguous()
+        y, mean, rstd = ops.layernorm_train(xc, gamma, beta, eps)
+        ctx.save_for_backward(xc, mean, rstd, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma = ctx.saved_tensors
+        dx, dg, db = ops.layernorm_bwd(dy.float().contiguous(), x, mean, rstd, gamma)
+        return dx, dg, db, None
+
+
+def layer_norm(x, gamma, beta, eps: float = 1e-5):
+    """F.layer_norm(x, (n,), gamma, beta, eps) on a token matrix; GPU tensors with n % 4 == 0, n <= 256 take the HIP kernels (fp32
+    atomics in the column sums of dgamma / dbeta: GRL_DETERMINISTIC=1 keeps torch's kernels)."""
+    n = x.shape[-1]
+    if x.is_cuda and x.dim() == 2 and n % 4 == 0 and n <= 256 and not ops.deterministic():
+        return LayerNormFn.apply(x, gamma, beta, eps)
+    return F.layer_norm(x, (n,), gamma, beta, eps)
+
+
 class CpbTableFn(torch.autograd.Function):
     """Bias tables of G AffineTransforms (ops.cpb_table / cpb_table_bwd, csrc/cpb.hip): differentiable w.r.t. the CPB-MLP weights,
     no [G, rows, 512] hidden layer in memory.  ``coords`` is a constant of the geometry."""

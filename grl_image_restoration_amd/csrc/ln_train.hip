@@ -1,0 +1,95 @@
+// Row LayerNorm of the TRAINING path (gfx950): forward with saved statistics, and backward.
+//
+// Replaces nn.LayerNorm on the token matrices of a training step -- norm1 / norm2 of every block
+// (models/common/mixed_attn_block_efficient.py:543-556), norm_start / norm_end (models/networks/grl.py:494,501) -- and autograd
+// through them.  As torch kernels they were 82 launches of 37 us forward and 82 x (33 + 32 + 5) us backward per step of BASELINE
+// config 5 (profiles/r06_train_kernel_stats.txt: 1.3 TB/s on a [32 768, 180] fp32 matrix); the rows are 720 bytes, one wave per row
+// with 16-byte accesses streams them at the HBM rate.
+//   forward : y = (x - mean) rstd gamma + beta;  mean / rstd per row kept for the backward pass
+//   backward: g = dy gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));  dgamma = sum_rows dy xhat;  dbeta = sum_rows dy
+//             (column sums: per-lane partials over a wave's rows, the four waves of a workgroup through LDS, one atomic per column
+//             and workgroup into the zeroed outputs)
+#include "common.h"
+#include "grl_hip_internal.h"
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) { return sum_halves(sum_rows16(row16_sum(v))); }
+
+__global__ __launch_bounds__(256) void ln_train_fwd_kernel(GrlLnTrainArgs p) {
+    const int lane = threadIdx.x & 63;
+    const int c = lane * 4;
+    const bool in = c < p.n;                       // (n is a multiple of 4)
+    float4 gm = float4{0, 0, 0, 0}, bt = gm;
+    if (in) { gm = *(const float4*)(p.gamma + c); bt = *(const float4*)(p.beta + c); }
+    const float inv_n = 1.0f / (float)p.n;
+    for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < p.M; row += gridDim.x * 4) {
+        float4 v = float4{0, 0, 0, 0};
+        if (in) v = *(const float4*)(p.x + (int64_t)row * p.ldx + c);
+        const float mean = wave_sum(v.x + v.y + v.z + v.w) * inv_n;
+        const float d0 = in ? v.x - mean : 0.f, d1 = in ? v.y - mean : 0.f, d2 = in ? v.z - mean : 0.f, d3 = in ? v.w - mean : 0.f;
+        const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * inv_n + p.eps);
+        if (in)
+            *(float4*)(p.y + (int64_t)row * p.ldy + c) =
+                float4{d0 * rstd * gm.x + bt.x, d1 * rstd * gm.y + bt.y, d2 * rstd * gm.z + bt.z, d3 * rstd * gm.w + bt.w};
+        if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
+    }
+}
+
+__global__ __launch_bounds__(256) void ln_train_bwd_kernel(GrlLnTrainArgs p) {
+    __shared__ float red[2][4][256];               // [dgamma | dbeta][wave][column]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int c = lane * 4;
+    const bool in = c < p.n;
+    float4 gm = float4{0, 0, 0, 0};
+    if (in) gm = *(const float4*)(p.gamma + c);
+    const float inv_n = 1.0f / (float)p.n;
+    float4 sg = float4{0, 0, 0, 0}, sb = sg;
+    for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
+        float4 v = float4{0, 0, 0, 0}, d = v;
+        if (in) { v = *(const float4*)(p.x + (int64_t)row * p.ldx + c); d = *(const float4*)(p.dy + (int64_t)row * p.lddy + c); }
+        const float mean = p.mean[row], rstd = p.rstd[row];
+        const float h0 = in ? (v.x - mean) * rstd : 0.f, h1 = in ? (v.y - mean) * rstd : 0.f, h2 = in ? (v.z - mean) * rstd : 0.f,
+                    h3 = in ? (v.w - mean) * rstd : 0.f;
+        const float g0 = d.x * gm.x, g1 = d.y * gm.y, g2 = d.z * gm.z, g3 = d.w * gm.w;
+        const float s1 = wave_sum(g0 + g1 + g2 + g3) * inv_n;
+        const float s2 = wave_sum(g0 * h0 + g1 * h1 + g2 * h2 + g3 * h3) * inv_n;
+        if (in)
+            *(float4*)(p.dx + (int64_t)row * p.lddx + c) =
+                float4{rstd * (g0 - s1 - h0 * s2), rstd * (g1 - s1 - h1 * s2), rstd * (g2 - s1 - h2 * s2), rstd * (g3 - s1 - h3 * s2)};
+        sg.x = fmaf(d.x, h0, sg.x); sg.y = fmaf(d.y, h1, sg.y); sg.z = fmaf(d.z, h2, sg.z); sg.w = fmaf(d.w, h3, sg.w);
+        sb.x += d.x; sb.y += d.y; sb.z += d.z; sb.w += d.w;
+    }
+    *(float4*)&red[0][wave][c] = sg;
+    *(float4*)&red[1][wave][c] = sb;
+    __syncthreads();
+    const int col = threadIdx.x;                   // 256 threads: one column each
+    if (col < p.n) {
+        unsafeAtomicAdd(p.dgamma + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
+        unsafeAtomicAdd(p.dbeta + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
+    }
+}
+
+bool ln_args_ok(const GrlLnTrainArgs& p) {
+    return p.M > 0 && p.n > 0 && p.n <= 256 && (p.n & 3) == 0 && p.x && p.gamma && p.mean && p.rstd && (p.ldx & 3) == 0 && p.ldx >= p.n;
+}
+
+}  // namespace
+
+extern "C" int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args) {
+    const GrlLnTrainArgs& p = *args;
+    if (!ln_args_ok(p) || !p.y || !p.beta || (p.ldy & 3) || p.ldy < p.n) return GRL_ERR_BAD_ARG;
+    const int grid = (p.M + 3) / 4 < 4096 ? (p.M + 3) / 4 : 4096;
+    hipLaunchKernelGGL(ln_train_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int grl_layernorm_bwd(void* stream, const GrlLnTrainArgs* args) {
+    const GrlLnTrainArgs& p = *args;
+    if (!ln_args_ok(p) || !p.dy || !p.dx || !p.dgamma || !p.dbeta || (p.lddy & 3) || (p.lddx & 3) || p.lddy < p.n || p.lddx < p.n) return GRL_ERR_BAD_ARG;
+    const int grid = (p.M + 3) / 4 < 1024 ? (p.M + 3) / 4 : 1024;
+    hipLaunchKernelGGL(ln_train_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}

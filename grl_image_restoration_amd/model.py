@@ -1238,7 +1238,7 @@ class GRL(nn.Module):
         M = B * H * W
         a = blk.attn
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
-        x1 = self._residual(r, F.layer_norm(x1, (C,), blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp)
+        x1 = self._residual(r, AG.layer_norm(x1, blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
             c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention
             u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
@@ -1246,7 +1246,7 @@ class GRL(nn.Module):
             gate = torch.sigmoid(F.linear(F.relu(F.linear(pool, se[1].weight.flatten(1), se[1].bias)), se[3].weight.flatten(1), se[3].bias))
             x1 = torch.addcmul(x1.view(B, H * W, C), u.view(B, H * W, C), gate.unsqueeze(1)).view(M, C)      # x1 + u * gate in one launch
         m = AG.linear(F.gelu(AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        return self._residual(x1, F.layer_norm(m, (C,), blk.norm2.weight, blk.norm2.bias, 1e-5), H * W, dp)
+        return self._residual(x1, AG.layer_norm(m, blk.norm2.weight, blk.norm2.bias, 1e-5), H * W, dp)
 
     def _residual(self, r, t, rows_per_image: int, p: float):
         """r + res_scale * DropPath(t) (efficient.py:543-556, timm DropPath with scale_by_keep: one Bernoulli draw per image) in ONE
@@ -1284,7 +1284,7 @@ class GRL(nn.Module):
             return t.view(B, h, w, -1).permute(0, 3, 1, 2)
 
         f = conv(x.permute(0, 2, 3, 1).reshape(B * H * W, Cin), self.conv_first)
-        z = F.layer_norm(f, (C,), self.norm_start.weight, self.norm_start.bias, 1e-5)
+        z = AG.layer_norm(f, self.norm_start.weight, self.norm_start.bias, 1e-5)
         pre = self._train_tables(sched, x.device) if os.environ.get("GRL_TRAIN_BATCHED_PLANES", "1") != "0" else {}
         j = 0
         for si, stage in enumerate(self.layers):
@@ -1293,7 +1293,7 @@ class GRL(nn.Module):
                 r = self._block_train(r, blk, sched[si][bi], B, H, W, self._dpr[j], pre.get((si, bi)))
                 j += 1
             z = conv(r, stage.conv) + z
-        z = F.layer_norm(z, (C,), self.norm_end.weight, self.norm_end.bias, 1e-5)
+        z = AG.layer_norm(z, self.norm_end.weight, self.norm_end.bias, 1e-5)
         body = conv(z, self.conv_after_body) + f
         if self.upsampler == "pixelshuffle":
             y = F.leaky_relu(conv(body, self.conv_before_upsample[0]), 0.01)

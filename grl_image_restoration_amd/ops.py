@@ -836,3 +836,36 @@ def cpb_table_bwd(coords: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: 
     with _timed("cpb_table_bwd"):
         L.check(L.lib().grl_cpb_table_bwd(L.stream_ptr(), C.byref(args)), "grl_cpb_table_bwd")
     return d_w1, d_b1, d_w2
+
+
+def layernorm_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+    """Row LayerNorm of a token matrix x [M, n] (fp32, n a multiple of 4, <= 256) with the row statistics kept for the backward
+    pass (grl_layernorm_train_fwd): returns (y, mean [M], rstd [M])."""
+    _dev_check(x, gamma, beta)
+    M, n = x.shape
+    assert x.dtype == torch.float32 and x.stride(1) == 1 and n % 4 == 0 and n <= 256 and x.stride(0) % 4 == 0
+    g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
+    y = empty(M, n, dtype=torch.float32, device=x.device)
+    mean = empty(M, dtype=torch.float32, device=x.device)
+    rstd = empty(M, dtype=torch.float32, device=x.device)
+    args = L.GrlLnTrainArgs(x=_ptr(x), ldx=x.stride(0), gamma=_ptr(g), beta=_ptr(b), y=_ptr(y), ldy=n, mean=_ptr(mean), rstd=_ptr(rstd),
+                            M=M, n=n, eps=eps)
+    with _timed("layernorm_train"):
+        L.check(L.lib().grl_layernorm_train_fwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_train_fwd")
+    return y, mean, rstd
+
+
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor):
+    """(dx, dgamma, dbeta) of layernorm_train (grl_layernorm_bwd)."""
+    _dev_check(dy, x, mean, rstd, gamma)
+    M, n = x.shape
+    assert dy.shape == x.shape and dy.dtype == torch.float32 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
+    g = gamma.detach().float().contiguous()
+    dx = empty(M, n, dtype=torch.float32, device=x.device)
+    dgamma = torch.zeros(n, dtype=torch.float32, device=x.device)
+    dbeta = torch.zeros(n, dtype=torch.float32, device=x.device)
+    args = L.GrlLnTrainArgs(x=_ptr(x), ldx=x.stride(0), gamma=_ptr(g), mean=_ptr(mean), rstd=_ptr(rstd), dy=_ptr(dy), lddy=dy.stride(0),
+                            dx=_ptr(dx), lddx=n, dgamma=_ptr(dgamma), dbeta=_ptr(dbeta), M=M, n=n, eps=0.0)
+    with _timed("layernorm_bwd"):
+        L.check(L.lib().grl_layernorm_bwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_bwd")
+    return dx, dgamma, dbeta

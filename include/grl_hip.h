@@ -502,6 +502,28 @@ typedef struct GrlAdamWArgs {
 
 int grl_adamw_step(void* stream, const GrlAdamWArgs* args);
 
+/* Row LayerNorm of the training path (ABI 21): forward with the row statistics kept, and backward.
+ *   replaces nn.LayerNorm on token matrices and autograd through it: norm1 / norm2  models/common/mixed_attn_block_efficient.py:543-556,
+ *   norm_start / norm_end  models/networks/grl.py:494,501.  n <= 256 channels, a multiple of 4; row strides in elements, multiples of 4.
+ * forward: y, mean[M], rstd[M];  backward: dx, and dgamma / dbeta ACCUMULATED with atomics into arrays the caller zeroes. */
+typedef struct GrlLnTrainArgs {
+    const float* x;  int64_t ldx;
+    const float* gamma;
+    const float* beta;       /* forward only */
+    float* y;        int64_t ldy;      /* forward only */
+    float* mean;             /* [M] written by the forward, read by the backward */
+    float* rstd;
+    const float* dy; int64_t lddy;     /* backward only */
+    float* dx;       int64_t lddx;
+    float* dgamma;
+    float* dbeta;
+    int32_t M, n;
+    float eps;
+} GrlLnTrainArgs;
+
+int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args);
+int grl_layernorm_bwd(void* stream, const GrlLnTrainArgs* args);
+
 /* Relative-position bias tables for MANY AffineTransforms at once, forward and backward (ABI 21, training path):
  *   replaces  16 * sigmoid(cpb_mlp(relative_coords_table))  models/common/mixed_attn_block_efficient.py:23-34,49-58  (cpb_mlp =
  *   Linear(2, 512, bias) -> ReLU -> Linear(512, nh, no bias)) and autograd through it, without the [G, rows, 512] hidden layer in

@@ -272,3 +272,24 @@ def test_cpb_table_kernels_match_torch(G, nh, win, df):
     errs = dict(w1=_rel(ad.grad, a.grad), b1=_rel(bd.grad, b.grad), w2=_rel(cd.grad, c.grad))
     print(f"cpb G={G} nh={nh} rows={rows}: {errs}")
     assert max(errs.values()) < 2e-5, errs
+
+
+@pytest.mark.parametrize("M,n", [(4099, 180), (777, 64), (1024, 128), (5, 256)])
+def test_layernorm_train_kernels_match_torch(M, n):
+    """grl_layernorm_train_fwd / grl_layernorm_bwd (csrc/ln_train.hip) against F.layer_norm and its autograd in float64."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(62)
+    x = torch.randn(M, n, generator=g) * 3 + 0.5
+    gamma, beta = 1 + 0.1 * torch.randn(n, generator=g), 0.1 * torch.randn(n, generator=g)
+    dy = torch.randn(M, n, generator=g) * 1e-6
+    xr, gr, br = (t.double().requires_grad_(True) for t in (x, gamma, beta))
+    yr = F.layer_norm(xr, (n,), gr, br, 1e-5)
+    yr.backward(dy.double())
+    xd, gd, bd = (t.clone().cuda().requires_grad_(True) for t in (x, gamma, beta))
+    y = AG.layer_norm(xd, gd, bd, 1e-5)
+    assert (y.double().cpu() - yr.detach()).abs().max().item() < 5e-6
+    y.backward(dy.cuda())
+    errs = dict(dx=_rel(xd.grad, xr.grad), dgamma=_rel(gd.grad, gr.grad), dbeta=_rel(bd.grad, br.grad))
+    print(f"layernorm M={M} n={n}: {errs}")
+    assert max(errs.values()) < 5e-6, errs
