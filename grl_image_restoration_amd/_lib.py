@@ -42,6 +42,8 @@ EXPORTS = [
     "grl_adamw_step",
     "grl_layernorm_train_fwd",
     "grl_layernorm_bwd",
+    "grl_head_planes_fwd",
+    "grl_head_planes_bwd",
     "grl_cpb_table_fwd",
     "grl_cpb_table_bwd",
     "grl_debug_dirty_lds",
@@ -383,6 +385,20 @@ class GrlLnTrainArgs(_Strict):
     ]
 
 
+class GrlPlanesArgs(_Strict):
+    _fields_ = [
+        ("x", C.c_void_p),
+        ("scale", C.c_void_p),
+        ("out32", C.c_void_p),
+        ("out16", C.c_void_p),
+        ("dy", C.c_void_p * 8),
+        ("dx", C.c_void_p),
+        ("dscale", C.c_void_p),
+        ("T", C.c_int32), ("S_in", C.c_int32), ("S_out", C.c_int32), ("nh", C.c_int32), ("d", C.c_int32),
+        ("src", C.c_int32 * 8), ("raw", C.c_int32 * 8), ("one_col", C.c_int32 * 8), ("want_dscale", C.c_int32 * 8),
+    ]
+
+
 class GrlCpbArgs(_Strict):
     _fields_ = [
         ("coords", C.c_void_p),
@@ -477,6 +493,10 @@ def lib():
     L.grl_layernorm_train_fwd.restype = C.c_int
     L.grl_layernorm_bwd.argtypes = [C.c_void_p, C.POINTER(GrlLnTrainArgs)]
     L.grl_layernorm_bwd.restype = C.c_int
+    L.grl_head_planes_fwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]
+    L.grl_head_planes_fwd.restype = C.c_int
+    L.grl_head_planes_bwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]
+    L.grl_head_planes_bwd.restype = C.c_int
     L.grl_cpb_table_fwd.argtypes = [C.c_void_p, C.POINTER(GrlCpbArgs)]
     L.grl_cpb_table_fwd.restype = C.c_int
     L.grl_cpb_table_bwd.argtypes = [C.c_void_p, C.POINTER(GrlCpbArgs)]

@@ -397,6 +397,30 @@ def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
 attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
 
 
+class HeadPlanesFn(torch.autograd.Function):
+    """x [T, S_in, nh, d] -> the fp32 head planes of S_out slots (differentiable) and their fp16 copies (ops.head_planes /
+    head_planes_bwd, csrc/planes.hip).  ``scale`` [S_out, nh]; ``src`` / ``raw`` / ``one_cols``: tuples per output slot."""
+
+    @staticmethod
+    def forward(ctx, x, scale, src, raw, one_cols):
+        xc, sc = x.detach().float().contiguous(), scale.detach().float().contiguous()
+        out32, out16 = ops.head_planes(xc, sc, src, raw, one_cols)
+        ctx.save_for_backward(xc, sc)
+        ctx.cfg = (tuple(src), tuple(raw), tuple(one_cols))
+        p32, p16 = out32.unbind(0), out16.unbind(0)
+        ctx.mark_non_differentiable(*p16)
+        return (*p32, *p16)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        x, scale = ctx.saved_tensors
+        src, raw, one_cols = ctx.cfg
+        S = len(src)
+        want = [ctx.needs_input_grad[1] and not r for r in raw]
+        dx, dscale = ops.head_planes_bwd(x, scale, src, raw, one_cols, list(grads[:S]), want)
+        return dx, (dscale if ctx.needs_input_grad[1] else None), None, None, None
+
+
 class LayerNormFn(torch.autograd.Function):
     """nn.LayerNorm over the last dimension of a token matrix [M, n] (ops.layernorm_train / layernorm_bwd, csrc/ln_train.hip)."""
 

@@ -1030,6 +1030,18 @@ class GRL(nn.Module):
         T, S, nh, d = x.shape
         dev = x.device
         cache = self.__dict__.setdefault("_coords_cache", {})
+        if ops.head_planes_ok(x, S) and os.environ.get("GRL_PLANES_KERNEL", "1") != "0" and not ops.deterministic():
+            # round 6: one launch forward (normalise, scale, pad constants, permute, fp16 copy), one backward (csrc/planes.hip).
+            # An expanded input (the anchors, used as scaled queries and as keys) is passed once: both slots read input slot 0.
+            expanded = x.stride(1) == 0
+            xin = x[:, :1] if expanded else x
+            ones = cache.get(("ones_nh", nh, str(dev)))
+            if ones is None:
+                ones = cache[("ones_nh", nh, str(dev))] = torch.ones(nh, dtype=torch.float32, device=dev)
+            sc = torch.stack([ones if s is None else s for s in scales])                     # [S, nh] (differentiable in the q scales)
+            outs = AG.HeadPlanesFn.apply(xin, sc, tuple(0 if expanded else j for j in range(S)), tuple(s is None for s in scales),
+                                         tuple(int(c) for c in one_cols))
+            return outs[:S], outs[S:]
         key = ("planes_const", T, S, nh, d, tuple(s is None for s in scales), tuple(one_cols), str(dev))
         const = cache.get(key)
         if const is None:

@@ -869,3 +869,50 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: t
     with _timed("layernorm_bwd"):
         L.check(L.lib().grl_layernorm_bwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_bwd")
     return dx, dgamma, dbeta
+
+
+def _planes_args(x, scale, src, raw, one_cols, want):
+    T, S_in, nh, d = x.shape
+    S_out = len(src)
+    i8 = lambda v: (C.c_int32 * 8)(*(list(v) + [0] * (8 - len(v))))
+    return L.GrlPlanesArgs(x=_ptr(x), scale=_ptr(scale), T=T, S_in=S_in, S_out=S_out, nh=nh, d=d, src=i8(src), raw=i8([int(r) for r in raw]),
+                           one_col=i8(one_cols), want_dscale=i8([int(w) for w in want]))
+
+
+def head_planes_ok(x: torch.Tensor, n_out: int) -> bool:
+    return x.is_cuda and x.dim() == 4 and x.shape[1] <= 8 and n_out <= 8 and x.shape[2] <= 8 and x.shape[3] <= 32 and x.shape[3] % 2 == 0
+
+
+def head_planes(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols):
+    """grl_head_planes_fwd: x [T, S_in, nh, d] fp32 -> (fp32 planes [S_out, nh, T, 32], fp16 copy); output slot s reads input slot
+    src[s], raw[s]: copied, else L2-normalised over d and multiplied by scale[s][head]; one_cols[s] >= 0: that plane column is 1.0."""
+    _dev_check(x, scale)
+    assert x.dtype == torch.float32 and x.is_contiguous() and scale.dtype == torch.float32 and scale.is_contiguous()
+    T, S_in, nh, d = x.shape
+    S_out = len(src)
+    assert scale.shape == (S_out, nh)
+    out32 = empty(S_out, nh, T, 32, dtype=torch.float32, device=x.device)
+    out16 = empty(S_out, nh, T, 32, dtype=PLANE_DTYPE, device=x.device)
+    args = _planes_args(x, scale, src, raw, one_cols, [False] * S_out)
+    args.out32, args.out16 = _ptr(out32), _ptr(out16)
+    with _timed("head_planes"):
+        L.check(L.lib().grl_head_planes_fwd(L.stream_ptr(), C.byref(args)), "grl_head_planes_fwd")
+    return out32, out16
+
+
+def head_planes_bwd(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols, grads, want_dscale):
+    """grl_head_planes_bwd: ``grads[s]``: fp32 plane [nh, T, 32] or None -> (dx like x, dscale [S_out, nh])."""
+    _dev_check(x, scale, *[g for g in grads if g is not None])
+    S_out = len(src)
+    gs = [None if g is None else g.float().contiguous() for g in grads]
+    dx = empty(x.shape, dtype=torch.float32, device=x.device)
+    dscale = torch.zeros(S_out, x.shape[2], dtype=torch.float32, device=x.device)
+    args = _planes_args(x, scale, src, raw, one_cols, want_dscale)
+    for s_, g in enumerate(gs):
+        if g is not None:
+            assert g.shape == (x.shape[2], x.shape[0], 32)
+            args.dy[s_] = g.data_ptr()
+    args.dx, args.dscale = _ptr(dx), _ptr(dscale)
+    with _timed("head_planes_bwd"):
+        L.check(L.lib().grl_head_planes_bwd(L.stream_ptr(), C.byref(args)), "grl_head_planes_bwd")
+    return dx, dscale

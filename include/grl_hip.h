@@ -524,6 +524,29 @@ typedef struct GrlLnTrainArgs {
 int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args);
 int grl_layernorm_bwd(void* stream, const GrlLnTrainArgs* args);
 
+/* Head planes of the training path (ABI 21): projection output x [T, S_in, nh, d] (fp32) -> the attention operands, fp32 planes
+ * out32 [S_out][nh][T][32] and their fp16 copy out16, forward; dx and the scale gradients, backward.
+ *   replaces F.normalize(q) * exp(min(logit_scale, ln 100)), F.normalize(k) and the head reshape / permute of
+ *   models/common/mixed_attn_block_efficient.py:36-47,85-90,147-150,240-250 and autograd through them.
+ * Output slot s reads input slot src[s];  raw[s] != 0: copied as it is (v), else y = x * scale[s][h] / max(|x|, 1e-12);
+ * one_col[s] >= 0: that column of the plane holds 1.0 (pad columns are otherwise 0).  d even, <= 32; S_in, S_out, nh <= 8.
+ * Backward: dy[s] = gradient of output slot s as an fp32 plane [nh][T][32] (NULL: none); dx [T, S_in, nh, d] is written, dscale
+ * [S_out][nh] ACCUMULATED (zero it first) for the slots with want_dscale[s] != 0. */
+typedef struct GrlPlanesArgs {
+    const float* x;
+    const float* scale;      /* [S_out][nh] (ignored for raw slots) */
+    float* out32;            /* forward */
+    void* out16;             /* forward: fp16 [S_out][nh][T][32] */
+    const float* dy[8];      /* backward */
+    float* dx;
+    float* dscale;
+    int32_t T, S_in, S_out, nh, d;
+    int32_t src[8], raw[8], one_col[8], want_dscale[8];
+} GrlPlanesArgs;
+
+int grl_head_planes_fwd(void* stream, const GrlPlanesArgs* args);
+int grl_head_planes_bwd(void* stream, const GrlPlanesArgs* args);
+
 /* Relative-position bias tables for MANY AffineTransforms at once, forward and backward (ABI 21, training path):
  *   replaces  16 * sigmoid(cpb_mlp(relative_coords_table))  models/common/mixed_attn_block_efficient.py:23-34,49-58  (cpb_mlp =
  *   Linear(2, 512, bias) -> ReLU -> Linear(512, nh, no bias)) and autograd through it, without the [G, rows, 512] hidden layer in

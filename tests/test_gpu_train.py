@@ -293,3 +293,41 @@ def test_layernorm_train_kernels_match_torch(M, n):
     errs = dict(dx=_rel(xd.grad, xr.grad), dgamma=_rel(gd.grad, gr.grad), dbeta=_rel(bd.grad, br.grad))
     print(f"layernorm M={M} n={n}: {errs}")
     assert max(errs.values()) < 5e-6, errs
+
+
+@pytest.mark.parametrize("T,nh,d,anchors", [(1000, 3, 30, False), (257, 3, 30, True), (512, 2, 32, False), (300, 2, 16, True)])
+def test_head_planes_kernels_match_the_torch_chain(T, nh, d, anchors, monkeypatch):
+    """grl_head_planes_fwd / _bwd (csrc/planes.hip: normalise, scale, pad constants, permute, fp16 copy in one launch; dx and the
+    logit-scale gradients in another) against GRL._block_planes' torch chain (GRL_PLANES_KERNEL=0) in float64-checked fp32."""
+    from grl_image_restoration_amd import GRL, make_config
+
+    m = GRL(**make_config("tiny", "yaml", upscale=2, img_size=16, depths=[1], num_heads_window=[2], num_heads_stripe=[2]))
+    g = torch.Generator().manual_seed(63)
+    k1, v1 = (31 if d <= 30 else -1), (d if d < 32 else -1)
+    ones = torch.ones(nh, device="cuda")
+    if anchors:
+        x0 = torch.randn(T, 1, nh, d, generator=g).cuda()
+        S, one_cols = 2, (-1, k1)
+    else:
+        x0 = torch.randn(T, 6, nh, d, generator=g).cuda()
+        S, one_cols = 6, (-1, k1, v1, -1, k1, v1)
+    s_a, s_b = (torch.rand(nh, generator=g) * 100 + 5).cuda(), (torch.rand(nh, generator=g) * 100 + 5).cuda()
+    grads = [(torch.randn(nh, T, 32, generator=g) * 1e-6).cuda() for _ in range(S)]
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GRL_PLANES_KERNEL", mode)
+        x = x0.clone().requires_grad_(True)
+        sa, sb = s_a.clone().requires_grad_(True), s_b.clone().requires_grad_(True)
+        scales = (sa, ones) if anchors else (sa, ones, None, sb, ones, None)
+        p32, p16 = m._block_planes(x.expand(-1, 2, nh, d) if anchors else x, scales, one_cols)
+        assert len(p32) == len(p16) == S and all(t.shape == (nh, T, 32) for t in p32) and all(t.dtype == torch.float16 for t in p16)
+        sum((a * b).sum() for a, b in zip(p32, grads)).backward()
+        res[mode] = ([t.detach().clone() for t in p32], [t.detach().clone() for t in p16], x.grad.clone(), sa.grad.clone(),
+                     None if anchors else sb.grad.clone())
+    for a, b in zip(res["0"][0], res["1"][0]):
+        assert (a - b).abs().max().item() <= 2e-5 * max(1.0, a.abs().max().item())
+    for a, b in zip(res["0"][1], res["1"][1]):
+        assert (a.float() - b.float()).abs().max().item() <= 1e-3 * max(1.0, a.float().abs().max().item())     # (fp16 roundings may differ by one ulp)
+    assert _rel(res["1"][2], res["0"][2]) < 1e-5 and _rel(res["1"][3], res["0"][3]) < 1e-4
+    if not anchors:
+        assert _rel(res["1"][4], res["0"][4]) < 1e-4
