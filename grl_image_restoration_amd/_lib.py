@@ -42,6 +42,7 @@ EXPORTS = [
     "grl_adamw_step",
     "grl_layernorm_train_fwd",
     "grl_layernorm_bwd",
+    "grl_pack_conv3x3",
     "grl_head_planes_fwd",
     "grl_head_planes_bwd",
     "grl_cpb_table_fwd",
@@ -493,6 +494,8 @@ def lib():
     L.grl_layernorm_train_fwd.restype = C.c_int
     L.grl_layernorm_bwd.argtypes = [C.c_void_p, C.POINTER(GrlLnTrainArgs)]
     L.grl_layernorm_bwd.restype = C.c_int
+    L.grl_pack_conv3x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.grl_pack_conv3x3.restype = C.c_int
     L.grl_head_planes_fwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]
     L.grl_head_planes_fwd.restype = C.c_int
     L.grl_head_planes_bwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]

@@ -283,7 +283,8 @@ def conv3x3_op(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, B: int, H: int
     CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
     xp = _padded(x.detach().float(), CinP, ones=True)   # (the ones column meets zero weight columns; see _padded)
     _leave_operand(x, xp)
-    y = ops.conv3x3(xp, ops.pack_conv_weight(w.detach(), CinP, CoutP), ops.pack_conv_bias(b.detach(), CoutP), B, H, W)
+    wp, bp = ops.pack_conv_train(w, b, CoutP, CinP)           # one launch (round 6; torch chain: pack_conv_weight + pack_conv_bias)
+    y = ops.conv3x3(xp, wp, bp, B, H, W)
     return y[:, :Cout].contiguous()
 
 
@@ -310,7 +311,7 @@ def _conv_backward(ctx, dy):
     if ctx.needs_input_grad[0]:
         # data gradient = the same convolution with the taps flipped and the channel roles swapped
         gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
-        wt = ops.pack_conv_weight(w.detach().flip(2, 3).transpose(0, 1).contiguous(), gin, gout)
+        wt, _ = ops.pack_conv_train(w, None, gout, gin, flip_t=True)
         dyp = _padded(dy.float(), gin)
         dx = ops.conv3x3(dyp, wt, _zeros(gout, dy.device), B, H, W, x_scale=s, out_scale=1.0 / s)[:, :Cin]
     want_b = ctx.needs_input_grad[2]

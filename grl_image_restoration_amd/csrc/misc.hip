@@ -114,6 +114,39 @@ extern "C" int grl_layernorm_fwd(void* stream, const float* x, int64_t ldx, floa
     return 0;
 }
 
+// torch conv weight [Cout][Cin][3][3] (fp32) -> the layout grl_conv3x3_fwd reads, fp16 [9 taps][rows_pad][cols_pad] (tap = ky*3+kx),
+// zero padded, and the padded fp32 bias, in ONE launch.  flip_t: the DATA-GRADIENT form of the same convolution -- taps flipped,
+// channel roles swapped: out[tap][ci][co] = w[co][ci][2-ky][2-kx].  The training path packs every convolution's weights twice per
+// step (they move every step); as torch code (permute + copy, zeros, slice assignment, fp16 copy; flip + transpose + copy for
+// the gradient form) that was 4-7 launches each, ~700 of a captured step's ~10 k kernel nodes.
+namespace {
+__global__ __launch_bounds__(256) void pack_conv_kernel(const float* __restrict__ w, const float* __restrict__ b, f16* __restrict__ ow,
+                                                        float* __restrict__ ob, int Cout, int Cin, int rows_pad, int cols_pad, int flip_t) {
+    const int total = 9 * rows_pad * cols_pad;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int col = i % cols_pad, row = (i / cols_pad) % rows_pad, tap = i / (cols_pad * rows_pad);
+        const int co = flip_t ? col : row, ci = flip_t ? row : col;
+        const int src_tap = flip_t ? 8 - tap : tap;
+        float v = 0.f;
+        if (co < Cout && ci < Cin) v = w[((int64_t)co * Cin + ci) * 9 + src_tap];
+        ow[i] = (f16)v;
+    }
+    if (ob != nullptr)
+        for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows_pad; i += gridDim.x * blockDim.x)
+            ob[i] = (b != nullptr && i < Cout) ? b[i] : 0.f;
+}
+}  // namespace
+
+extern "C" int grl_pack_conv3x3(void* stream, const float* w, const float* b, void* out_w, float* out_b, int32_t Cout, int32_t Cin,
+                                int32_t rows_pad, int32_t cols_pad, int32_t flip_t) {
+    if (!w || !out_w || Cout <= 0 || Cin <= 0 || rows_pad < (flip_t ? Cin : Cout) || cols_pad < (flip_t ? Cout : Cin)) return GRL_ERR_BAD_ARG;
+    const int total = 9 * rows_pad * cols_pad;
+    hipLaunchKernelGGL(pack_conv_kernel, dim3((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024), dim3(256), 0, (hipStream_t)stream, w, b,
+                       (f16*)out_w, out_b, Cout, Cin, rows_pad, cols_pad, flip_t);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
 // Debug aid (GRL_DIRTY_LDS=1 in the Python wrappers calls it before every C-ABI launch): overwrites the LDS of every CU with
 // 0xFF bytes (fp32 / fp16 NaN).  LDS is not cleared between workgroups, so a kernel that reads a location it has not written sees
 // whatever the previous workgroup on that CU left there -- zeros or finite numbers most of the time, which hides the bug and makes

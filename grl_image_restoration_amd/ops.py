@@ -916,3 +916,18 @@ def head_planes_bwd(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols, gr
     with _timed("head_planes_bwd"):
         L.check(L.lib().grl_head_planes_bwd(L.stream_ptr(), C.byref(args)), "grl_head_planes_bwd")
     return dx, dscale
+
+
+def pack_conv_train(w: torch.Tensor, b: Optional[torch.Tensor], rows_pad: int, cols_pad: int, flip_t: bool = False):
+    """grl_pack_conv3x3: (fp16 [9, rows_pad, cols_pad], fp32 bias [rows_pad] or None) of a conv weight [Cout, Cin, 3, 3] in ONE launch --
+    what pack_conv_weight / pack_conv_bias give for the plain layout, or with ``flip_t`` the operand of the data-gradient convolution
+    (taps flipped, channel roles swapped)."""
+    _dev_check(w, b)
+    Cout, Cin = w.shape[:2]
+    wc = w.detach().float().contiguous()
+    bc = None if b is None else b.detach().float().contiguous()
+    ow = empty(9, rows_pad, cols_pad, dtype=GEMM_DTYPE, device=w.device)
+    ob = empty(rows_pad, dtype=torch.float32, device=w.device) if (b is not None or not flip_t) else None
+    L.check(L.lib().grl_pack_conv3x3(L.stream_ptr(), _ptr(wc), _ptr(bc), _ptr(ow), _ptr(ob), Cout, Cin, rows_pad, cols_pad, int(flip_t)),
+            "grl_pack_conv3x3")
+    return ow, ob

@@ -524,6 +524,14 @@ typedef struct GrlLnTrainArgs {
 int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args);
 int grl_layernorm_bwd(void* stream, const GrlLnTrainArgs* args);
 
+/* Weight / bias packing of a 3x3 convolution for grl_conv3x3_fwd in one launch (ABI 21, training path: the weights move every step):
+ *   w [Cout][Cin][3][3] fp32 (nn.Conv2d.weight: grl.py:137,293,348; mixed_attn_block.py:970-983) -> out_w fp16 [9][rows_pad][cols_pad],
+ *   tap = ky*3+kx, zero padded; flip_t = 0: rows = output channels, columns = input channels (the forward operand);
+ *   flip_t = 1: the data-gradient operand out_w[tap][ci][co] = w[co][ci][2-ky][2-kx] (rows = Cin side, columns = Cout side).
+ *   out_b (optional): fp32 [rows_pad] = b padded with zeros (b may be NULL: all zeros). */
+int grl_pack_conv3x3(void* stream, const float* w, const float* b, void* out_w, float* out_b, int32_t Cout, int32_t Cin,
+                     int32_t rows_pad, int32_t cols_pad, int32_t flip_t);
+
 /* Head planes of the training path (ABI 21): projection output x [T, S_in, nh, d] (fp32) -> the attention operands, fp32 planes
  * out32 [S_out][nh][T][32] and their fp16 copy out16, forward; dx and the scale gradients, backward.
  *   replaces F.normalize(q) * exp(min(logit_scale, ln 100)), F.normalize(k) and the head reshape / permute of

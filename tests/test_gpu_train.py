@@ -331,3 +331,18 @@ def test_head_planes_kernels_match_the_torch_chain(T, nh, d, anchors, monkeypatc
     assert _rel(res["1"][2], res["0"][2]) < 1e-5 and _rel(res["1"][3], res["0"][3]) < 1e-4
     if not anchors:
         assert _rel(res["1"][4], res["0"][4]) < 1e-4
+
+
+@pytest.mark.parametrize("Cout,Cin", [(180, 180), (45, 180), (180, 45), (64, 3), (3, 64)])
+def test_pack_conv_train_matches_the_torch_packing(Cout, Cin):
+    """grl_pack_conv3x3 (one launch) against ops.pack_conv_weight / pack_conv_bias, plain and in the data-gradient form."""
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(64)
+    w, b = torch.randn(Cout, Cin, 3, 3, generator=g).cuda(), torch.randn(Cout, generator=g).cuda()
+    CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
+    wp, bp = ops.pack_conv_train(w, b, CoutP, CinP)
+    assert torch.equal(wp, ops.pack_conv_weight(w, CinP, CoutP)) and torch.equal(bp, ops.pack_conv_bias(b, CoutP))
+    gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
+    wt, none = ops.pack_conv_train(w, None, gout, gin, flip_t=True)
+    assert none is None and torch.equal(wt, ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous(), gin, gout))
