@@ -9,7 +9,7 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
-ABI_VERSION = 21
+ABI_VERSION = 22
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
 EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
@@ -100,6 +100,10 @@ class GrlLinearArgs(_Strict):
         ("out_plane_stride", C.c_int64),
         ("out_lo", C.c_void_p),
         ("w_regs", C.c_void_p),
+        ("a_cols", C.c_int32),
+        ("a_one", C.c_int32),
+        ("n_store", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -283,6 +287,8 @@ class GrlConvArgs(_Strict):
         ("shuffle_r", C.c_int32),
         ("shuffle_cg", C.c_int32),
         ("shuffle_ij0", C.c_int32),
+        ("x_cols", C.c_int32),
+        ("n_store", C.c_int32),
     ]
 
 
@@ -329,6 +335,10 @@ class GrlGemmTnArgs(_Strict):
         ("ldc", C.c_int64),
         ("c_tap_stride", C.c_int64),
         ("c_fix", C.c_void_p),
+        ("b_ones", C.c_int32),
+        ("reserved0", C.c_int32),
+        ("c_bias", C.c_void_p),
+        ("c_bias_fix", C.c_void_p),
     ]
 
 

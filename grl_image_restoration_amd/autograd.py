@@ -214,24 +214,53 @@ def _take_operand(x):
     return slot[3] if slot[:3] == key else None
 
 
-def _linear_operands(x, w, b):
-    M, K = x.shape
-    N = w.shape[0]
-    Kp, Np = pad_width(K), pad_width(N)
-    xp = _padded(x.detach().float(), Kp, ones=True)
-    wp = _padded_weight(w, Np, Kp)
-    bp = _zeros(Np, x.device)
+def _rows16(t: torch.Tensor) -> torch.Tensor:
+    """fp32 matrix whose rows the kernels can read in 16-byte pieces where it lies: unit column stride, row stride a multiple of 4,
+    16-byte aligned base (a narrow() of a wider matrix qualifies); anything else is copied."""
+    t = t.float()
+    if t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16 or t.stride(0) < t.shape[1]:
+        t = t.contiguous()
+    return t
+
+
+# Round 6: operands and results at their REAL widths.  The kernels used to want every token matrix padded to their channel multiple
+# (C = 180 -> 192): one cat per operand on the way in, one strided copy per result on the way out -- ~650 cats and ~600 copies of a
+# captured step's ~10 k nodes, 18 ms of 117.  GrlLinearArgs.a_cols / n_store, GrlConvArgs.x_cols / n_store and GrlGemmTnArgs.b_ones
+# (ABI 22) let the loaders supply the pad columns as constants and the epilogues skip them, for widths that are multiples of 4
+# (16-byte pieces); other widths (the 90-wide anchor projection, the 45-wide CAB bottleneck) keep the padded path.
+# GRL_REAL_WIDTHS=0: the padded path everywhere (A/B timing, and the reference the tests compare the new path with).
+def _real(n: int, npad: int) -> bool:
+    return n % 4 == 0 and n < npad and _REAL_WIDTHS[0]
+
+
+_REAL_WIDTHS = [__import__("os").environ.get("GRL_REAL_WIDTHS", "1") != "0"]
+
+
+def _bias_padded(b, N, Np, device):
+    bp = _zeros(Np, device)
     if b is not None:
-        bp = torch.cat([b.detach().float(), _zeros(Np - N, x.device)]) if Np > N else b.detach().float()
-    return xp, wp, bp, (M, K, N, Kp, Np)
+        bp = torch.cat([b.detach().float(), _zeros(Np - N, device)]) if Np > N else b.detach().float()
+    return bp
 
 
 @torch.library.custom_op("grl::linear", mutates_args=())
 def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
     """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in grl_linear_fwd)."""
-    xp, wp, bp, (M, K, N, Kp, Np) = _linear_operands(x, w, b)
-    _leave_operand(x, xp)
-    return ops.linear(xp, wp, bp, out_dtype=torch.float32)[:, :N].contiguous()
+    M, K = x.shape
+    N = w.shape[0]
+    Kp, Np = pad_width(K), pad_width(N)
+    wp = _padded_weight(w, Np, Kp)
+    bp = _bias_padded(b, N, Np, x.device)
+    if _real(K, Kp):
+        xa, kw = _rows16(x.detach()), dict(a_cols=K, a_one=True)      # (the ones column meets a zero weight column)
+        _leave_operand(x, xa)
+    else:
+        xa, kw = _padded(x.detach().float(), Kp, ones=True), {}
+        _leave_operand(x, xa)
+    if _real(N, Np):
+        return ops.linear(xa, wp, bp, out_dtype=torch.float32, n_store=N, **kw)
+    y = ops.linear(xa, wp, bp, out_dtype=torch.float32, **kw)
+    return y if N == Np else y[:, :N].contiguous()
 
 
 @linear_op.register_fake
@@ -242,10 +271,11 @@ def _(x, w, b):
 def _linear_setup(ctx, inputs, output):
     x, w, b = inputs
     xp = _take_operand(x)
-    # the padded operand [x | 1 | 0] of the forward launch is all the backward needs of x: saved INSTEAD of x (both were
-    # kept, doubling the saved activation of every layer whose width is not a kernel width -- C = 180 in all GRL-Base blocks)
+    # the operand the forward launch read -- [x | 1 | 0], or x itself where the kernels take real widths -- is all the backward needs
+    # of x: saved INSTEAD of x (both were kept, doubling the saved activation of every layer whose width is not a kernel
+    # width -- C = 180 in all GRL-Base blocks)
     ctx.save_for_backward(xp if xp is not None else x, w)
-    ctx.x_shape, ctx.padded = tuple(x.shape), xp is not None
+    ctx.x_shape, ctx.padded = tuple(x.shape), xp is not None and xp.shape[1] != x.shape[1]
     ctx.has_b = b is not None
 
 
@@ -254,20 +284,38 @@ def _linear_backward(ctx, dy):
     M, K = ctx.x_shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
-    xp = xs if ctx.padded else _padded(xs.detach().float(), Kp, ones=True)
+    rk, rn = _real(K, Kp), _real(N, Np)
     s = grad_scale(dy.device)
-    dyp = _padded(dy.float(), Np)
+    if rn:
+        dya, dkw = _rows16(dy), dict(a_cols=N)
+    else:
+        dya, dkw = _padded(dy.float(), Np), {}
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
         wt = _padded_weight(w, Np, Kp, transposed=True)            # [Kp, Np]: rows = input channels
-        dx = ops.linear(dyp, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s)[:, :K]
+        if rk:
+            dx = ops.linear(dya, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s, n_store=K, **dkw)
+        else:
+            dx = ops.linear(dya, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s, **dkw)[:, :K]
     want_b = ctx.has_b and ctx.needs_input_grad[2]
     if ctx.needs_input_grad[1] or (want_b and Kp > K):
-        full = ops.gemm_tn(dyp, xp, Np, Kp, a_scale=s, out_scale=1.0 / s)[0]
+        if ctx.padded:
+            xb = xs                                                  # [x | 1 | 0] of the forward launch
+        elif rk:
+            xb = _rows16(xs.detach())                                # x at its real width; the ones column is virtual
+        else:
+            xb = _padded(xs.detach().float(), Kp, ones=True)
+        virt = xb.shape[1] == K and Kp > K and rk                    # bias gradient from the virtual ones column
+        Ng, Kg = (N if rn else Np), (K if xb.shape[1] == K else Kp)
+        if virt and want_b:
+            full, cb = ops.gemm_tn(dya, xb, Ng, Kg, a_scale=s, out_scale=1.0 / s, b_ones=True)
+            db = cb[:N]
+        else:
+            full = ops.gemm_tn(dya, xb, Ng, Kg, a_scale=s, out_scale=1.0 / s)
+            if want_b and Kg > K:
+                db = full[0][:N, K]                                  # the ones column of [x | 1 | 0]: sum over the rows of dy
         if ctx.needs_input_grad[1]:
-            dw = full[:N, :K]
-        if want_b and Kp > K:
-            db = full[:N, K]                                       # the ones column of xp: sum over the rows of dy
+            dw = full[0][:N, :K]                                     # (contiguous -- adopted as .grad without a copy -- when Kg == K)
     if want_b and db is None:
         db = dy.float().sum(0)
     return dx, dw, db
@@ -276,16 +324,27 @@ def _linear_backward(ctx, dy):
 linear_op.register_autograd(_linear_backward, setup_context=_linear_setup)
 
 
+def _conv_pads(Cin: int, Cout: int):
+    CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
+    keep192 = CinP == 192 and CoutP == 192        # csrc/conv192.hip's shape (stage / after-body convolutions): it reads padded rows
+    return CinP, CoutP, keep192
+
+
 @torch.library.custom_op("grl::conv3x3", mutates_args=())
 def conv3x3_op(x: torch.Tensor, w: torch.Tensor, b: torch.Tensor, B: int, H: int, W: int) -> torch.Tensor:
     """3x3 convolution, stride 1, zero pad 1, on channels-last token matrices x[B*H*W, Cin] -> [B*H*W, Cout] (grl_conv3x3_fwd)."""
     Cout, Cin = w.shape[:2]
-    CinP, CoutP = (Cin + 31) // 32 * 32, (Cout + 15) // 16 * 16
-    xp = _padded(x.detach().float(), CinP, ones=True)   # (the ones column meets zero weight columns; see _padded)
-    _leave_operand(x, xp)
+    CinP, CoutP, keep192 = _conv_pads(Cin, Cout)
     wp, bp = ops.pack_conv_train(w, b, CoutP, CinP)           # one launch (round 6; torch chain: pack_conv_weight + pack_conv_bias)
-    y = ops.conv3x3(xp, wp, bp, B, H, W)
-    return y[:, :Cout].contiguous()
+    if _real(Cin, CinP) and not keep192:
+        xa, kw = _rows16(x.detach()), dict(x_cols=Cin)
+    else:
+        xa, kw = _padded(x.detach().float(), CinP, ones=True), {}   # (the ones column meets zero weight columns; see _padded)
+    _leave_operand(x, xa)
+    if _real(Cout, CoutP) and not keep192:
+        return ops.conv3x3(xa, wp, bp, B, H, W, n_store=Cout, **kw)
+    y = ops.conv3x3(xa, wp, bp, B, H, W, **kw)
+    return y if Cout == CoutP else y[:, :Cout].contiguous()
 
 
 @conv3x3_op.register_fake
@@ -297,7 +356,7 @@ def _conv_setup(ctx, inputs, output):
     x, w, b, B, H, W = inputs
     xp = _take_operand(x)
     ctx.save_for_backward(xp if xp is not None else x, w)      # (see _linear_setup)
-    ctx.padded = xp is not None
+    ctx.padded = xp is not None and xp.shape[1] != x.shape[1]
     ctx.bhw = (B, H, W)
 
 
@@ -305,25 +364,45 @@ def _conv_backward(ctx, dy):
     xs, w = ctx.saved_tensors
     B, H, W = ctx.bhw
     Cout, Cin = w.shape[:2]
-    CinP = (Cin + 31) // 32 * 32
+    CinP, CoutP, keep192 = _conv_pads(Cin, Cout)
     s = grad_scale(dy.device)
     dx = dw = db = None
     if ctx.needs_input_grad[0]:
         # data gradient = the same convolution with the taps flipped and the channel roles swapped
         gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
+        g192 = gin == 192 and gout == 192
         wt, _ = ops.pack_conv_train(w, None, gout, gin, flip_t=True)
-        dyp = _padded(dy.float(), gin)
-        dx = ops.conv3x3(dyp, wt, _zeros(gout, dy.device), B, H, W, x_scale=s, out_scale=1.0 / s)[:, :Cin]
+        if _real(Cout, gin) and not g192:
+            dya, kw = _rows16(dy), dict(x_cols=Cout)
+        else:
+            dya, kw = _padded(dy.float(), gin), {}
+        if _real(Cin, gout) and not g192:
+            dx = ops.conv3x3(dya, wt, _zeros(gout, dy.device), B, H, W, x_scale=s, out_scale=1.0 / s, n_store=Cin, **kw)
+        else:
+            dx = ops.conv3x3(dya, wt, _zeros(gout, dy.device), B, H, W, x_scale=s, out_scale=1.0 / s, **kw)[:, :Cin]
     want_b = ctx.needs_input_grad[2]
     if ctx.needs_input_grad[1] or (want_b and CinP > Cin):
         n8 = (Cout + 7) // 8 * 8
-        dyp = _padded(dy.float(), n8)
-        xp = xs if ctx.padded else _padded(xs.detach().float(), CinP, ones=True)
-        c = ops.gemm_tn(dyp, xp, n8, CinP, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s)      # [9, n8, CinP]
+        rn = Cout % 4 == 0 and _REAL_WIDTHS[0]
+        dya = _rows16(dy) if rn else _padded(dy.float(), n8)
+        Ng = Cout if rn else n8
+        if ctx.padded:
+            xb = xs
+        elif _real(Cin, CinP) and not keep192:
+            xb = _rows16(xs.detach())
+        else:
+            xb = _padded(xs.detach().float(), CinP, ones=True)
+        virt = xb.shape[1] == Cin and CinP > Cin
+        Kg = Cin if xb.shape[1] == Cin else CinP
+        if virt and want_b:
+            c, cb = ops.gemm_tn(dya, xb, Ng, Kg, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s, b_ones=True)   # [9, Ng, Kg], [Ng]
+            db = cb[:Cout]
+        else:
+            c = ops.gemm_tn(dya, xb, Ng, Kg, taps=9, hw=(H, W), a_scale=s, out_scale=1.0 / s)
+            if want_b and Kg > Cin:
+                db = c[4, :Cout, Cin]          # centre tap against the ones column of [x | 1 | 0]: sum of dy over all pixels
         if ctx.needs_input_grad[1]:
             dw = c[:, :Cout, :Cin].reshape(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
-        if want_b and CinP > Cin:
-            db = c[4, :Cout, Cin]          # centre tap against the ones column of xp: sum of dy over all pixels
     if want_b and db is None:
         db = dy.float().sum(0)
     return dx, dw, db, None, None, None
@@ -383,11 +462,16 @@ def _attn_setup(ctx, inputs, output):
     q16, k16, v16 = (i if i is not None else t for i, t in zip((q16_in, k16_in, v16_in), (q16, k16, v16)))
     ctx.save_for_backward(q16, k16, v16, table, o, lse)
     ctx.geo = (tuple(qgeo), tuple(kgeo), B, nh, d, masked)
+    # only `o` carries a gradient: without this autograd hands the backward a zero tensor per unused output (lse and up to three
+    # fp16 operand planes of 6 MB each, per call -- ~300 fills per training step)
+    ctx.set_materialize_grads(False)
 
 
 def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
     q16, k16, v16, table, o, lse = ctx.saved_tensors
     qgeo, kgeo, B, nh, d, masked = ctx.geo
+    if d_o is None:                      # (set_materialize_grads(False): the output took no part in the loss)
+        return (None,) * 15
     TG = ops.TokenGrid
     dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o.float().contiguous(),
                                          lse, B=B, nh=nh, table=table.detach().contiguous(), masked=masked, ones_col=d if d < 32 else -1,
@@ -410,6 +494,7 @@ class HeadPlanesFn(torch.autograd.Function):
         ctx.cfg = (tuple(src), tuple(raw), tuple(one_cols))
         p32, p16 = out32.unbind(0), out16.unbind(0)
         ctx.mark_non_differentiable(*p16)
+        ctx.set_materialize_grads(False)     # (no zero tensors for the fp16 copies / unused planes: head_planes_bwd takes None)
         return (*p32, *p16)
 
     @staticmethod

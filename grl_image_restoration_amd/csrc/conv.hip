@@ -100,7 +100,13 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                     v = *(const gemm_x8*)((const gemm_t*)p.x + row * p.ldx + ch0);
                 } else {
                     const float4* q = (const float4*)((const float*)p.x + row * p.ldx + ch0);
-                    const float4 a0 = q[0], a1 = q[1];
+                    float4 a0, a1;
+                    if (p.x_cols > 0) {   // input at its real width: channels >= x_cols read as zeros
+                        a0 = ch0 < p.x_cols ? q[0] : float4{0, 0, 0, 0};
+                        a1 = ch0 + 4 < p.x_cols ? q[1] : float4{0, 0, 0, 0};
+                    } else {
+                        a0 = q[0]; a1 = q[1];
+                    }
                     const float e[8] = {a0.x * xsc, a0.y * xsc, a0.z * xsc, a0.w * xsc, a1.x * xsc, a1.y * xsc, a1.z * xsc, a1.w * xsc};
 #pragma unroll
                     for (int i = 0; i < 8; ++i) v[i] = to_f16(e[i]);
@@ -253,7 +259,7 @@ __global__ __launch_bounds__(CWAVES * 64) void conv3x3_kernel(GrlConvArgs p) {
                     keep = ij < r * r;  // channel slots beyond r*r sub-pixels are padding
                     orow = ((int64_t)b * p.H * r + (gy * r + ij / r)) * (p.W * r) + (gx * r + ij % r);
                 }
-                if (!keep) {
+                if (!keep || (p.n_store > 0 && oc >= p.n_store)) {   // (n_store: result at its real width)
                 } else if (p.out_dtype != GRL_DT_F32) {
                     uint2 pk;
                     pk.x = pack_f16(v[0], v[1]);
@@ -379,7 +385,10 @@ int grl_conv192_launch(const GrlConvArgs& p, hipStream_t st);
 extern "C" int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args) {
     const GrlConvArgs& p = *args;
     if (p.B <= 0 || p.H <= 0 || p.W <= 0) return GRL_ERR_BAD_ARG;
-    if (p.CinP % 32 || p.CoutP % 16 || p.CoutP > 192 || (p.ldx % 8) || (p.ldo % 4)) return GRL_ERR_BAD_ARG;
+    if (p.CinP % 32 || p.CoutP % 16 || p.CoutP > 192 || (p.ldx % (p.x_cols > 0 ? 4 : 8)) || (p.ldo % 4)) return GRL_ERR_BAD_ARG;
+    if (p.x_cols < 0 || p.n_store < 0) return GRL_ERR_BAD_ARG;
+    if (p.x_cols > 0 && ((p.x_cols % 4) || p.x_cols > p.CinP || p.ldx < p.x_cols || p.x_dtype != GRL_DT_F32 || p.x_split >= 2)) return GRL_ERR_BAD_ARG;
+    if (p.n_store > 0 && ((p.n_store % 4) || p.n_store > p.CoutP || p.ldo < p.n_store || p.out_dtype != GRL_DT_F32 || p.shuffle_r > 1)) return GRL_ERR_BAD_ARG;
     if (p.x_split < 0 || p.x_split > 3) return GRL_ERR_BAD_ARG;
     if (p.x_split >= 2 && (p.x_dtype != GRL_DT_F32 || p.CinP % (8 * p.x_split) != 0)) return GRL_ERR_BAD_ARG;   // parts are whole 8-channel segments
     if (p.pool_partial != nullptr && p.pool_stride < p.CoutP) return GRL_ERR_BAD_ARG;

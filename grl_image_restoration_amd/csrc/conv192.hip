@@ -263,7 +263,7 @@ __global__ __launch_bounds__(C9_THREADS) void conv192_kernel(GrlConvArgs p) {
 bool grl_conv192_supported(const GrlConvArgs& p) {
     return p.CinP == C9_C && p.CoutP == C9_C && (p.CinP % C9_GC) == 0 && p.x_dtype == GRL_DT_F32 && p.out_dtype == GRL_DT_F32 && p.x_split <= 1 && p.act == 0 &&
            p.shuffle_r <= 1 && p.pool_partial == nullptr && (p.x_scale == 0.0f || p.x_scale == 1.0f) && (p.ldx % 4) == 0 && (p.ldo % 4) == 0 &&
-           (p.resid == nullptr || (p.ldr % 4) == 0) && p.w_tap_stride == (int64_t)C9_C * C9_C;
+           (p.resid == nullptr || (p.ldr % 4) == 0) && p.w_tap_stride == (int64_t)C9_C * C9_C && p.x_cols == 0 && p.n_store == 0;
 }
 
 int grl_conv192_launch(const GrlConvArgs& p, hipStream_t st) {

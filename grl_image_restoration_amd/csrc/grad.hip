@@ -24,13 +24,15 @@ constexpr int GT = 64;        // output tile side
 constexpr int GM = 32;        // rows (reduction) per LDS piece
 constexpr int GROW = GT * 2;  // bytes per LDS row (64 fp16), XOR-swizzled in 16-B segments by row
 
-__device__ __forceinline__ f16x8 load8_f16(const void* base, int dtype, int64_t off, float scale) {
-    f16x8 v;
+// 8 operand values from column `off` on; `nv` of them exist (8, 4 or 0: widths are multiples of 4, nothing is read beyond a row's end)
+__device__ __forceinline__ f16x8 load8_f16(const void* base, int dtype, int64_t off, float scale, int nv) {
+    f16x8 v = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (nv <= 0) return v;
     if (dtype == GRL_DT_F16) {
         v = *(const f16x8*)((const f16*)base + off);
     } else {
         const float4* q = (const float4*)((const float*)base + off);
-        const float4 a0 = q[0], a1 = q[1];
+        const float4 a0 = q[0], a1 = nv > 4 ? q[1] : float4{0, 0, 0, 0};
         v[0] = to_f16(a0.x * scale); v[1] = to_f16(a0.y * scale); v[2] = to_f16(a0.z * scale); v[3] = to_f16(a0.w * scale);
         v[4] = to_f16(a1.x * scale); v[5] = to_f16(a1.y * scale); v[6] = to_f16(a1.z * scale); v[7] = to_f16(a1.w * scale);
     }
@@ -61,7 +63,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
         const int m = pc * GM + srow;
         f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0}, bv = av;
         if (m < p.M) {
-            if (n0 + sseg * 8 < p.N) av = load8_f16(p.a, GRL_DT_F32, (int64_t)m * p.lda + n0 + sseg * 8, p.a_scale);
+            av = load8_f16(p.a, GRL_DT_F32, (int64_t)m * p.lda + n0 + sseg * 8, p.a_scale, p.N - (n0 + sseg * 8));
             int64_t brow = m;
             bool inside = true;
             if (p.taps == 9) {   // image shift: B row of pixel (y + dy, x + dx), zero outside the image
@@ -69,7 +71,14 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
                 inside = (unsigned)(y + dy) < (unsigned)p.H && (unsigned)(x + dx) < (unsigned)p.W;
                 brow = (int64_t)m + dy * p.W + dx;
             }
-            if (inside && k0 + sseg * 8 < p.K) bv = load8_f16(p.b, p.b_dtype, brow * p.ldb + k0 + sseg * 8, 1.0f);
+            const int kc = k0 + sseg * 8;
+            if (inside) {
+                bv = load8_f16(p.b, p.b_dtype, brow * p.ldb + kc, 1.0f, p.K - kc);
+                if (p.b_ones) {   // the virtual ones column (bias gradient); K and kc are multiples of 4 / 8: slot 0 or 4
+                    if (p.K == kc) bv[0] = (f16)1.0f;
+                    else if (p.K == kc + 4) bv[4] = (f16)1.0f;
+                }
+            }
         }
         __syncthreads();   // previous piece's readers are done
         *(f16x8*)(As + srow * GROW + ((sseg ^ (srow & 7)) << 4)) = av;
@@ -117,6 +126,11 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
                           (unsigned long long)(long long)__float2ll_rn(acc[r] * 1073741824.0f));
             else
                 unsafeAtomicAdd(c + (int64_t)n * p.ldc + k, acc[r] * p.out_scale);
+        } else if (n < p.N && k == p.K && p.b_ones && (p.taps == 1 || tap == 4)) {   // column sums of a: the bias gradient
+            if (p.c_bias_fix != nullptr)
+                atomicAdd((unsigned long long*)(p.c_bias_fix + n), (unsigned long long)(long long)__float2ll_rn(acc[r] * 1073741824.0f));
+            else
+                unsafeAtomicAdd(p.c_bias + n, acc[r] * p.out_scale);
         }
     }
 }
@@ -160,12 +174,15 @@ __global__ __launch_bounds__(256) void adamw_kernel(GrlAdamWArgs p) {
 extern "C" int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args) {
     const GrlGemmTnArgs& p = *args;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 0;
-    if ((p.lda % 8) || (p.ldb % 8) || (p.N % 8) || (p.K % 8) || p.lda < p.N || p.ldb < p.K || p.ldc < p.K) return GRL_ERR_BAD_ARG;
     if (p.b_dtype != GRL_DT_F32 && p.b_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
+    const int bq = p.b_dtype == GRL_DT_F16 ? 8 : 4;   // 16-byte pieces of b
+    if ((p.lda % 4) || (p.ldb % bq) || (p.N % 4) || (p.K % bq) || p.lda < p.N || p.ldb < p.K || p.ldc < p.K) return GRL_ERR_BAD_ARG;
+    if (p.b_ones && p.c_bias == nullptr && p.c_bias_fix == nullptr) return GRL_ERR_BAD_ARG;
+    if ((p.c_fix != nullptr) != (p.c_bias_fix != nullptr) && p.b_ones) return GRL_ERR_BAD_ARG;
     if (p.taps != 1 && p.taps != 9) return GRL_ERR_BAD_ARG;
     if (p.taps == 9 && (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W) != 0)) return GRL_ERR_BAD_ARG;
     if (p.splits <= 0 || p.splits * p.taps > 65535 || (p.c == nullptr && p.c_fix == nullptr)) return GRL_ERR_BAD_ARG;
-    const dim3 grid((p.N + GT - 1) / GT, (p.K + GT - 1) / GT, p.splits * p.taps);
+    const dim3 grid((p.N + GT - 1) / GT, (p.K + (p.b_ones ? 1 : 0) + GT - 1) / GT, p.splits * p.taps);
     hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
     GRL_CHECK_LAUNCH();
     return 0;

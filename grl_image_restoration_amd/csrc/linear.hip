@@ -31,7 +31,14 @@ int grl_linear_split_launch(const GrlLinearArgs& p, hipStream_t st);
 extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     const GrlLinearArgs& p = *args;
     if (p.M <= 0) return 0;
-    if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % 8 != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
+    if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % (p.a_cols > 0 ? 4 : 8) != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
+    if (p.a_cols < 0 || p.n_store < 0) return GRL_ERR_BAD_ARG;
+    if (p.a_cols > 0 && ((p.a_cols % 4) || p.a_cols > p.Kpad || p.lda < p.a_cols || p.a_dtype != GRL_DT_F32 || p.pool_df > 1 || p.a_split == 3 ||
+                         (p.a_one && p.a_cols >= p.Kpad)))
+        return GRL_ERR_BAD_ARG;
+    if (p.n_store > 0 && ((p.n_store % 4) || p.n_store > p.Npad || p.ldo < p.n_store || p.out_dtype != GRL_DT_F32 || p.out_plane_stride > 0 ||
+                          (p.epi != GRL_EPI_PLAIN && p.epi != GRL_EPI_GELU)))
+        return GRL_ERR_BAD_ARG;
     if (p.out_dtype != GRL_DT_F32 && p.out_plane_stride <= 0 && (p.ldo % 8) != 0) return GRL_ERR_BAD_ARG;  // 16-B stores
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;

@@ -85,7 +85,14 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
                 const int ss = split ? s % KS3 : s;
                 const bool lo = split && s / KS3 == 1;
                 const float4* q = (const float4*)(base + 32 * ss + 8 * kg);
-                float4 v0 = q[0], v1 = q[1];
+                float4 v0, v1;
+                if (p.a_cols > 0) {   // operand at its real width: columns >= a_cols are constants (0; 1.0 in column a_cols with a_one)
+                    const int c0 = 32 * ss + 8 * kg;
+                    v0 = c0 < p.a_cols ? q[0] : float4{(c0 == p.a_cols && p.a_one) ? 1.0f : 0.0f, 0, 0, 0};
+                    v1 = c0 + 4 < p.a_cols ? q[1] : float4{(c0 + 4 == p.a_cols && p.a_one) ? 1.0f : 0.0f, 0, 0, 0};
+                } else {
+                    v0 = q[0]; v1 = q[1];
+                }
                 if (!valid) { v0 = float4{0, 0, 0, 0}; v1 = v0; }
                 gemm_x8 v;
                 v[0] = split_part(v0.x * asc, lo); v[1] = split_part(v0.y * asc, lo); v[2] = split_part(v0.z * asc, lo); v[3] = split_part(v0.w * asc, lo);
@@ -250,6 +257,7 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             const int col = n0 + 16 * (c * NT + nt) + 4 * g4;
+            if (p.n_store > 0 && col >= p.n_store) continue;   // result at its real width
             *(float4*)((float*)p.out + (int64_t)m * p.ldo + col) =
                 float4{acc[c][mt][nt][0], acc[c][mt][nt][1], acc[c][mt][nt][2], acc[c][mt][nt][3]};
         }
@@ -438,6 +446,11 @@ int launch_split(const GrlLinearArgs& p0, hipStream_t st) {
         GrlLinearArgs p = p0;
         const int c0 = sidx * ncol;
         p.Npad = ncol;
+        if (p0.n_store > 0) {   // this slab's share of the real output columns
+            const int ns = p0.n_store - c0;
+            if (ns <= 0) continue;
+            p.n_store = ns >= ncol ? 0 : ns;
+        }
         p.w = (const char*)p0.w + (size_t)c0 * KSTEPS * 32 * 2;
         p.bias = p0.bias + c0;
         if (p0.gscale) p.gscale = p0.gscale + c0 / 32;

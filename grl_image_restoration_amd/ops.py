@@ -170,9 +170,15 @@ def linear(
     out_scale: float = 1.0,
     out_lo: Optional[torch.Tensor] = None,
     w_regs: Optional[torch.Tensor] = None,
+    a_cols: int = 0,
+    a_one: bool = False,
+    n_store: int = 0,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
+    ``a_cols`` > 0: ``a`` is [M, a_cols] at its real width (multiple of 4): the kernel reads the columns up to Kpad as 0 (column
+    a_cols as 1.0 with ``a_one``); ``n_store`` > 0: the result is [M, n_store] (fp32, multiple of 4) -- the training path's operands
+    and results without padded copies (GrlLinearArgs, ABI 22).
     ``a_split=3``: split-precision operands -- ``w`` is packed by ``split3_weight`` ([hi | hi | lo], Kpad = 3 x the
     source width) and the kernel stages the fp32 ``a`` as [hi | lo | hi]."""
     _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale, w_regs)
@@ -185,7 +191,9 @@ def linear(
     assert a.dim() == 2 and a.stride(1) == 1 and w.dim() == 2 and w.is_contiguous() and w.dtype == GEMM_DTYPE
     assert a.dtype in (torch.float32, GEMM_DTYPE) and bias.dtype == torch.float32
     Npad, Kpad = w.shape
-    assert a_split in (1, 3) and a.shape[1] >= Kpad // a_split and bias.numel() == Npad
+    assert a_split in (1, 3) and a.shape[1] >= (a_cols if a_cols > 0 else Kpad // a_split) and bias.numel() == Npad
+    assert a_cols == 0 or (a.dtype == torch.float32 and pool is None and a_split == 1 and a_cols % 4 == 0 and a.stride(0) % 4 == 0)
+    assert n_store == 0 or (n_store % 4 == 0 and n_store <= Npad and not planes and epi in (L.EPI_PLAIN, L.EPI_GELU))
     assert a_split == 1 or (a.dtype == torch.float32 and Kpad % 96 == 0)
     if pool is not None:
         df, H, W = pool
@@ -203,8 +211,9 @@ def linear(
         ldo, plane_stride = 32, M * 32
     else:
         if out is None:
-            out = empty(M, Npad, dtype=out_dtype, device=a.device)
-        assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= Npad
+            out = empty(M, n_store if n_store > 0 else Npad, dtype=out_dtype, device=a.device)
+        assert out.dim() == 2 and out.stride(1) == 1 and out.shape[0] >= M and out.shape[1] >= (n_store if n_store > 0 else Npad)
+        assert n_store == 0 or out.dtype == torch.float32
         ldo, plane_stride = out.stride(0), 0
     args = L.GrlLinearArgs(
         a=_ptr(a), a_dtype=_KIND[a.dtype], lda=a.stride(0),
@@ -216,7 +225,7 @@ def linear(
         ldadd2=add2.stride(0) if add2 is not None else 0,
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split, a_scale=a_scale, out_scale=out_scale,
         out_lo=_ptr(out_lo), out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
-        w_regs=_ptr(w_regs),
+        w_regs=_ptr(w_regs), a_cols=a_cols, a_one=int(a_one), n_store=n_store,
     )
     if out_lo is not None:   # rounding residuals of the fp16 outputs, same layout (split-precision attention operands)
         assert out_lo.dtype == torch.float16 and out_lo.shape == out.shape and out_lo.stride() == out.stride() and out.dtype == torch.float16
@@ -641,19 +650,23 @@ def pack_conv_bias(b: torch.Tensor, cout_pad: int, shuffle_r: int = 0, shuffle_c
 def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int, W: int, *, act: int = 0,
             slope: float = 0.0, resid: Optional[torch.Tensor] = None, want_pool: bool = False,
             out_dtype=torch.float32, out: Optional[torch.Tensor] = None, shuffle_r: int = 0, shuffle_cg: int = 0,
-            x_split: int = 1, x_scale: float = 1.0, out_scale: float = 1.0):
+            x_split: int = 1, x_scale: float = 1.0, out_scale: float = 1.0, x_cols: int = 0, n_store: int = 0):
     """3x3 conv (stride 1, pad 1) on a channels-last token matrix x[B*H*W, >=CinP]; w packed by
-    pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool)."""
+    pack_conv_weight.  Returns out (and the per-workgroup channel sums if want_pool).  ``x_cols`` > 0: x is [rows, x_cols] at its
+    real width (fp32, multiple of 4; the channels up to CinP read as 0); ``n_store`` > 0: the result is [rows, n_store] (fp32,
+    multiple of 4) -- GrlConvArgs, ABI 22."""
     _dev_check(x, w, bias, resid, out)
     assert x.dim() == 2 and x.stride(1) == 1 and x.dtype in (torch.float32, GEMM_DTYPE)
     assert w.dtype == GEMM_DTYPE and w.is_contiguous() and w.dim() == 3 and w.shape[0] == 9
     CoutP, CinP = w.shape[1], w.shape[2]
-    assert x_split in (1, 2, 3) and x.shape[0] >= B * H * W and x.shape[1] >= CinP // x_split and bias.numel() == CoutP
+    assert x_split in (1, 2, 3) and x.shape[0] >= B * H * W and x.shape[1] >= (x_cols if x_cols > 0 else CinP // x_split) and bias.numel() == CoutP
     assert x_split == 1 or x.dtype == torch.float32
+    assert x_cols == 0 or (x.dtype == torch.float32 and x_split == 1 and x_cols % 4 == 0 and x.stride(0) % 4 == 0)
+    assert n_store == 0 or (n_store % 4 == 0 and n_store <= CoutP and shuffle_r <= 1 and out_dtype == torch.float32 and not want_pool)
     if shuffle_r > 1:
         rows, cols = B * H * W * shuffle_r * shuffle_r, shuffle_cg
     else:
-        rows, cols = B * H * W, CoutP
+        rows, cols = B * H * W, (n_store if n_store > 0 else CoutP)
     if out is None:
         out = empty(rows, cols, dtype=out_dtype, device=x.device)
     pool = None
@@ -672,6 +685,12 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
     elif CoutP > 192:
         step = max(s for s in (192, 128, 96, 64, 48, 32, 16) if CoutP % s == 0 and (shuffle_r <= 1 or s % shuffle_cg == 0))
     for c0 in range(0, CoutP, step):
+        ns = 0
+        if n_store > 0:                     # this launch's share of the real output channels
+            ns = min(step, n_store - c0)
+            if ns <= 0:
+                continue
+            ns = 0 if ns == step else ns
         args = L.GrlConvArgs(
             x=_ptr(x), x_dtype=_KIND[x.dtype], ldx=x.stride(0),
             w=C.c_void_p(w.data_ptr() + c0 * CinP * 2), w_tap_stride=CoutP * CinP,
@@ -683,6 +702,7 @@ def conv3x3(x: torch.Tensor, w: torch.Tensor, bias: torch.Tensor, B: int, H: int
             out=C.c_void_p(out.data_ptr() + (0 if shuffle_r > 1 else c0 * out.element_size())),
             out_dtype=_KIND[out.dtype], ldo=out.stride(0),
             shuffle_r=shuffle_r, shuffle_cg=shuffle_cg, shuffle_ij0=(c0 // shuffle_cg if shuffle_r > 1 else 0),
+            x_cols=x_cols, n_store=ns,
         )
         with _timed(f"conv3x3 {CinP}->{CoutP} {H}x{W}" if _PROFILE is not None else "conv3x3"):
             L.check(lib.grl_conv3x3_fwd(L.stream_ptr(), C.byref(args)), "grl_conv3x3_fwd")
@@ -752,26 +772,34 @@ def se_scale(pool: torch.Tensor, B: int, CP: int, C_: int, HW: int, w1, b1, w2, 
 
 # ---- training path (BASELINE config 5): the contractions of the backward pass and the optimizer step --------------------
 def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, hw: Optional[Tuple[int, int]] = None,
-            a_scale: float = 1.0, out_scale: float = 1.0) -> torch.Tensor:
+            a_scale: float = 1.0, out_scale: float = 1.0, b_ones: bool = False):
     """c[taps, N, K] = out_scale * sum_m (a_scale * a[m, :N])^T b[row(m, tap), :K]  (grl_gemm_tn): the weight gradient of a
-    token-wise linear (taps=1) or of a 3x3 convolution on channels-last pixel matrices (taps=9, hw=(H, W))."""
+    token-wise linear (taps=1) or of a 3x3 convolution on channels-last pixel matrices (taps=9, hw=(H, W)).  N, K multiples of 4;
+    nothing is read beyond column N / K of a row, so a and b may be the layer's tensors at their real widths.  ``b_ones``: returns
+    (c, bias) with bias[n] = out_scale * sum_m a_scale * a[m, n] -- the bias gradient, as if b had a column of ones (ABI 22)."""
     _dev_check(a, b)
     assert a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype in (torch.float32, torch.float16)
     assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0] and a.shape[1] >= N and b.shape[1] >= K
     M = a.shape[0]
     H, W = hw if hw is not None else (0, 0)
     det = deterministic()
-    c = torch.zeros(taps, N, K, dtype=torch.int64 if det else torch.float32, device=a.device)
-    tiles = ((N + 63) // 64) * ((K + 63) // 64) * taps
+    # one zeroed buffer for the taps and -- behind them -- the bias sums (a second fill per weight gradient otherwise)
+    buf = torch.zeros(taps * N * K + (N if b_ones else 0), dtype=torch.int64 if det else torch.float32, device=a.device)
+    c = buf[: taps * N * K].view(taps, N, K)
+    cb = buf[taps * N * K :] if b_ones else None
+    kcols = K + (1 if b_ones else 0)
+    tiles = ((N + 63) // 64) * ((kcols + 63) // 64) * taps
     splits = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))   # >= ~1000 workgroups, >= 256 rows each
     args = L.GrlGemmTnArgs(a=_ptr(a), lda=a.stride(0), b=_ptr(b), b_dtype=_KIND[b.dtype], ldb=b.stride(0), M=M, N=N, K=K, taps=taps,
                            H=H, W=W, splits=splits, a_scale=a_scale, out_scale=out_scale, c=None if det else _ptr(c), ldc=K,
-                           c_tap_stride=N * K, c_fix=_ptr(c) if det else None)
+                           c_tap_stride=N * K, c_fix=_ptr(c) if det else None, b_ones=int(b_ones),
+                           c_bias=None if det else _ptr(cb), c_bias_fix=_ptr(cb) if det else None)
     with _timed("gemm_tn"):
         L.check(L.lib().grl_gemm_tn(L.stream_ptr(), C.byref(args)), "grl_gemm_tn")
     if det:
-        return (c.double() * (out_scale * 2.0 ** -30)).float()
-    return c
+        c = (c.double() * (out_scale * 2.0 ** -30)).float()
+        cb = (cb.double() * (out_scale * 2.0 ** -30)).float() if b_ones else None
+    return (c, cb) if b_ones else c
 
 
 def _attn_args(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, B, nh, table, masked, ones_col, head_dim, k_one31, lazy_floor, lse):

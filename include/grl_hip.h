@@ -23,7 +23,7 @@ extern "C" {
 
 #define GRL_ERR_BAD_ARG (-1)
 #define GRL_ERR_UNSUPPORTED (-2)
-#define GRL_ABI_VERSION 21
+#define GRL_ABI_VERSION 22
 
 /* element kinds of activation / weight buffers */
 enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
@@ -84,6 +84,14 @@ typedef struct GrlLinearArgs {
                               /* then lo = fp16(W - hi); fragment s, lane l, element e = W[column 32 (6 slab + w) +      */
                               /* (l & 31)][16 s + 8 (l >> 5) + e]; columns >= Npad zero.  grl_linear_split_blob_bytes;   */
                               /* ops.pack_linear_split.  NULL, or a shape it does not take: the generic kernel on `w`.   */
+    /* ABI 22 -- operands and results at their REAL widths (training path: no padded copies of activations / gradients):  */
+    int32_t a_cols;         /* > 0 (fp32 A, no pooling, a_split <= 1): A has a_cols real columns (multiple of 4), lda >= a_cols, */
+                            /* lda % 4 == 0; the columns a_cols .. Kpad-1 of the operand are read as 0 ...                        */
+    int32_t a_one;          /* ... except column a_cols, read as 1.0, when a_one != 0 (it meets a zero weight column in a        */
+                            /* forward launch; the weight-gradient contraction finds the bias gradient there)                     */
+    int32_t n_store;        /* > 0 (fp32 output, PLAIN / GELU epilogue, no planes): only the columns < n_store (multiple of 4)    */
+                            /* are stored; ldo >= n_store, ldo % 4 == 0                                                           */
+    int32_t reserved0;
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
@@ -344,6 +352,10 @@ typedef struct GrlConvArgs {
     int32_t shuffle_r;      /* >1: PixelShuffle(r) store into a [B, H*r, W*r, shuffle_cg] matrix;    */
     int32_t shuffle_cg;     /*     output channels are packed in (i, j, c) order, this call's        */
     int32_t shuffle_ij0;    /*     channel 0 belongs to sub-pixel group shuffle_ij0                  */
+    /* ABI 22 (see GrlLinearArgs.a_cols / n_store): */
+    int32_t x_cols;         /* > 0 (fp32 x, x_split <= 1): x has x_cols real channels (multiple of 4), ldx >= x_cols,   */
+                            /* ldx % 4 == 0; channels x_cols .. CinP-1 are read as 0                                    */
+    int32_t n_store;        /* > 0 (fp32 output, no pixel shuffle): only channels < n_store (multiple of 4) are stored  */
 } GrlConvArgs;
 
 int grl_conv3x3_fwd(void* stream, const GrlConvArgs* args);
@@ -436,7 +448,7 @@ typedef struct GrlGemmTnArgs {
     const void* b;          /* [M, ldb] GRL_DT_F32 or GRL_DT_F16 (the layer's input)                */
     int32_t b_dtype;
     int64_t ldb;
-    int32_t M, N, K;        /* N, K multiples of 8                                                  */
+    int32_t M, N, K;        /* N, K multiples of 4 (of 8 for fp16 b)                                */
     int32_t taps, H, W;     /* 1, or 9 with the image size                                          */
     int32_t splits;         /* M is cut into this many slabs (one workgroup column each)            */
     float a_scale, out_scale;
@@ -446,6 +458,12 @@ typedef struct GrlGemmTnArgs {
                             /* fixed point (2^30 x the a_scale-d sums; integer atomics commute, fp32 atomics do not) into     */
                             /* this zeroed [taps][N][ldc] array instead of `c`; the caller converts:                          */
                             /* c = c_fix * 2^-30 * out_scale.  Bit-identical results run to run.                              */
+    /* ABI 22: a / b at their real widths -- N, K multiples of 4 (fp32 operands), lda >= N, ldb >= K, nothing is read beyond   */
+    /* column N / K of a row -- and the bias gradient without a ones column in memory:                                          */
+    int32_t b_ones;         /* != 0: b has a VIRTUAL column K that holds 1.0 (taps = 9: inside the image); its products, the   */
+    int32_t reserved0;      /* column sums of a, go to c_bias[n] (taps = 9: of the centre tap) instead of a column of c         */
+    float* c_bias;          /* [N] fp32, zeroed by the caller (required with b_ones unless c_bias_fix)                          */
+    int64_t* c_bias_fix;    /* [N], the deterministic counterpart (with c_fix)                                                  */
 } GrlGemmTnArgs;
 
 int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args);

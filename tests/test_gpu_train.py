@@ -346,3 +346,83 @@ def test_pack_conv_train_matches_the_torch_packing(Cout, Cin):
     gin, gout = (Cout + 31) // 32 * 32, (Cin + 15) // 16 * 16
     wt, none = ops.pack_conv_train(w, None, gout, gin, flip_t=True)
     assert none is None and torch.equal(wt, ops.pack_conv_weight(w.flip(2, 3).transpose(0, 1).contiguous(), gin, gout))
+
+
+@pytest.mark.parametrize("taps", [1, 9])
+def test_gemm_tn_real_widths_and_virtual_ones_column(taps):
+    """grl_gemm_tn on operands at their real widths (ABI 22): N = 180, K = 180 with row strides of exactly that, the bias gradient
+    from the VIRTUAL ones column -- against float64, and against the launch on the padded operands [a | 0], [b | 1 | 0]."""
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(46)
+    B, H, W, N, K = 2, 24, 40, 180, 180
+    M = B * H * W
+    a, b = (torch.randn(M, N, generator=g) * 1e-4).cuda(), torch.randn(M, K, generator=g).cuda()
+    kw = dict(taps=taps, hw=(H, W) if taps == 9 else None, a_scale=4096.0, out_scale=1.0 / 4096.0)
+    c, cb = ops.gemm_tn(a, b, N, K, b_ones=True, **kw)
+    assert c.shape == (taps, N, K) and c.is_contiguous() and cb.shape == (N,)
+    ap = torch.cat([a, torch.zeros(M, 12).cuda()], 1)
+    bp = torch.cat([b, torch.ones(M, 1).cuda(), torch.zeros(M, 11).cuda()], 1)
+    cp = ops.gemm_tn(ap, bp, 192, 192, **kw)
+    assert _rel(c, cp[:, :N, :K]) < 1e-5 and _rel(cb, cp[taps // 2, :N, K]) < 1e-5     # same products, another summation order
+    assert _rel(cb, a.double().sum(0)) < 2e-3
+    if taps == 1:
+        assert _rel(c[0], a.double().t() @ b.double()) < 2e-3
+    else:
+        ai = a.double().view(B, H, W, N).permute(0, 3, 1, 2)
+        bi = F.pad(b.double().view(B, H, W, K).permute(0, 3, 1, 2), (1, 1, 1, 1))
+        for t in (0, 4, 8):
+            dy, dx = t // 3, t % 3
+            ref = torch.einsum("bnhw,bkhw->nk", ai, bi[:, :, dy : dy + H, dx : dx + W])
+            assert _rel(c[t], ref) < 2e-3
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 180, 540), (700, 360, 180), (640, 180, 90), (333, 180, 180)])
+def test_linear_real_widths_equal_the_padded_path(M, K, N):
+    """The linear op on operands / results at their real widths (GrlLinearArgs.a_cols / n_store, virtual ones column in the weight
+    gradient) against the same op on padded copies (GRL_REAL_WIDTHS=0, the path of rounds 2-5): same fp16 products -- y and dx bit
+    for bit, dW / db up to the order of the atomics.  Also with a gradient that arrives as a column slice of a wider matrix."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(47)
+    x = torch.randn(M, K, generator=g).cuda()
+    w = (torch.randn(N, K, generator=g) / math.sqrt(K)).cuda()
+    b = (0.1 * torch.randn(N, generator=g)).cuda()
+    wide = (torch.randn(M, N + 8, generator=g) * 1e-6).cuda()
+    res = {}
+    for flag in (True, False):
+        prev, AG._REAL_WIDTHS[0] = AG._REAL_WIDTHS[0], flag
+        try:
+            xd, wd, bd = (t.clone().requires_grad_(True) for t in (x, w, b))
+            y = AG.GradScaleTop.apply(AG.linear(xd, wd, bd))
+            y.backward(wide[:, 4 : 4 + N])
+            res[flag] = (y.detach(), xd.grad, wd.grad, bd.grad)
+        finally:
+            AG._REAL_WIDTHS[0] = prev
+    assert res[True][0].is_contiguous() and res[True][0].shape == (M, N)
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert _rel(res[True][2], res[False][2]) < 1e-5 and _rel(res[True][3], res[False][3]) < 1e-5
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(2, 16, 40, 180, 48), (1, 24, 32, 48, 180), (1, 17, 33, 180, 64), (2, 12, 20, 64, 180)])
+def test_conv3x3_real_widths_equal_the_padded_path(B, H, W, Cin, Cout):
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(48)
+    M = B * H * W
+    x = torch.randn(M, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)).cuda()
+    b = (0.1 * torch.randn(Cout, generator=g)).cuda()
+    dy = (torch.randn(M, Cout, generator=g) * 1e-5).cuda()
+    res = {}
+    for flag in (True, False):
+        prev, AG._REAL_WIDTHS[0] = AG._REAL_WIDTHS[0], flag
+        try:
+            xd, wd, bd = (t.clone().requires_grad_(True) for t in (x, w, b))
+            y = AG.GradScaleTop.apply(AG.conv3x3(xd, wd, bd, B, H, W))
+            y.backward(dy)
+            res[flag] = (y.detach(), xd.grad, wd.grad, bd.grad)
+        finally:
+            AG._REAL_WIDTHS[0] = prev
+    assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
+    assert _rel(res[True][2], res[False][2]) < 1e-5 and _rel(res[True][3], res[False][3]) < 1e-5
