@@ -43,6 +43,7 @@ EXPORTS = [
     "grl_layernorm_train_fwd",
     "grl_layernorm_bwd",
     "grl_pack_conv3x3",
+    "grl_pack_linear",
     "grl_head_planes_fwd",
     "grl_head_planes_bwd",
     "grl_cpb_table_fwd",
@@ -393,6 +394,10 @@ class GrlLnTrainArgs(_Strict):
         ("dbeta", C.c_void_p),
         ("M", C.c_int32), ("n", C.c_int32),
         ("eps", C.c_float),
+        ("resid", C.c_void_p), ("ldr", C.c_int64),
+        ("row_scale", C.c_void_p),
+        ("rows_per_image", C.c_int32),
+        ("alpha", C.c_float),
     ]
 
 
@@ -506,6 +511,8 @@ def lib():
     L.grl_layernorm_bwd.restype = C.c_int
     L.grl_pack_conv3x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.grl_pack_conv3x3.restype = C.c_int
+    L.grl_pack_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.grl_pack_linear.restype = C.c_int
     L.grl_head_planes_fwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]
     L.grl_head_planes_fwd.restype = C.c_int
     L.grl_head_planes_bwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]

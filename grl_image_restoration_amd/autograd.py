@@ -176,15 +176,27 @@ def _padded_weight(w: torch.Tensor, Np: int, Kp: int, transposed: bool = False) 
     keep = _is_registered(key)
     ent = _WEIGHTS.get(key) if keep else None
     if ent is None or ent[0] != w._version or ent[1] != sig:
-        buf = ent[2] if ent is not None and ent[1] == sig else torch.zeros(Np, Kp, dtype=ops.GEMM_DTYPE, device=w.device)
-        buf[: w.shape[0], : w.shape[1]].copy_(w.detach())
-        ent = [w._version, sig, buf, None]
+        reuse = ent is not None and ent[1] == sig
+        buf = ent[2] if reuse else ops.empty(Np, Kp, dtype=ops.GEMM_DTYPE, device=w.device)
+        # a parameter that needs gradients will want the transpose in this step's backward pass: both in one launch (the buffers
+        # are kept: a captured step holds their addresses, see forget_parameters)
+        tbuf = ent[4] if reuse else None
+        if tbuf is None and (w.requires_grad or transposed):
+            tbuf = ops.empty(Kp, Np, dtype=ops.GEMM_DTYPE, device=w.device)
+        if w.is_cuda:
+            ops.pack_linear_train(w, buf, tbuf)
+        else:                                  # (host-side cache logic is tested on CPU tensors; nothing computes there)
+            buf.zero_()
+            buf[: w.shape[0], : w.shape[1]].copy_(w.detach())
+            if tbuf is not None:
+                tbuf.copy_(buf.t())
+        ent = [w._version, sig, buf, tbuf, tbuf]
         if keep:
             _WEIGHTS[key] = ent
     if not transposed:
         return ent[2]
     if ent[3] is None:
-        ent[3] = ent[2].t().contiguous()
+        ent[3] = ent[4] = ent[2].t().contiguous()
     return ent[3]
 
 
@@ -522,6 +534,39 @@ class LayerNormFn(torch.autograd.Function):
         x, mean, rstd, gamma = ctx.saved_tensors
         dx, dg, db = ops.layernorm_bwd(dy.float().contiguous(), x, mean, rstd, gamma)
         return dx, dg, db, None
+
+
+class LayerNormResFn(torch.autograd.Function):
+    """resid + alpha * row_scale[image] * LayerNorm(x): the post-norm residual of a block (efficient.py:543-556) in the LayerNorm
+    launches (csrc/ln_train.hip).  ``row_scale``: DropPath keep mask, one entry per image (no gradient), or None."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps, resid, row_scale, rows_per_image, alpha):
+        xc = _rows16(x.detach())
+        y, mean, rstd = ops.layernorm_train(xc, gamma, beta, eps, resid=_rows16(resid.detach()), row_scale=row_scale,
+                                            rows_per_image=rows_per_image, alpha=alpha)
+        ctx.save_for_backward(xc, mean, rstd, gamma, row_scale)
+        ctx.cfg = (rows_per_image, alpha)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, mean, rstd, gamma, row_scale = ctx.saved_tensors
+        rpi, alpha = ctx.cfg
+        dyc = _rows16(dy)
+        dx, dg, db = ops.layernorm_bwd(dyc, x, mean, rstd, gamma, row_scale=row_scale, rows_per_image=rpi, alpha=alpha)
+        return dx, dg, db, None, (dy if ctx.needs_input_grad[4] else None), None, None, None
+
+
+def layer_norm_residual(resid, x, gamma, beta, eps: float, row_scale, rows_per_image: int, alpha: float):
+    """resid + alpha * row_scale[row // rows_per_image] * F.layer_norm(x) on token matrices [M, n] (row_scale None: 1)."""
+    n = x.shape[-1]
+    if x.is_cuda and x.dim() == 2 and n % 4 == 0 and n <= 256 and not ops.deterministic() and alpha != 0.0:
+        return LayerNormResFn.apply(x, gamma, beta, eps, resid, row_scale, rows_per_image, alpha)
+    t = F.layer_norm(x, (n,), gamma, beta, eps)
+    if row_scale is None:
+        return torch.add(resid, t, alpha=alpha)
+    return torch.addcmul(resid.view(-1, rows_per_image, n), t.view(-1, rows_per_image, n), row_scale.view(-1, 1, 1), value=alpha).view_as(resid)
 
 
 def layer_norm(x, gamma, beta, eps: float = 1e-5):

@@ -6,6 +6,11 @@
 // config 5 (profiles/r06_train_kernel_stats.txt: 1.3 TB/s on a [32 768, 180] fp32 matrix); the rows are 720 bytes, one wave per row
 // with 16-byte accesses streams them at the HBM rate.
 //   forward : y = (x - mean) rstd gamma + beta;  mean / rstd per row kept for the backward pass
+//             with `resid` (round 6): y = resid + c_row ((x - mean) rstd gamma + beta),  c_row = alpha * row_scale[row / rows_per_image]
+//             -- the post-norm residual of a block with its residual scale and DropPath keep mask (one Bernoulli draw per image,
+//             scale_by_keep; mixed_attn_block_efficient.py:543-556) in the same pass: as torch code the addcmul after every norm was one
+//             more 47 MB pass forward and two multiplies backward; the backward kernel takes dL/dy and applies c_row itself
+//             (dL/dresid = dL/dy: no launch at all)
 //   backward: g = dy gamma;  dx = rstd (g - mean_c(g) - xhat mean_c(g xhat));  dgamma = sum_rows dy xhat;  dbeta = sum_rows dy
 //             (column sums: per-lane partials over a wave's rows, the four waves of a workgroup through LDS, one atomic per column
 //             and workgroup into the zeroed outputs)
@@ -29,9 +34,15 @@ __global__ __launch_bounds__(256) void ln_train_fwd_kernel(GrlLnTrainArgs p) {
         const float mean = wave_sum(v.x + v.y + v.z + v.w) * inv_n;
         const float d0 = in ? v.x - mean : 0.f, d1 = in ? v.y - mean : 0.f, d2 = in ? v.z - mean : 0.f, d3 = in ? v.w - mean : 0.f;
         const float rstd = rsqrtf(wave_sum(d0 * d0 + d1 * d1 + d2 * d2 + d3 * d3) * inv_n + p.eps);
-        if (in)
-            *(float4*)(p.y + (int64_t)row * p.ldy + c) =
-                float4{d0 * rstd * gm.x + bt.x, d1 * rstd * gm.y + bt.y, d2 * rstd * gm.z + bt.z, d3 * rstd * gm.w + bt.w};
+        if (in) {
+            float4 o = float4{d0 * rstd * gm.x + bt.x, d1 * rstd * gm.y + bt.y, d2 * rstd * gm.z + bt.z, d3 * rstd * gm.w + bt.w};
+            if (p.resid != nullptr) {
+                const float cr = p.row_scale != nullptr ? p.alpha * p.row_scale[row / p.rows_per_image] : p.alpha;
+                const float4 r = *(const float4*)(p.resid + (int64_t)row * p.ldr + c);
+                o = float4{fmaf(cr, o.x, r.x), fmaf(cr, o.y, r.y), fmaf(cr, o.z, r.z), fmaf(cr, o.w, r.w)};
+            }
+            *(float4*)(p.y + (int64_t)row * p.ldy + c) = o;
+        }
         if (lane == 0) { p.mean[row] = mean; p.rstd[row] = rstd; }
     }
 }
@@ -48,6 +59,10 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(GrlLnTrainArgs p) {
     for (int row = blockIdx.x * 4 + wave; row < p.M; row += gridDim.x * 4) {
         float4 v = float4{0, 0, 0, 0}, d = v;
         if (in) { v = *(const float4*)(p.x + (int64_t)row * p.ldx + c); d = *(const float4*)(p.dy + (int64_t)row * p.lddy + c); }
+        if (p.alpha != 0.0f) {                     // fused residual: the norm's output entered y times c_row
+            const float cr = p.row_scale != nullptr ? p.alpha * p.row_scale[row / p.rows_per_image] : p.alpha;
+            d.x *= cr; d.y *= cr; d.z *= cr; d.w *= cr;
+        }
         const float mean = p.mean[row], rstd = p.rstd[row];
         const float h0 = in ? (v.x - mean) * rstd : 0.f, h1 = in ? (v.y - mean) * rstd : 0.f, h2 = in ? (v.z - mean) * rstd : 0.f,
                     h3 = in ? (v.w - mean) * rstd : 0.f;
@@ -79,6 +94,8 @@ bool ln_args_ok(const GrlLnTrainArgs& p) {
 extern "C" int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args) {
     const GrlLnTrainArgs& p = *args;
     if (!ln_args_ok(p) || !p.y || !p.beta || (p.ldy & 3) || p.ldy < p.n) return GRL_ERR_BAD_ARG;
+    if (p.resid != nullptr && ((p.ldr & 3) || p.ldr < p.n)) return GRL_ERR_BAD_ARG;
+    if (p.row_scale != nullptr && p.rows_per_image <= 0) return GRL_ERR_BAD_ARG;
     const int grid = (p.M + 3) / 4 < 4096 ? (p.M + 3) / 4 : 4096;
     hipLaunchKernelGGL(ln_train_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     GRL_CHECK_LAUNCH();
@@ -88,6 +105,7 @@ extern "C" int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args)
 extern "C" int grl_layernorm_bwd(void* stream, const GrlLnTrainArgs* args) {
     const GrlLnTrainArgs& p = *args;
     if (!ln_args_ok(p) || !p.dy || !p.dx || !p.dgamma || !p.dbeta || (p.lddy & 3) || (p.lddx & 3) || p.lddy < p.n || p.lddx < p.n) return GRL_ERR_BAD_ARG;
+    if (p.row_scale != nullptr && (p.rows_per_image <= 0 || p.alpha == 0.0f)) return GRL_ERR_BAD_ARG;
     const int grid = (p.M + 3) / 4 < 1024 ? (p.M + 3) / 4 : 1024;
     hipLaunchKernelGGL(ln_train_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, p);
     GRL_CHECK_LAUNCH();

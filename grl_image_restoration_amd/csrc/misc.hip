@@ -147,6 +147,38 @@ extern "C" int grl_pack_conv3x3(void* stream, const float* w, const float* b, vo
     return 0;
 }
 
+// nn.Linear weight [N][K] (fp32) -> the operand of grl_linear_fwd, fp16 [Np][Kp] zero padded, AND its transpose [Kp][Np] (the
+// operand of the data-gradient launch dX = dY W) in one launch: the training path refreshes both once per step and parameter
+// (torch: a converting slice copy + .t().contiguous(), two launches per linear layer, 400 per step).
+namespace {
+__global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, f16* __restrict__ wp, f16* __restrict__ wt, int N, int K,
+                                                          int Np, int Kp) {
+    __shared__ f16 tile[32][33];
+    const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        const f16 v = (n < N && k < K) ? (f16)w[(int64_t)n * K + k] : (f16)0.f;
+        tile[r][tx] = v;
+        if (n < Np && k < Kp) wp[(int64_t)n * Kp + k] = v;
+    }
+    __syncthreads();
+    if (wt != nullptr)
+        for (int r = ty; r < 32; r += 8) {
+            const int k = k0 + r, n = n0 + tx;
+            if (k < Kp && n < Np) wt[(int64_t)k * Np + n] = tile[tx][r];
+        }
+}
+}  // namespace
+
+extern "C" int grl_pack_linear(void* stream, const float* w, void* out_w, void* out_wt, int32_t N, int32_t K, int32_t Np, int32_t Kp) {
+    if (!w || !out_w || N <= 0 || K <= 0 || Np < N || Kp < K) return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(pack_linear_kernel, dim3((Kp + 31) / 32, (Np + 31) / 32), dim3(256), 0, (hipStream_t)stream, w, (f16*)out_w, (f16*)out_wt,
+                       N, K, Np, Kp);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
 // Debug aid (GRL_DIRTY_LDS=1 in the Python wrappers calls it before every C-ABI launch): overwrites the LDS of every CU with
 // 0xFF bytes (fp32 / fp16 NaN).  LDS is not cleared between workgroups, so a kernel that reads a location it has not written sees
 // whatever the previous workgroup on that CU left there -- zeros or finite numbers most of the time, which hides the bug and makes

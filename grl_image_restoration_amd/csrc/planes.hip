@@ -21,30 +21,50 @@ namespace {
 
 constexpr int PL_T = 256;            // threads per workgroup = 16 vectors at a time
 
+// (Both kernels keep PL_U vectors per 16-lane group in flight: the loads of all of them are issued before the first is used.  One
+// vector at a time the kernels were latency bound -- 35 / 72 us per launch for 36 / 100 MB of traffic.)
+constexpr int PL_U = 4;
+
 __global__ __launch_bounds__(PL_T) void planes_fwd_kernel(GrlPlanesArgs p) {
     const int sub = threadIdx.x & 15;                  // lane inside the vector's DPP row: channels 2 sub, 2 sub + 1
+    const int c = 2 * sub;
     const int64_t nvec = (int64_t)p.T * p.S_out * p.nh;
-    for (int64_t v = (int64_t)blockIdx.x * (PL_T / 16) + (threadIdx.x >> 4); v < nvec; v += (int64_t)gridDim.x * (PL_T / 16)) {
+    const int64_t stride = (int64_t)gridDim.x * (PL_T / 16);
+    for (int64_t v0 = (int64_t)blockIdx.x * (PL_T / 16) + (threadIdx.x >> 4); v0 < nvec; v0 += stride * PL_U) {
         // v = (t * S_out + s) * nh + h: consecutive vectors read consecutive memory of x
-        const int h = (int)(v % p.nh);
-        const int s = (int)((v / p.nh) % p.S_out);
-        const int64_t t = v / ((int64_t)p.nh * p.S_out);
-        const float* xv = p.x + ((t * p.S_in + p.src[s]) * p.nh + h) * p.d;
-        const int c = 2 * sub;
-        float2 a = float2{0.f, 0.f};
-        if (c + 1 < p.d) a = *(const float2*)(xv + c);
-        else if (c < p.d) a.x = xv[c];
-        float f = 1.0f;
-        if (!p.raw[s]) {
-            const float nrm = sqrtf(row16_sum(a.x * a.x + a.y * a.y));
-            f = p.scale[s * p.nh + h] / fmaxf(nrm, 1e-12f);
+        float2 a[PL_U];
+        int hh[PL_U], ss[PL_U];
+        int64_t tt[PL_U];
+#pragma unroll
+        for (int u = 0; u < PL_U; ++u) {
+            const int64_t v = v0 + u * stride;
+            a[u] = float2{0.f, 0.f};
+            hh[u] = 0; ss[u] = 0; tt[u] = 0;
+            if (v < nvec) {
+                hh[u] = (int)(v % p.nh);
+                ss[u] = (int)((v / p.nh) % p.S_out);
+                tt[u] = v / ((int64_t)p.nh * p.S_out);
+                const float* xv = p.x + ((tt[u] * p.S_in + p.src[ss[u]]) * p.nh + hh[u]) * p.d;
+                if (c + 1 < p.d) a[u] = *(const float2*)(xv + c);
+                else if (c < p.d) a[u].x = xv[c];
+            }
         }
-        float y0 = a.x * f, y1 = a.y * f;
-        if (c == p.one_col[s]) y0 = 1.0f;
-        if (c + 1 == p.one_col[s]) y1 = 1.0f;
-        const int64_t o = (((int64_t)s * p.nh + h) * p.T + t) * 32 + c;
-        *(float2*)(p.out32 + o) = float2{y0, y1};
-        *(uint32_t*)((f16*)p.out16 + o) = pack_f16(y0, y1);
+#pragma unroll
+        for (int u = 0; u < PL_U; ++u) {
+            const int64_t v = v0 + u * stride;
+            const int s = ss[u], h = hh[u];
+            float f = 1.0f;
+            const float nrm = sqrtf(row16_sum(a[u].x * a[u].x + a[u].y * a[u].y));      // (all lanes take part in the row reduction)
+            if (!p.raw[s]) f = p.scale[s * p.nh + h] / fmaxf(nrm, 1e-12f);
+            float y0 = a[u].x * f, y1 = a[u].y * f;
+            if (c == p.one_col[s]) y0 = 1.0f;
+            if (c + 1 == p.one_col[s]) y1 = 1.0f;
+            if (v < nvec) {
+                const int64_t o = (((int64_t)s * p.nh + h) * p.T + tt[u]) * 32 + c;
+                *(float2*)(p.out32 + o) = float2{y0, y1};
+                *(uint32_t*)((f16*)p.out16 + o) = pack_f16(y0, y1);
+            }
+        }
     }
 }
 
@@ -55,38 +75,61 @@ __global__ __launch_bounds__(PL_T) void planes_bwd_kernel(GrlPlanesArgs p) {
     __syncthreads();
     const int c = 2 * sub;
     const int64_t nvec = (int64_t)p.T * p.S_in * p.nh;
-    float acc[8];                                      // this lane group's partial scale gradients per output slot (one head per pass)
-    for (int64_t v = (int64_t)blockIdx.x * (PL_T / 16) + (threadIdx.x >> 4); v < nvec; v += (int64_t)gridDim.x * (PL_T / 16)) {
+    const int64_t stride = (int64_t)gridDim.x * (PL_T / 16);
+    constexpr int U = 2;
+    for (int64_t v0 = (int64_t)blockIdx.x * (PL_T / 16) + (threadIdx.x >> 4); v0 < nvec; v0 += stride * U) {
         // v = (t * S_in + i) * nh + h: one INPUT vector; every output slot fed by it contributes
-        const int h = (int)(v % p.nh);
-        const int i = (int)((v / p.nh) % p.S_in);
-        const int64_t t = v / ((int64_t)p.nh * p.S_in);
-        const float* xv = p.x + v * p.d;
-        float2 a = float2{0.f, 0.f};
-        if (c + 1 < p.d) a = *(const float2*)(xv + c);
-        else if (c < p.d) a.x = xv[c];
-        const float nrm = fmaxf(sqrtf(row16_sum(a.x * a.x + a.y * a.y)), 1e-12f);
-        const float u0 = a.x / nrm, u1 = a.y / nrm;
-        float g0 = 0.f, g1 = 0.f;
+        float2 a[U], dd[U][8];
+        int hh[U], ii[U];
+        bool live[U];
 #pragma unroll
-        for (int s = 0; s < 8; ++s) {
-            acc[s] = 0.f;
-            if (s >= p.S_out || p.src[s] != i || p.dy[s] == nullptr) continue;
-            const float2 d = *(const float2*)(p.dy[s] + ((int64_t)h * p.T + t) * 32 + c);     // (pad columns carry no gradient)
-            const float d0 = c < p.d ? d.x : 0.f, d1 = c + 1 < p.d ? d.y : 0.f;
-            if (p.raw[s]) { g0 += d0; g1 += d1; continue; }
-            const float dot = row16_sum(d0 * u0 + d1 * u1);                                     // dy . u  (= the scale gradient's term)
-            const float f = p.scale[s * p.nh + h] / nrm;
-            g0 = fmaf(f, d0 - u0 * dot, g0);
-            g1 = fmaf(f, d1 - u1 * dot, g1);
-            acc[s] = dot;
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = v0 + u * stride;
+            live[u] = v < nvec;
+            const int64_t vc = live[u] ? v : 0;
+            hh[u] = (int)(vc % p.nh);
+            ii[u] = (int)((vc / p.nh) % p.S_in);
+            const int64_t t = vc / ((int64_t)p.nh * p.S_in);
+            const float* xv = p.x + vc * p.d;
+            a[u] = float2{0.f, 0.f};
+            if (c + 1 < p.d) a[u] = *(const float2*)(xv + c);
+            else if (c < p.d) a[u].x = xv[c];
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                dd[u][s] = float2{0.f, 0.f};
+                if (s < p.S_out && p.src[s] == ii[u] && p.dy[s] != nullptr)
+                    dd[u][s] = *(const float2*)(p.dy[s] + ((int64_t)hh[u] * p.T + t) * 32 + c);     // (pad columns carry no gradient)
+            }
         }
-        if (c + 1 < p.d) *(float2*)(p.dx + v * p.d + c) = float2{g0, g1};
-        else if (c < p.d) p.dx[v * p.d + c] = g0;
-        if (sub == 0) {
 #pragma unroll
-            for (int s = 0; s < 8; ++s)
-                if (s < p.S_out && p.want_dscale[s] && acc[s] != 0.f) atomicAdd(&ds[s * 8 + h], acc[s]);
+        for (int u = 0; u < U; ++u) {
+            const int64_t v = v0 + u * stride;
+            const int h = hh[u], i = ii[u];
+            const float nrm = fmaxf(sqrtf(row16_sum(a[u].x * a[u].x + a[u].y * a[u].y)), 1e-12f);
+            const float u0 = a[u].x / nrm, u1 = a[u].y / nrm;
+            float g0 = 0.f, g1 = 0.f;
+            float acc[8];                              // this vector's scale-gradient term per output slot
+#pragma unroll
+            for (int s = 0; s < 8; ++s) {
+                acc[s] = 0.f;
+                if (s >= p.S_out || p.src[s] != i || p.dy[s] == nullptr) continue;    // (group-uniform: the row reduction below is safe)
+                const float d0 = c < p.d ? dd[u][s].x : 0.f, d1 = c + 1 < p.d ? dd[u][s].y : 0.f;
+                if (p.raw[s]) { g0 += d0; g1 += d1; continue; }
+                const float dot = row16_sum(d0 * u0 + d1 * u1);                         // dy . u  (= the scale gradient's term)
+                const float f = p.scale[s * p.nh + h] / nrm;
+                g0 = fmaf(f, d0 - u0 * dot, g0);
+                g1 = fmaf(f, d1 - u1 * dot, g1);
+                acc[s] = dot;
+            }
+            if (live[u]) {
+                if (c + 1 < p.d) *(float2*)(p.dx + v * p.d + c) = float2{g0, g1};
+                else if (c < p.d) p.dx[v * p.d + c] = g0;
+                if (sub == 0) {
+#pragma unroll
+                    for (int s = 0; s < 8; ++s)
+                        if (s < p.S_out && p.want_dscale[s] && acc[s] != 0.f) atomicAdd(&ds[s * 8 + h], acc[s]);
+                }
+            }
         }
     }
     __syncthreads();

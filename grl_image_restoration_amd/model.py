@@ -1250,7 +1250,7 @@ class GRL(nn.Module):
         M = B * H * W
         a = blk.attn
         x1 = AG.linear(att, a.proj.weight, a.proj.bias)
-        x1 = self._residual(r, AG.layer_norm(x1, blk.norm1.weight, blk.norm1.bias, 1e-5), H * W, dp)
+        x1 = self._norm_residual(r, x1, blk.norm1, H * W, dp)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
             c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention
             u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
@@ -1258,7 +1258,16 @@ class GRL(nn.Module):
             gate = torch.sigmoid(F.linear(F.relu(F.linear(pool, se[1].weight.flatten(1), se[1].bias)), se[3].weight.flatten(1), se[3].bias))
             x1 = torch.addcmul(x1.view(B, H * W, C), u.view(B, H * W, C), gate.unsqueeze(1)).view(M, C)      # x1 + u * gate in one launch
         m = AG.linear(F.gelu(AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
-        return self._residual(x1, AG.layer_norm(m, blk.norm2.weight, blk.norm2.bias, 1e-5), H * W, dp)
+        return self._norm_residual(x1, m, blk.norm2, H * W, dp)
+
+    def _norm_residual(self, r, t, norm, rows_per_image: int, p: float):
+        """r + res_scale * DropPath(norm(t)) (efficient.py:543-556; timm DropPath, scale_by_keep: one Bernoulli draw per image) inside the
+        LayerNorm launches (autograd.layer_norm_residual; round 6 -- _residual's addcmul was one more pass forward and two backward)."""
+        if p == 0.0 or not self.training:
+            return AG.layer_norm_residual(r, t, norm.weight, norm.bias, 1e-5, None, rows_per_image, self.res_scale)
+        keep = 1.0 - p
+        m = t.new_empty(t.shape[0] // rows_per_image).bernoulli_(keep)
+        return AG.layer_norm_residual(r, t, norm.weight, norm.bias, 1e-5, m, rows_per_image, self.res_scale / keep)
 
     def _residual(self, r, t, rows_per_image: int, p: float):
         """r + res_scale * DropPath(t) (efficient.py:543-556, timm DropPath with scale_by_keep: one Bernoulli draw per image) in ONE

@@ -866,37 +866,44 @@ def cpb_table_bwd(coords: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: 
     return d_w1, d_b1, d_w2
 
 
-def layernorm_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5):
+def layernorm_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, resid: Optional[torch.Tensor] = None,
+                    row_scale: Optional[torch.Tensor] = None, rows_per_image: int = 0, alpha: float = 1.0):
     """Row LayerNorm of a token matrix x [M, n] (fp32, n a multiple of 4, <= 256) with the row statistics kept for the backward
-    pass (grl_layernorm_train_fwd): returns (y, mean [M], rstd [M])."""
-    _dev_check(x, gamma, beta)
+    pass (grl_layernorm_train_fwd): returns (y, mean [M], rstd [M]).  ``resid``: y = resid + alpha * row_scale[row // rows_per_image]
+    * LayerNorm(x) -- a block's post-norm residual with its residual scale and DropPath keep mask in the same pass."""
+    _dev_check(x, gamma, beta, resid, row_scale)
     M, n = x.shape
     assert x.dtype == torch.float32 and x.stride(1) == 1 and n % 4 == 0 and n <= 256 and x.stride(0) % 4 == 0
+    assert resid is None or (resid.shape == x.shape and resid.dtype == torch.float32 and resid.stride(1) == 1 and resid.stride(0) % 4 == 0)
+    assert row_scale is None or (resid is not None and row_scale.dtype == torch.float32 and row_scale.is_contiguous() and rows_per_image > 0
+                                 and row_scale.numel() * rows_per_image >= M)
     g, b = gamma.detach().float().contiguous(), beta.detach().float().contiguous()
     y = empty(M, n, dtype=torch.float32, device=x.device)
-    mean = empty(M, dtype=torch.float32, device=x.device)
-    rstd = empty(M, dtype=torch.float32, device=x.device)
+    stats = empty(2, M, dtype=torch.float32, device=x.device)
+    mean, rstd = stats[0], stats[1]
     args = L.GrlLnTrainArgs(x=_ptr(x), ldx=x.stride(0), gamma=_ptr(g), beta=_ptr(b), y=_ptr(y), ldy=n, mean=_ptr(mean), rstd=_ptr(rstd),
-                            M=M, n=n, eps=eps)
+                            M=M, n=n, eps=eps, resid=_ptr(resid), ldr=resid.stride(0) if resid is not None else 0,
+                            row_scale=_ptr(row_scale), rows_per_image=rows_per_image, alpha=alpha if resid is not None else 0.0)
     with _timed("layernorm_train"):
         L.check(L.lib().grl_layernorm_train_fwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_train_fwd")
     return y, mean, rstd
 
 
-def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor):
-    """(dx, dgamma, dbeta) of layernorm_train (grl_layernorm_bwd)."""
-    _dev_check(dy, x, mean, rstd, gamma)
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: torch.Tensor, gamma: torch.Tensor,
+                  row_scale: Optional[torch.Tensor] = None, rows_per_image: int = 0, alpha: float = 0.0):
+    """(dx, dgamma, dbeta) of layernorm_train (grl_layernorm_bwd); ``alpha`` != 0: of its fused-residual form (dy = dL/dy of the sum)."""
+    _dev_check(dy, x, mean, rstd, gamma, row_scale)
     M, n = x.shape
     assert dy.shape == x.shape and dy.dtype == torch.float32 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
     g = gamma.detach().float().contiguous()
     dx = empty(M, n, dtype=torch.float32, device=x.device)
-    dgamma = torch.zeros(n, dtype=torch.float32, device=x.device)
-    dbeta = torch.zeros(n, dtype=torch.float32, device=x.device)
+    dgb = torch.zeros(2, n, dtype=torch.float32, device=x.device)       # (dgamma | dbeta: one fill)
     args = L.GrlLnTrainArgs(x=_ptr(x), ldx=x.stride(0), gamma=_ptr(g), mean=_ptr(mean), rstd=_ptr(rstd), dy=_ptr(dy), lddy=dy.stride(0),
-                            dx=_ptr(dx), lddx=n, dgamma=_ptr(dgamma), dbeta=_ptr(dbeta), M=M, n=n, eps=0.0)
+                            dx=_ptr(dx), lddx=n, dgamma=_ptr(dgb[0]), dbeta=_ptr(dgb[1]), M=M, n=n, eps=0.0,
+                            row_scale=_ptr(row_scale), rows_per_image=rows_per_image, alpha=alpha)
     with _timed("layernorm_bwd"):
         L.check(L.lib().grl_layernorm_bwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_bwd")
-    return dx, dgamma, dbeta
+    return dx, dgb[0], dgb[1]
 
 
 def _planes_args(x, scale, src, raw, one_cols, want):
@@ -959,3 +966,13 @@ def pack_conv_train(w: torch.Tensor, b: Optional[torch.Tensor], rows_pad: int, c
     L.check(L.lib().grl_pack_conv3x3(L.stream_ptr(), _ptr(wc), _ptr(bc), _ptr(ow), _ptr(ob), Cout, Cin, rows_pad, cols_pad, int(flip_t)),
             "grl_pack_conv3x3")
     return ow, ob
+
+
+def pack_linear_train(w: torch.Tensor, wp: torch.Tensor, wt: Optional[torch.Tensor]) -> None:
+    """grl_pack_linear: wp [Np, Kp] (fp16) <- zero-padded w [N, K]; wt [Kp, Np] <- its transpose (optional); one launch."""
+    _dev_check(w, wp, wt)
+    N, K = w.shape
+    Np, Kp = wp.shape
+    wc = w.detach().float().contiguous()
+    assert wp.dtype == GEMM_DTYPE and wp.is_contiguous() and (wt is None or (wt.dtype == GEMM_DTYPE and wt.is_contiguous() and wt.shape == (Kp, Np)))
+    L.check(L.lib().grl_pack_linear(L.stream_ptr(), _ptr(wc), _ptr(wp), _ptr(wt), N, K, Np, Kp), "grl_pack_linear")

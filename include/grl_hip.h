@@ -537,6 +537,14 @@ typedef struct GrlLnTrainArgs {
     float* dbeta;
     int32_t M, n;
     float eps;
+    /* ABI 22 -- the post-norm residual of a block in the same pass (mixed_attn_block_efficient.py:543-556: x + res_scale *    */
+    /* DropPath(norm(f(x)))):  forward, resid != NULL: y = resid + c_row * LayerNorm(x);  backward, alpha != 0: dy is dL/dy of   */
+    /* that sum and is multiplied by c_row first (dL/dresid = dy is the caller's).  c_row = alpha * row_scale[row /              */
+    /* rows_per_image] (row_scale: one keep-mask entry per image, NULL = 1).                                                     */
+    const float* resid; int64_t ldr;
+    const float* row_scale;
+    int32_t rows_per_image;
+    float alpha;
 } GrlLnTrainArgs;
 
 int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args);
@@ -549,6 +557,11 @@ int grl_layernorm_bwd(void* stream, const GrlLnTrainArgs* args);
  *   out_b (optional): fp32 [rows_pad] = b padded with zeros (b may be NULL: all zeros). */
 int grl_pack_conv3x3(void* stream, const float* w, const float* b, void* out_w, float* out_b, int32_t Cout, int32_t Cin,
                      int32_t rows_pad, int32_t cols_pad, int32_t flip_t);
+
+/* nn.Linear weight for grl_linear_fwd and for its data-gradient launch in one launch (ABI 22, training path):
+ *   w [N][K] fp32 (mixed_attn_block.py:669-676, 727-736; mixed_attn_block_efficient.py:379; swin_v1_block.py:29-33)
+ *   -> out_w fp16 [Np][Kp] zero padded, and (optional) out_wt fp16 [Kp][Np], its transpose. */
+int grl_pack_linear(void* stream, const float* w, void* out_w, void* out_wt, int32_t N, int32_t K, int32_t Np, int32_t Kp);
 
 /* Head planes of the training path (ABI 21): projection output x [T, S_in, nh, d] (fp32) -> the attention operands, fp32 planes
  * out32 [S_out][nh][T][32] and their fp16 copy out16, forward; dx and the scale gradients, backward.

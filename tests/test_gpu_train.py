@@ -426,3 +426,42 @@ def test_conv3x3_real_widths_equal_the_padded_path(B, H, W, Cin, Cout):
             AG._REAL_WIDTHS[0] = prev
     assert torch.equal(res[True][0], res[False][0]) and torch.equal(res[True][1], res[False][1])
     assert _rel(res[True][2], res[False][2]) < 1e-5 and _rel(res[True][3], res[False][3]) < 1e-5
+
+
+@pytest.mark.parametrize("rows_per_image,drop", [(250, True), (250, False)])
+def test_layer_norm_residual_matches_the_torch_chain(rows_per_image, drop):
+    """resid + alpha * keep_mask[image] * LayerNorm(x) inside the LayerNorm launches (autograd.layer_norm_residual, csrc/ln_train.hip)
+    against the torch expression it replaces (F.layer_norm + addcmul), values and all four gradients."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(49)
+    M, n = 4 * rows_per_image, 180
+    x, r = torch.randn(M, n, generator=g).cuda() * 3 + 1, torch.randn(M, n, generator=g).cuda()
+    gm, bt = (1 + 0.1 * torch.randn(n, generator=g)).cuda(), (0.1 * torch.randn(n, generator=g)).cuda()
+    mask = torch.tensor([1.0, 0.0, 1.0, 1.0]).cuda() if drop else None
+    dy = torch.randn(M, n, generator=g).cuda()
+    outs = []
+    for fused in (True, False):
+        xs, rs, gs, bs = (t.clone().requires_grad_(True) for t in (x, r, gm, bt))
+        if fused:
+            y = AG.layer_norm_residual(rs, xs, gs, bs, 1e-5, mask, rows_per_image, 0.4)
+        else:
+            t = F.layer_norm(xs, (n,), gs, bs, 1e-5)
+            y = rs + 0.4 * (t if mask is None else (t.view(4, -1, n) * mask.view(4, 1, 1)).view(M, n))
+        y.backward(dy)
+        outs.append((y.detach(), xs.grad, rs.grad, gs.grad, bs.grad))
+    for a, b in zip(*outs):
+        assert _rel(a, b) < 2e-5
+
+
+def test_pack_linear_train_matches_the_torch_packing():
+    from grl_image_restoration_amd import ops
+
+    g = torch.Generator().manual_seed(50)
+    for N, K, Np, Kp in [(180, 180, 192, 192), (540, 180, 576, 192), (90, 180, 96, 192), (180, 360, 192, 384), (33, 70, 64, 96)]:
+        w = torch.randn(N, K, generator=g).cuda()
+        wp, wt = torch.full((Np, Kp), 7.0, dtype=torch.float16).cuda(), torch.full((Kp, Np), 7.0, dtype=torch.float16).cuda()
+        ops.pack_linear_train(w, wp, wt)
+        ref = torch.zeros(Np, Kp, dtype=torch.float16).cuda()
+        ref[:N, :K] = w.half()
+        assert torch.equal(wp, ref) and torch.equal(wt, ref.t().contiguous())
