@@ -16,6 +16,7 @@
 // reduction index in its k-slots -- so nothing is transposed in registers.  Four waves = 2 x 2 tiles of
 // mfma_f32_32x32x16_f16; partial tiles of the M slabs are combined with fp32 atomics (C must be zeroed by the caller).
 #include "common.h"
+#include <stdlib.h>
 #include "grl_hip_internal.h"
 
 namespace {
@@ -39,13 +40,30 @@ __device__ __forceinline__ f16x8 load8_f16(const void* base, int dtype, int64_t 
     return v;
 }
 
+// (csrc/attn_common.h: xcd_remap) XCD x works on a contiguous range of the n work items; bijective for any n
+__device__ __forceinline__ int xcd_remap_tn(int bid, int n) {
+    const int q = n >> 3, r = n & 7, x = bid & 7;
+    return (x < r ? x * (q + 1) : r * (q + 1) + (x - r) * q) + (bid >> 3);
+}
+
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
     __shared__ __attribute__((aligned(16))) char As[GM * GROW];
     __shared__ __attribute__((aligned(16))) char Bs[GM * GROW];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int half = lane >> 5, l31 = lane & 31;
-    const int n0 = blockIdx.x * GT, k0 = blockIdx.y * GT;
-    const int tap = blockIdx.z / p.splits, slab = blockIdx.z - tap * p.splits;
+    // Work item = (slab of M, tap; output tile).  The tiles of one slab read the same rows of a and b -- a is re-read by every k tile,
+    // b by every n tile -- so they are kept on ONE XCD, next to each other in time: its L2 then serves the re-reads (the dispatcher
+    // places workgroup i on XCD i % 8; with the plain blockIdx order the 27 tiles of a QKV slab were spread over all eight L2s and
+    // every one of them fetched its own copy).  GRL_GEMM_TN_XCD=0 at launch time restores the plain order (A/B timing).
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (p.reserved0 == 0) {
+        const int T = gridDim.x * gridDim.y;
+        const int w = xcd_remap_tn(bx + gridDim.x * (by + gridDim.y * bz), T * gridDim.z);
+        const int tile = w % T;
+        bz = w / T; by = tile / gridDim.x; bx = tile - by * gridDim.x;
+    }
+    const int n0 = bx * GT, k0 = by * GT;
+    const int tap = bz / p.splits, slab = bz - tap * p.splits;
     const int dy = p.taps == 9 ? tap / 3 - 1 : 0, dx = p.taps == 9 ? tap % 3 - 1 : 0;
     // M slab of this workgroup (multiple of GM rows)
     const int pieces = (p.M + GM - 1) / GM;
@@ -183,7 +201,10 @@ extern "C" int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args) {
     if (p.taps == 9 && (p.H <= 0 || p.W <= 0 || p.M % (p.H * p.W) != 0)) return GRL_ERR_BAD_ARG;
     if (p.splits <= 0 || p.splits * p.taps > 65535 || (p.c == nullptr && p.c_fix == nullptr)) return GRL_ERR_BAD_ARG;
     const dim3 grid((p.N + GT - 1) / GT, (p.K + (p.b_ones ? 1 : 0) + GT - 1) / GT, p.splits * p.taps);
-    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, p);
+    GrlGemmTnArgs q = p;
+    static const int plain_order = getenv("GRL_GEMM_TN_XCD") ? atoi(getenv("GRL_GEMM_TN_XCD")) == 0 : 0;
+    q.reserved0 = plain_order;         // (kernel-internal use of the reserved field: 1 = blockIdx order)
+    hipLaunchKernelGGL(gemm_tn_kernel, grid, dim3(256), 0, (hipStream_t)stream, q);
     GRL_CHECK_LAUNCH();
     return 0;
 }

@@ -789,7 +789,11 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, 
     cb = buf[taps * N * K :] if b_ones else None
     kcols = K + (1 if b_ones else 0)
     tiles = ((N + 63) // 64) * ((kcols + 63) // 64) * taps
-    splits = max(1, min((M + 255) // 256, (1024 + tiles - 1) // tiles))   # >= ~1000 workgroups, >= 256 rows each
+    # ~1000 workgroups of >= 256 rows each; measured per shape with the XCD-aware tile order (tools/bench_gemm_tn.py, 512 / 768 /
+    # 1024 / 1536 / 2048): the 3 x 3-tile proj gradient is fastest at 512 (42 against 51 us), the nine-tap 184 x 192 stage convolution
+    # at 1536 (118 against 137), everything else at 1024
+    wgs = int(os.environ.get("GRL_GEMM_TN_WGS", "0")) or (512 if tiles <= 9 else (1536 if tiles >= 81 else 1024))
+    splits = max(1, min((M + 255) // 256, (wgs + tiles - 1) // tiles))
     args = L.GrlGemmTnArgs(a=_ptr(a), lda=a.stride(0), b=_ptr(b), b_dtype=_KIND[b.dtype], ldb=b.stride(0), M=M, N=N, K=K, taps=taps,
                            H=H, W=W, splits=splits, a_scale=a_scale, out_scale=out_scale, c=None if det else _ptr(c), ldc=K,
                            c_tap_stride=N * K, c_fix=_ptr(c) if det else None, b_ones=int(b_ones),

@@ -14,16 +14,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from grl_image_restoration_amd import ops  # noqa: E402
 
 M, H, W = 8 * 64 * 64, 64, 64
-shapes = [("qkv 576x192", 576, 192, 1), ("proj 192x192", 192, 192, 1), ("fc1 384x192", 384, 192, 1), ("fc2 192x384", 192, 384, 1),
-          ("anchor 96x192 (M/4)", 96, 192, 1), ("cab conv1 48x192 x9", 48, 192, 9), ("cab conv2 184x64 x9", 184, 64, 9), ("stage conv 184x192 x9", 184, 192, 9)]
+shapes = [("qkv 540x180", 540, 180, 1), ("proj 180x180", 180, 180, 1), ("fc1 360x180", 360, 180, 1), ("fc2 180x360", 180, 360, 1),
+          ("anchor 96x180 (M/4)", 96, 180, 1), ("cab conv1 48x180 x9", 48, 180, 9), ("cab conv2 180x64 x9", 180, 64, 9), ("stage conv 184x192 x9", 184, 192, 9)]
 g = torch.Generator().manual_seed(0)
 tot = 0.0
 for name, N, K, taps in shapes:
     m = M // 4 if "M/4" in name else M
-    a = (torch.randn(m, (N + 7) // 8 * 8, generator=g) * 1e-4).cuda()
+    a = (torch.randn(m, N, generator=g) * 1e-4).cuda()          # (real widths: row strides of N and K floats, as the training path passes them)
     b = torch.randn(m, K, generator=g).cuda()
-    n8 = (N + 7) // 8 * 8
-    f = lambda: ops.gemm_tn(a, b, n8, K, taps=taps, hw=(H, W) if taps == 9 else None, a_scale=4096.0, out_scale=1 / 4096.0)
+    ones = K % 32 != 0
+    f = lambda: ops.gemm_tn(a, b, N, K, taps=taps, hw=(H, W) if taps == 9 else None, a_scale=4096.0, out_scale=1 / 4096.0, b_ones=ones)
     for _ in range(3):
         f()
     torch.cuda.synchronize()
@@ -33,7 +33,7 @@ for name, N, K, taps in shapes:
         f()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
-    fl = 2.0 * m * n8 * K * taps
+    fl = 2.0 * m * N * K * taps
     tot += us
     print(f"{name:26s} {us:8.1f} us  {fl / us / 1e6:7.1f} TFLOP/s")
 print(f"sum {tot:.1f} us")
