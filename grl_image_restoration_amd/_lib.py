@@ -353,6 +353,7 @@ class GrlAttnBwdArgs(_Strict):
         ("d_table", C.c_void_p),
         ("g_scale", C.c_float),
         ("d_table_fix", C.c_void_p),
+        ("d_o_ld", C.c_int64),
     ]
 
 

@@ -256,8 +256,10 @@ def _bias_padded(b, N, Np, device):
 
 
 @torch.library.custom_op("grl::linear", mutates_args=())
-def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> torch.Tensor:
-    """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in grl_linear_fwd)."""
+def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_col: int = -1) -> torch.Tensor:
+    """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in grl_linear_fwd).  ``one_col`` >= 0: the caller's promise
+    that column one_col of x holds 1.0 (against a zero weight column) -- the bias gradient is then read off the weight-gradient
+    contraction, as with the pad column elsewhere, instead of a separate column sum of dy."""
     M, K = x.shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
@@ -276,12 +278,13 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor]) -> to
 
 
 @linear_op.register_fake
-def _(x, w, b):
+def _(x, w, b, one_col=-1):
     return x.new_empty(x.shape[0], w.shape[0], dtype=torch.float32)
 
 
 def _linear_setup(ctx, inputs, output):
-    x, w, b = inputs
+    x, w, b, one_col = inputs
+    ctx.one_col = int(one_col)
     xp = _take_operand(x)
     # the operand the forward launch read -- [x | 1 | 0], or x itself where the kernels take real widths -- is all the backward needs
     # of x: saved INSTEAD of x (both were kept, doubling the saved activation of every layer whose width is not a kernel
@@ -326,11 +329,13 @@ def _linear_backward(ctx, dy):
             full = ops.gemm_tn(dya, xb, Ng, Kg, a_scale=s, out_scale=1.0 / s)
             if want_b and Kg > K:
                 db = full[0][:N, K]                                  # the ones column of [x | 1 | 0]: sum over the rows of dy
+            elif want_b and 0 <= ctx.one_col < K:
+                db = full[0][:N, ctx.one_col]                        # a column of x that holds 1.0 (the caller's promise)
         if ctx.needs_input_grad[1]:
             dw = full[0][:N, :K]                                     # (contiguous -- adopted as .grad without a copy -- when Kg == K)
     if want_b and db is None:
         db = dy.float().sum(0)
-    return dx, dw, db
+    return dx, dw, db, None
 
 
 linear_op.register_autograd(_linear_backward, setup_context=_linear_setup)
@@ -442,17 +447,20 @@ def _attn_operands(q, k, v, d, prepared, have=(None, None, None)):
 def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch.Tensor, floor: torch.Tensor, qgeo: Sequence[int],
                  kgeo: Sequence[int], B: int, nh: int, d: int, masked: bool, prepared: bool = False,
                  q16: Optional[torch.Tensor] = None, k16: Optional[torch.Tensor] = None,
-                 v16: Optional[torch.Tensor] = None) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
+                 v16: Optional[torch.Tensor] = None,
+                 token_major: bool = False) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor, torch.Tensor]:
     """softmax(q k^T + bias (+ mask)) v over every window (grl_attention_fwd); operands are fp32 head planes [nh, tokens, 32]
     (fp16 in the kernel): q = normalised * scale * log2e, k normalised, v raw; ``table`` from tables.kernel_table; ``floor`` from
     tables.lazy_floor; qgeo / kgeo = (Himg, Wimg, wh, ww, shy, shx).  Returns (fp32 planes [nh, q_tokens, 32], log2-sum-exp2,
     and the fp16 operand planes the kernel ran on -- kept for the backward pass instead of converting them again).
     ``q16`` / ``k16`` / ``v16``: fp16 copies of (prepared) q / k / v the caller already has -- GRL._block_train converts the planes of
     a whole block in one launch instead of three per attention call; the matching outputs are empty then (an op's outputs must not
-    alias its inputs) and the backward takes the operands from the inputs."""
+    alias its inputs) and the backward takes the operands from the inputs.  ``token_major``: the output as a token matrix
+    [q_tokens, nh * 32] instead of head planes -- what the projection behind the attention reads (round 6: the planes of the two
+    branches were concatenated, permuted and sliced into it, and the gradient took the same way back)."""
     have = (q16, k16, v16)
     q16, k16, v16 = _attn_operands(q, k, v, d, prepared, have)
-    o = ops.empty(nh, q.shape[1], 32, dtype=torch.float32, device=q.device)
+    o = ops.empty(*((q.shape[1], nh * 32) if token_major else (nh, q.shape[1], 32)), dtype=torch.float32, device=q.device)
     lse = ops.empty(nh, q.shape[1], dtype=torch.float32, device=q.device)
     TG = ops.TokenGrid
     ops.attention(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), B=B, nh=nh, table=table.detach().contiguous(),
@@ -462,14 +470,15 @@ def attention_op(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, table: torch
 
 
 @attention_op.register_fake
-def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared=False, q16=None, k16=None, v16=None):
+def _(q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared=False, q16=None, k16=None, v16=None, token_major=False):
     h = lambda t, g: t.new_empty(t.shape if g is None else (0,), dtype=ops.PLANE_DTYPE)
-    return (q.new_empty(nh, q.shape[1], 32, dtype=torch.float32), q.new_empty(nh, q.shape[1], dtype=torch.float32),
+    return (q.new_empty(*((q.shape[1], nh * 32) if token_major else (nh, q.shape[1], 32)), dtype=torch.float32),
+            q.new_empty(nh, q.shape[1], dtype=torch.float32),
             h(q, q16), h(k, k16), h(v, v16))
 
 
 def _attn_setup(ctx, inputs, output):
-    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared, q16_in, k16_in, v16_in = inputs
+    q, k, v, table, floor, qgeo, kgeo, B, nh, d, masked, prepared, q16_in, k16_in, v16_in, token_major = inputs
     o, lse, q16, k16, v16 = output
     q16, k16, v16 = (i if i is not None else t for i, t in zip((q16_in, k16_in, v16_in), (q16, k16, v16)))
     ctx.save_for_backward(q16, k16, v16, table, o, lse)
@@ -483,12 +492,13 @@ def _attn_backward(ctx, d_o, d_lse, d_q16, d_k16, d_v16):
     q16, k16, v16, table, o, lse = ctx.saved_tensors
     qgeo, kgeo, B, nh, d, masked = ctx.geo
     if d_o is None:                      # (set_materialize_grads(False): the output took no part in the loss)
-        return (None,) * 15
+        return (None,) * 16
     TG = ops.TokenGrid
-    dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o.float().contiguous(),
+    d_o = _rows16(d_o) if d_o.dim() == 2 else d_o.float().contiguous()      # (token-major: a column block of the projection's input gradient)
+    dq, dk, dv, dtab = ops.attention_bwd(TG(q16, 0, *qgeo), TG(k16, 0, *kgeo), TG(v16, 0, *kgeo), TG(o, 0, *qgeo), d_o,
                                          lse, B=B, nh=nh, table=table.detach().contiguous(), masked=masked, ones_col=d if d < 32 else -1,
                                          head_dim=d, g_scale=grad_scale(d_o.device))
-    return dq, dk, dv, dtab, None, None, None, None, None, None, None, None, None, None, None
+    return dq, dk, dv, dtab, None, None, None, None, None, None, None, None, None, None, None, None
 
 
 attention_op.register_autograd(_attn_backward, setup_context=_attn_setup)
@@ -613,17 +623,19 @@ class AttentionFn:
 
     @staticmethod
     def apply(q, k, v, table, geo):
+        tm = bool(geo.get("token_major", False))
         if not q.is_cuda:
-            return composite.attention(q, k, v, table, list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]))
+            o = composite.attention(q, k, v, table, list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]))
+            return o.permute(1, 0, 2).reshape(o.shape[1], -1) if tm else o
         q16, k16, v16 = geo.get("f16", (None, None, None))
         return attention_op(q, k, v, table, geo["floor"], list(geo["q"]), list(geo["k"]), geo["B"], geo["nh"], geo["d"], bool(geo["masked"]),
-                            bool(geo.get("prepared", False)), q16, k16, v16)[0]
+                            bool(geo.get("prepared", False)), q16, k16, v16, tm)[0]
 
 
-def linear(x, w, b=None):
+def linear(x, w, b=None, one_col: int = -1):
     if not x.is_cuda:                      # CPU tensors: the composite torch path (composite.py; never a CUDA tensor)
         return composite.linear(x, w, b)
-    return linear_op(x, w, b)
+    return linear_op(x, w, b, one_col)
 
 
 def conv3x3(x, w, b, B, H, W):

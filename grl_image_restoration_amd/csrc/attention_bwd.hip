@@ -70,9 +70,13 @@ __device__ __forceinline__ f16x8 load_f16x8(const GrlTokenGrid& g, int64_t row, 
     return *(const f16x8*)((const f16*)g.ptr + row * g.ld + g.col0 + head * g.hstride + seg * 8);
 }
 
-__device__ __forceinline__ f16x8 load_f32x8_as_f16(const float* base, const GrlTokenGrid& g, int64_t row, int head, int seg, float scale) {
-    const float4* q = (const float4*)(base + row * g.ld + g.col0 + head * g.hstride + seg * 8);
+// dO lies on o's grid except, optionally, for its row stride (GrlAttnBwdArgs.d_o_ld: a column block of a wider gradient matrix)
+__device__ __forceinline__ f16x8 load_do_as_f16(const GrlAttnBwdArgs& a, int64_t row, int head, int seg) {
+    const GrlTokenGrid& g = a.fwd.o;
+    const int64_t ld = a.d_o_ld > 0 ? a.d_o_ld : g.ld;
+    const float4* q = (const float4*)(a.d_o + row * ld + g.col0 + head * g.hstride + seg * 8);
     const float4 a0 = q[0], a1 = q[1];
+    const float scale = a.g_scale;
     f16x8 v;
     v[0] = to_f16(a0.x * scale); v[1] = to_f16(a0.y * scale); v[2] = to_f16(a0.z * scale); v[3] = to_f16(a0.w * scale);
     v[4] = to_f16(a1.x * scale); v[5] = to_f16(a1.y * scale); v[6] = to_f16(a1.z * scale); v[7] = to_f16(a1.w * scale);
@@ -255,8 +259,8 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdLaunch a, int sp
         qf[t][0] = load_f16x8(p.q, qrow[t], head, half);
         qf[t][1] = load_f16x8(p.q, qrow[t], head, 2 + half);
         // slot 31 of q carries the forward kernel's running offset in registers only: in memory it is a pad column (0)
-        dof[t][0] = load_f32x8_as_f16(a.d_o, p.o, qrow[t], head, half, a.g_scale);
-        dof[t][1] = load_f32x8_as_f16(a.d_o, p.o, qrow[t], head, 2 + half, a.g_scale);
+        dof[t][0] = load_do_as_f16(a, qrow[t], head, half);
+        dof[t][1] = load_do_as_f16(a, qrow[t], head, 2 + half);
         // D_i = sum_c dO_ic O_ic (scaled like dO): this lane holds 16 of the 32 columns.  Taken from the SAME fp16-rounded dO the
         // MFMA contracts with v: dS = P (dO.v_j - D_i) is a small difference of two nearly equal numbers wherever the values of a
         // window resemble each other (stripe tokens -> anchors: v is the anchors' aggregate), and with D from the unrounded dO the
@@ -490,7 +494,7 @@ __global__ __launch_bounds__(256, 2) void attn_dkv_kernel(GrlAttnBwdLaunch a, in
             float dpart = 0.f;
             if (valid) {
                 qv = load_f16x8(p.q, row, head, seg);
-                gv = load_f32x8_as_f16(a.d_o, p.o, row, head, seg, a.g_scale);
+                gv = load_do_as_f16(a, row, head, seg);
                 const float* op = (const float*)p.o.ptr + row * p.o.ld + p.o.col0 + head * p.o.hstride + seg * 8;
 #pragma unroll
                 for (int e = 0; e < 8; ++e)                              // (from the rounded dO: see attn_dq_kernel)
@@ -636,13 +640,14 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
     if (p.trows != (p.q.wh + p.k.wh - 1) * (p.q.ww + p.k.ww - 1) || p.tstride < p.trows || (p.tstride & 3)) return GRL_ERR_BAD_ARG;
     if (p.head_dim > 32 || p.out_dtype != GRL_DT_F32 || p.lse == nullptr || p.lse_stride <= 0) return GRL_ERR_BAD_ARG;
     if (!a.d_o || !a.d_q || !a.d_k || !a.d_v || !a.d_table || !(a.g_scale > 0.f)) return GRL_ERR_BAD_ARG;
+    if (a.d_o_ld < 0 || (a.d_o_ld % 4) || ((uintptr_t)a.d_o & 15)) return GRL_ERR_BAD_ARG;
     if ((p.q.ld % 8) || (p.k.ld % 8) || (p.v.ld % 8) || (p.o.ld % 8) || (p.q.col0 % 8) || (p.k.col0 % 8) || (p.v.col0 % 8) ||
         (p.o.col0 % 8) || (p.q.hstride % 8) || (p.k.hstride % 8) || (p.v.hstride % 8) || (p.o.hstride % 8))
         return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;
     GrlAttnBwdLaunch a_l;                               // the caller's arguments + the table-window sizes of the two launches
     a_l.fwd = a.fwd; a_l.d_o = a.d_o; a_l.d_q = a.d_q; a_l.d_k = a.d_k; a_l.d_v = a.d_v; a_l.d_table = a.d_table; a_l.g_scale = a.g_scale;
-    a_l.d_table_fix = a.d_table_fix; a_l.tab_window = 0; a_l.tab_window_kv = 0;
+    a_l.d_table_fix = a.d_table_fix; a_l.d_o_ld = a.d_o_ld; a_l.tab_window = 0; a_l.tab_window_kv = 0;
     const int Dw = p.q.ww + p.k.ww - 1;
     // Split launches (see attn_dq_kernel): when a launch has fewer workgroups than the chip has CUs and a long streamed dimension,
     // cut that dimension over several workgroups that accumulate with atomics.  Needs a destination this function can zero: dense

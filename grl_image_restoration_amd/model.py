@@ -1226,9 +1226,13 @@ class GRL(nn.Module):
         g_tok_w = (H, W, ws[0], ws[1], sh, sh)
         g_tok_s = (H, W, st[0], st[1], ss[0], ss[1])
         g_anc = (Ha, Wa, ast[0], ast[1], ass[0], ass[1])
+        # (round 6: the two branch outputs as token matrices [M, nh * 32]: one cat along the channels gives the projection's input --
+        # _block_train_tail places the weight columns accordingly -- and the cat's backward hands each attention backward its column
+        # block of the gradient in place; before: cat of the planes, permute, slice, copy, and zeros + copy + two copies back)
+        tm = os.environ.get("GRL_TRAIN_TOKEN_MAJOR", "1") != "0"
         ow = AG.AttentionFn.apply(qw, kw, vw, tabs[0],
                                   dict(q=g_tok_w, k=g_tok_w, B=B, nh=nh, d=d, masked=sh > 0, floor=fw, prepared=True,
-                                       f16=(qw16, kw16, vw16)))
+                                       f16=(qw16, kw16, vw16), token_major=tm))
         y = AG.AttentionFn.apply(aq, ks, vs, tabs[1],
                                  dict(q=g_anc, k=g_tok_s, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f1, prepared=True,
                                       f16=(aq16, ks16, vs16)))
@@ -1241,7 +1245,9 @@ class GRL(nn.Module):
         yv = torch.addcmul(onev, y, dmask)                              # real head dims only, and the constant 1.0 in column d again
         os_ = AG.AttentionFn.apply(qs, ak, yv, tabs[2],
                                    dict(q=g_tok_s, k=g_anc, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f2, prepared=True,
-                                        f16=(qs16, ak16, None)))
+                                        f16=(qs16, ak16, None), token_major=tm))
+        if tm:
+            return torch.cat([ow, os_], dim=1)                          # [M, 2 * nh * 32]
         return torch.cat([ow, os_], dim=0).permute(1, 0, 2)[..., :d].reshape(M, C)
 
     def _block_train_tail(self, r, att, blk: _Block, B, H, W, dp: float):
@@ -1249,7 +1255,21 @@ class GRL(nn.Module):
         C = self.embed_dim
         M = B * H * W
         a = blk.attn
-        x1 = AG.linear(att, a.proj.weight, a.proj.bias)
+        if att.shape[1] != C:
+            # att = [M, heads * 32]: head h's d channels at columns 32 h .. 32 h + d - 1 (the attention kernels' own layout); the weight
+            # columns go where their channels are, zero elsewhere.  Column d of a head holds the softmax denominator over itself = 1.0
+            # (v's ones column through the PV product): the bias gradient's ones column.
+            nht = att.shape[1] // 32
+            dh = C // nht
+            cache = self.__dict__.setdefault("_coords_cache", {})
+            zkey = ("wzero", C, nht, 32 - dh, str(att.device))
+            zb = cache.get(zkey)
+            if zb is None:
+                zb = cache[zkey] = torch.zeros(C, nht, 32 - dh, dtype=torch.float32, device=att.device)
+            wpad = torch.cat([a.proj.weight.view(C, nht, dh), zb], dim=2).view(C, nht * 32)
+            x1 = AG.linear(att, wpad, a.proj.bias, one_col=dh if dh < 32 else -1)
+        else:
+            x1 = AG.linear(att, a.proj.weight, a.proj.bias)
         x1 = self._norm_residual(r, x1, blk.norm1, H * W, dp)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
             c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention

@@ -819,7 +819,10 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     """Gradients of grl_attention_fwd w.r.t. its operands: (d_q, d_k, d_v, d_table), fp32, laid out like q, k, v (fp32 planes of
     the same shape) and table.  ``o``: the forward output grid (fp32), ``d_o`` its gradient (same layout), ``lse`` from the forward."""
     _dev_check(q.t, k.t, v.t, o.t, d_o, lse, table)
-    assert o.t.dtype == torch.float32 and d_o.dtype == torch.float32 and d_o.shape == o.t.shape and d_o.is_contiguous() and o.t.is_contiguous()
+    assert o.t.dtype == torch.float32 and d_o.dtype == torch.float32 and d_o.shape == o.t.shape and o.t.is_contiguous()
+    # d_o: on o's grid; a token-major o [tokens, nh * 32] may come with a gradient that is a column block of a wider matrix (row stride)
+    assert d_o.is_contiguous() or (d_o.dim() == 2 and d_o.stride(1) == 1 and d_o.stride(0) % 4 == 0 and d_o.data_ptr() % 16 == 0)
+    d_o_ld = 0 if d_o.is_contiguous() else d_o.stride(0)
     assert q.t.is_contiguous() and k.t.is_contiguous() and v.t.is_contiguous() and q.slot == 0 and k.slot == 0 and v.slot == 0 and o.slot == 0
     # every token of q / k / v belongs to exactly one window of the launch: the kernels write all 32 columns of every row
     d_q = empty(q.t.shape, dtype=torch.float32, device=q.t.device)
@@ -829,7 +832,7 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     fix = torch.zeros(table.shape, dtype=torch.int64, device=table.device) if deterministic() else None
     fwd = _attn_args(q, k, v, o, B, nh, table, masked, ones_col, head_dim, False, None, lse)
     args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale,
-                            d_table_fix=_ptr(fix))
+                            d_table_fix=_ptr(fix), d_o_ld=d_o_ld)
     with _timed("attention_bwd"):
         L.check(L.lib().grl_attention_bwd(L.stream_ptr(), C.byref(args)), "grl_attention_bwd")
     if fix is not None:

@@ -488,6 +488,9 @@ typedef struct GrlAttnBwdArgs {
                             /* filled in program order) and the workgroups' tables are added as 64-bit fixed point (2^32 x the   */
                             /* g_scale-d sums) into this zeroed [nh, tstride] array instead of `d_table`; the caller converts:   */
                             /* d_table = d_table_fix * 2^-32 / g_scale.  Bit-identical gradients run to run.                     */
+    int64_t d_o_ld;         /* optional (ABI 22): row stride of d_o in floats when it differs from o's (0 = o's): d_o as a column  */
+                            /* block of a wider gradient matrix -- the two branches' outputs are concatenated along the channels     */
+                            /* before the projection (mixed_attn_block_efficient.py:374-379), so their gradients arrive that way     */
 } GrlAttnBwdArgs;
 
 int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args);
