@@ -33,6 +33,7 @@ namespace {
 struct GrlAttnBwdLaunch : GrlAttnBwdArgs {
     int32_t tab_window;      // floats of a table window in attn_dq_kernel's LDS (table and histogram)
     int32_t tab_window_kv;   // ... in attn_dkv_kernel's
+    int32_t no_prefetch;     // GRL_ATTN_BWD_PREFETCH=0: attn_dq_kernel stages every chunk behind its loads (A/B timing)
 };
 
 constexpr int QT = 2;            // tiles (32 queries resp. keys) per wave
@@ -285,31 +286,69 @@ __global__ __launch_bounds__(256) void attn_dq_kernel(GrlAttnBwdLaunch a, int sp
     }
 
     const int nchunks = (Nk + KC - 1) / KC;
-    for (int ch = sp * nchunks / splits; ch < (sp + 1) * nchunks / splits; ++ch) {
+    // Round 6: with the full 256 threads a chunk is two (key, 16-byte segment) items per thread, and their K / V loads for chunk ch + 1
+    // are ISSUED before the tiles of chunk ch are computed (16 registers); the LDS stores follow behind the next barrier.  Before, every
+    // chunk began with the full global-load latency in front of its first tile -- with one wave per SIMD nothing else covers it.
+    const bool pre = nthreads == 256 && !a.no_prefetch;
+    const int ch_end = (sp + 1) * nchunks / splits;
+    f16x8 pk[2], pv[2];
+    int prid[2];
+    auto chunk_load = [&](int ch) {
+        const int k0 = ch * KC;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int i = tid + j * 256;
+            const int kk = i >> 2, seg = i & 3;
+            const int n = k0 + kk;
+            const bool valid = n < Nk;
+            int64_t row;
+            locate(p.k, b, wy, wx, valid ? n : 0, row, prid[j]);
+            pk[j] = f16x8{0, 0, 0, 0, 0, 0, 0, 0}; pv[j] = pk[j];
+            if (valid) {
+                pk[j] = load_f16x8(p.k, row, head, seg);
+                pv[j] = load_f16x8(p.v, row, head, seg);
+            }
+        }
+    };
+    auto stage_item = [&](int k0, int i, const f16x8& kv, const f16x8& vv, int rid) {
+        const int kk = i >> 2, seg = i & 3;
+        const int n = k0 + kk;
+        const bool valid = n < Nk;
+        *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
+        *(f16x8*)(Vs + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = vv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) *(f16*)(Kt + (seg * 8 + e) * TROW + kk * 2) = kv[e];
+        if (seg == 0) {
+            const int nn = valid ? n : 0;
+            const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
+            koff[kk] = hk * D + wk;
+            kreg[kk] = valid ? (unsigned char)rid : (unsigned char)255;
+        }
+    };
+    if (pre && sp * nchunks / splits < ch_end) chunk_load(sp * nchunks / splits);
+    for (int ch = sp * nchunks / splits; ch < ch_end; ++ch) {
         const int k0 = ch * KC;
         const int klen = min(KC, Nk - k0);
         const int ntiles = (klen + 31) >> 5;
         __syncthreads();
-        for (int i = tid; i < ntiles * 32 * 4; i += nthreads) {
-            const int kk = i >> 2, seg = i & 3;
-            const int n = k0 + kk;
-            const bool valid = n < Nk;
-            int64_t row; int rid;
-            locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
-            f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
-            if (valid) {
-                kv = load_f16x8(p.k, row, head, seg);
-                vv = load_f16x8(p.v, row, head, seg);
-            }
-            *(f16x8*)(Ks + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = kv;
-            *(f16x8*)(Vs + kk * 64 + ((seg ^ ((kk >> 2) & 3)) << 4)) = vv;
+        if (pre) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) *(f16*)(Kt + (seg * 8 + e) * TROW + kk * 2) = kv[e];
-            if (seg == 0) {
-                const int nn = valid ? n : 0;
-                const int hk = nn / p.k.ww, wk = nn - hk * p.k.ww;
-                koff[kk] = hk * D + wk;
-                kreg[kk] = valid ? (unsigned char)rid : (unsigned char)255;
+            for (int j = 0; j < 2; ++j)
+                if (tid + j * 256 < ntiles * 32 * 4) stage_item(k0, tid + j * 256, pk[j], pv[j], prid[j]);
+            if (ch + 1 < ch_end) chunk_load(ch + 1);       // in flight while this chunk's tiles are computed
+        } else {
+            for (int i = tid; i < ntiles * 32 * 4; i += nthreads) {
+                const int kk = i >> 2, seg = i & 3;
+                const int n = k0 + kk;
+                const bool valid = n < Nk;
+                int64_t row; int rid;
+                locate(p.k, b, wy, wx, valid ? n : 0, row, rid);
+                f16x8 kv = {0, 0, 0, 0, 0, 0, 0, 0}, vv = kv;
+                if (valid) {
+                    kv = load_f16x8(p.k, row, head, seg);
+                    vv = load_f16x8(p.v, row, head, seg);
+                }
+                stage_item(k0, i, kv, vv, rid);
             }
         }
         __syncthreads();
@@ -648,6 +687,8 @@ extern "C" int grl_attention_bwd(void* stream, const GrlAttnBwdArgs* args) {
     GrlAttnBwdLaunch a_l;                               // the caller's arguments + the table-window sizes of the two launches
     a_l.fwd = a.fwd; a_l.d_o = a.d_o; a_l.d_q = a.d_q; a_l.d_k = a.d_k; a_l.d_v = a.d_v; a_l.d_table = a.d_table; a_l.g_scale = a.g_scale;
     a_l.d_table_fix = a.d_table_fix; a_l.d_o_ld = a.d_o_ld; a_l.tab_window = 0; a_l.tab_window_kv = 0;
+    static const int no_pre = getenv("GRL_ATTN_BWD_PREFETCH") ? atoi(getenv("GRL_ATTN_BWD_PREFETCH")) == 0 : 0;
+    a_l.no_prefetch = no_pre;
     const int Dw = p.q.ww + p.k.ww - 1;
     // Split launches (see attn_dq_kernel): when a launch has fewer workgroups than the chip has CUs and a long streamed dimension,
     // cut that dimension over several workgroups that accumulate with atomics.  Needs a destination this function can zero: dense
