@@ -105,6 +105,8 @@ class GrlLinearArgs(_Strict):
         ("a_one", C.c_int32),
         ("n_store", C.c_int32),
         ("reserved0", C.c_int32),
+        ("a16_out", C.c_void_p),
+        ("lda16", C.c_int64),
     ]
 
 
@@ -340,6 +342,8 @@ class GrlGemmTnArgs(_Strict):
         ("reserved0", C.c_int32),
         ("c_bias", C.c_void_p),
         ("c_bias_fix", C.c_void_p),
+        ("a_dtype", C.c_int32),
+        ("reserved1", C.c_int32),
     ]
 
 

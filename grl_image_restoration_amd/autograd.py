@@ -246,6 +246,7 @@ def _real(n: int, npad: int) -> bool:
 
 
 _REAL_WIDTHS = [__import__("os").environ.get("GRL_REAL_WIDTHS", "1") != "0"]
+_F16_HANDOVER = [__import__("os").environ.get("GRL_F16_HANDOVER", "1") != "0"]     # linear layers: fp16 operand copies for the weight gradient
 
 
 def _bias_padded(b, N, Np, device):
@@ -271,6 +272,13 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_c
     else:
         xa, kw = _padded(x.detach().float(), Kp, ones=True), {}
         _leave_operand(x, xa)
+    if w.requires_grad and _F16_HANDOVER[0] and K % 4 == 0:
+        # the fp16 operand [x | 1 | 0] the kernel contracts, kept for the weight gradient INSTEAD of x: grl_gemm_tn then reads 2-byte
+        # values from 16-byte aligned rows once per output tile instead of converting the fp32 matrix every time (and the saved
+        # activation is half the size)
+        x16 = ops.empty(M, Kp, dtype=ops.GEMM_DTYPE, device=x.device)
+        kw["a16_out"] = x16
+        _leave_operand(x, x16)
     if _real(N, Np):
         return ops.linear(xa, wp, bp, out_dtype=torch.float32, n_store=N, **kw)
     y = ops.linear(xa, wp, bp, out_dtype=torch.float32, **kw)
@@ -291,6 +299,7 @@ def _linear_setup(ctx, inputs, output):
     # width -- C = 180 in all GRL-Base blocks)
     ctx.save_for_backward(xp if xp is not None else x, w)
     ctx.x_shape, ctx.padded = tuple(x.shape), xp is not None and xp.shape[1] != x.shape[1]
+    ctx.x16 = xp is not None and xp.dtype == ops.GEMM_DTYPE
     ctx.has_b = b is not None
 
 
@@ -306,14 +315,31 @@ def _linear_backward(ctx, dy):
     else:
         dya, dkw = _padded(dy.float(), Np), {}
     dx = dw = db = None
+    want_b = ctx.has_b and ctx.needs_input_grad[2]
+    need_w = ctx.needs_input_grad[1] or (want_b and Kp > K)
+    dy16 = None
     if ctx.needs_input_grad[0]:
         wt = _padded_weight(w, Np, Kp, transposed=True)            # [Kp, Np]: rows = input channels
+        if need_w and ctx.x16:                                     # the fp16 (scaled) dy of this launch feeds the weight gradient below
+            dy16 = dkw["a16_out"] = ops.empty(M, Np, dtype=ops.GEMM_DTYPE, device=dy.device)
         if rk:
             dx = ops.linear(dya, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s, n_store=K, **dkw)
         else:
             dx = ops.linear(dya, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s, **dkw)[:, :K]
-    want_b = ctx.has_b and ctx.needs_input_grad[2]
-    if ctx.needs_input_grad[1] or (want_b and Kp > K):
+    if need_w and ctx.x16:
+        # fp16 operands on both sides: xs = [x | 1 | 0] (Kp wide, the ones column routes the bias gradient), dy16 = s * dy (Np wide)
+        ga = dy16 if dy16 is not None else dya
+        Ng = N if (N % 4 == 0 and (dy16 is not None or rn or N == Np)) else Np       # (rows beyond N: zero pad columns of the operand)
+        if Kp > K:
+            full, cb = ops.gemm_tn(ga, xs, Ng, K, a_scale=s, out_scale=1.0 / s, b_ones=True)
+            db = cb[:N] if want_b else None
+        else:
+            full = ops.gemm_tn(ga, xs, Ng, K, a_scale=s, out_scale=1.0 / s)
+            if want_b and 0 <= ctx.one_col < K:
+                db = full[0][:N, ctx.one_col]                        # a column of x that holds 1.0 (the caller's promise)
+        if ctx.needs_input_grad[1]:
+            dw = full[0][:N]
+    elif need_w:
         if ctx.padded:
             xb = xs                                                  # [x | 1 | 0] of the forward launch
         elif rk:

@@ -70,6 +70,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
     const int per = (pieces + p.splits - 1) / p.splits;
     const int pc0 = slab * per, pc1 = min(pieces, pc0 + per);
     const int wn = wave & 1, wk = wave >> 1;
+    const bool a_f16 = p.a_dtype == GRL_DT_F16;       // (already a_scale-d: GrlLinearArgs.a16_out of the data-gradient launch)
 
     f32x16 acc;
 #pragma unroll
@@ -81,7 +82,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GrlGemmTnArgs p) {
         const int m = pc * GM + srow;
         f16x8 av = {0, 0, 0, 0, 0, 0, 0, 0}, bv = av;
         if (m < p.M) {
-            av = load8_f16(p.a, GRL_DT_F32, (int64_t)m * p.lda + n0 + sseg * 8, p.a_scale, p.N - (n0 + sseg * 8));
+            av = load8_f16(p.a, a_f16 ? GRL_DT_F16 : GRL_DT_F32, (int64_t)m * p.lda + n0 + sseg * 8, a_f16 ? 1.0f : p.a_scale, p.N - (n0 + sseg * 8));
             int64_t brow = m;
             bool inside = true;
             if (p.taps == 9) {   // image shift: B row of pixel (y + dy, x + dx), zero outside the image
@@ -193,8 +194,10 @@ extern "C" int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args) {
     const GrlGemmTnArgs& p = *args;
     if (p.M <= 0 || p.N <= 0 || p.K <= 0) return 0;
     if (p.b_dtype != GRL_DT_F32 && p.b_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
-    const int bq = p.b_dtype == GRL_DT_F16 ? 8 : 4;   // 16-byte pieces of b
-    if ((p.lda % 4) || (p.ldb % bq) || (p.N % 4) || (p.K % bq) || p.lda < p.N || p.ldb < p.K || p.ldc < p.K) return GRL_ERR_BAD_ARG;
+    if (p.a_dtype != 0 && p.a_dtype != GRL_DT_F32 && p.a_dtype != GRL_DT_F16) return GRL_ERR_BAD_ARG;
+    const int aq = p.a_dtype == GRL_DT_F16 ? 8 : 4, bq = p.b_dtype == GRL_DT_F16 ? 8 : 4;   // elements per 16-byte piece
+    if ((p.lda % aq) || (p.ldb % bq) || (p.N % 4) || (p.K % 4) || p.ldc < p.K) return GRL_ERR_BAD_ARG;
+    if (p.lda < (p.N + aq - 1) / aq * aq || p.ldb < (p.K + bq - 1) / bq * bq) return GRL_ERR_BAD_ARG;   // (whole pieces are read)
     if (p.b_ones && p.c_bias == nullptr && p.c_bias_fix == nullptr) return GRL_ERR_BAD_ARG;
     if ((p.c_fix != nullptr) != (p.c_bias_fix != nullptr) && p.b_ones) return GRL_ERR_BAD_ARG;
     if (p.taps != 1 && p.taps != 9) return GRL_ERR_BAD_ARG;

@@ -33,6 +33,8 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
     if (p.M <= 0) return 0;
     if (p.Kpad % 32 != 0 || p.Npad % 32 != 0 || p.lda % (p.a_cols > 0 ? 4 : 8) != 0 || p.ldo % 4 != 0) return GRL_ERR_BAD_ARG;
     if (p.a_cols < 0 || p.n_store < 0) return GRL_ERR_BAD_ARG;
+    if (p.a16_out != nullptr && (p.a_dtype != GRL_DT_F32 || p.a_split == 3 || p.pool_df > 1 || (p.lda16 % 8) || p.lda16 < p.Kpad || p.w_regs != nullptr))
+        return GRL_ERR_BAD_ARG;
     if (p.a_cols > 0 && ((p.a_cols % 4) || p.a_cols > p.Kpad || p.lda < p.a_cols || p.a_dtype != GRL_DT_F32 || p.pool_df > 1 || p.a_split == 3 ||
                          (p.a_one && p.a_cols >= p.Kpad)))
         return GRL_ERR_BAD_ARG;

@@ -307,6 +307,17 @@ __global__ __launch_bounds__(WV * 64) void linear_kernel(GrlLinearArgs p) {
         if (row0 >= p.M) continue;
         gemm_x8 a[MT][KSTEPS];
         load_a_slab<KSTEPS, MT>(p, row0, lane, a);
+        if (p.a16_out != nullptr) {   // the fp16 operand as the layer's weight-gradient GEMM will want it (64 contiguous bytes per row and k-step)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int m = row0 + 16 * mt + r16;
+                if (m < p.M) {
+#pragma unroll
+                    for (int s = 0; s < KSTEPS; ++s)
+                        *(gemm_x8*)((gemm_t*)p.a16_out + (int64_t)m * p.lda16 + 32 * s + 8 * g4) = a[mt][s];
+                }
+            }
+        }
         // opaque per-iteration copy of the lane's column group: keeps the compiler from hoisting the
         // (tile-invariant) bias / gamma / beta / column addresses out of the persistent loop, where
         // ~150 live address registers force the accumulators into scratch
@@ -446,6 +457,7 @@ int launch_split(const GrlLinearArgs& p0, hipStream_t st) {
         GrlLinearArgs p = p0;
         const int c0 = sidx * ncol;
         p.Npad = ncol;
+        if (sidx > 0) p.a16_out = nullptr;   // (every slab reads the same A: one copy)
         if (p0.n_store > 0) {   // this slab's share of the real output columns
             const int ns = p0.n_store - c0;
             if (ns <= 0) continue;

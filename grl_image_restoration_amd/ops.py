@@ -173,12 +173,14 @@ def linear(
     a_cols: int = 0,
     a_one: bool = False,
     n_store: int = 0,
+    a16_out: Optional[torch.Tensor] = None,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
     ``a_cols`` > 0: ``a`` is [M, a_cols] at its real width (multiple of 4): the kernel reads the columns up to Kpad as 0 (column
     a_cols as 1.0 with ``a_one``); ``n_store`` > 0: the result is [M, n_store] (fp32, multiple of 4) -- the training path's operands
-    and results without padded copies (GrlLinearArgs, ABI 22).
+    and results without padded copies (GrlLinearArgs, ABI 22).  ``a16_out`` [M, >= Kpad] fp16: receives the operand as the kernel contracts
+    it (a_scale * a, pad / ones columns included) for the weight-gradient GEMM of the same layer.
     ``a_split=3``: split-precision operands -- ``w`` is packed by ``split3_weight`` ([hi | hi | lo], Kpad = 3 x the
     source width) and the kernel stages the fp32 ``a`` as [hi | lo | hi]."""
     _dev_check(a, w, bias, out, gscale, ln_g, ln_b, resid, add2, add2_scale, w_regs)
@@ -226,7 +228,10 @@ def linear(
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split, a_scale=a_scale, out_scale=out_scale,
         out_lo=_ptr(out_lo), out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
         w_regs=_ptr(w_regs), a_cols=a_cols, a_one=int(a_one), n_store=n_store,
+        a16_out=_ptr(a16_out), lda16=a16_out.stride(0) if a16_out is not None else 0,
     )
+    assert a16_out is None or (a16_out.dtype == GEMM_DTYPE and a16_out.dim() == 2 and a16_out.stride(1) == 1 and a16_out.shape[0] >= M
+                               and a16_out.shape[1] >= Kpad and a16_out.stride(0) % 8 == 0 and a.dtype == torch.float32)
     if out_lo is not None:   # rounding residuals of the fp16 outputs, same layout (split-precision attention operands)
         assert out_lo.dtype == torch.float16 and out_lo.shape == out.shape and out_lo.stride() == out.stride() and out.dtype == torch.float16
     if epi == L.EPI_GROUPNORM:
@@ -778,8 +783,9 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, 
     nothing is read beyond column N / K of a row, so a and b may be the layer's tensors at their real widths.  ``b_ones``: returns
     (c, bias) with bias[n] = out_scale * sum_m a_scale * a[m, n] -- the bias gradient, as if b had a column of ones (ABI 22)."""
     _dev_check(a, b)
-    assert a.dim() == 2 and b.dim() == 2 and a.dtype == torch.float32 and b.dtype in (torch.float32, torch.float16)
+    assert a.dim() == 2 and b.dim() == 2 and a.dtype in (torch.float32, torch.float16) and b.dtype in (torch.float32, torch.float16)
     assert a.stride(1) == 1 and b.stride(1) == 1 and a.shape[0] == b.shape[0] and a.shape[1] >= N and b.shape[1] >= K
+    # (an fp16 ``a`` is taken as already multiplied by a_scale: the operand copy of the data-gradient launch, linear(a16_out=...))
     M = a.shape[0]
     H, W = hw if hw is not None else (0, 0)
     det = deterministic()
@@ -797,7 +803,7 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, 
     args = L.GrlGemmTnArgs(a=_ptr(a), lda=a.stride(0), b=_ptr(b), b_dtype=_KIND[b.dtype], ldb=b.stride(0), M=M, N=N, K=K, taps=taps,
                            H=H, W=W, splits=splits, a_scale=a_scale, out_scale=out_scale, c=None if det else _ptr(c), ldc=K,
                            c_tap_stride=N * K, c_fix=_ptr(c) if det else None, b_ones=int(b_ones),
-                           c_bias=None if det else _ptr(cb), c_bias_fix=_ptr(cb) if det else None)
+                           c_bias=None if det else _ptr(cb), c_bias_fix=_ptr(cb) if det else None, a_dtype=_KIND[a.dtype])
     with _timed("gemm_tn"):
         L.check(L.lib().grl_gemm_tn(L.stream_ptr(), C.byref(args)), "grl_gemm_tn")
     if det:

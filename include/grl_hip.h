@@ -92,6 +92,9 @@ typedef struct GrlLinearArgs {
     int32_t n_store;        /* > 0 (fp32 output, PLAIN / GELU epilogue, no planes): only the columns < n_store (multiple of 4)    */
                             /* are stored; ldo >= n_store, ldo % 4 == 0                                                           */
     int32_t reserved0;
+    void* a16_out;          /* optional (fp32 A, a_split <= 1): the fp16 operand the kernel contracts -- a_scale * A, pad columns     */
+    int64_t lda16;          /* and the a_one column included -- written as [M, lda16] (lda16 >= Kpad, multiple of 8): the weight-     */
+                            /* gradient GEMM of the same layer reads it instead of converting the fp32 matrix once per output tile     */
 } GrlLinearArgs;
 
 int grl_linear_fwd(void* stream, const GrlLinearArgs* args);
@@ -464,6 +467,9 @@ typedef struct GrlGemmTnArgs {
     int32_t reserved0;      /* column sums of a, go to c_bias[n] (taps = 9: of the centre tap) instead of a column of c         */
     float* c_bias;          /* [N] fp32, zeroed by the caller (required with b_ones unless c_bias_fix)                          */
     int64_t* c_bias_fix;    /* [N], the deterministic counterpart (with c_fix)                                                  */
+    int32_t a_dtype;        /* 0 / GRL_DT_F32: a is fp32 (the field `a`); GRL_DT_F16: a points at fp16 values that are ALREADY     */
+    int32_t reserved1;      /* multiplied by a_scale (GrlLinearArgs.a16_out of the data-gradient launch).  16-bit operands: lda /  */
+                            /* ldb multiples of 8 and at least N / K rounded up to 8 (the pad columns are read)                    */
 } GrlGemmTnArgs;
 
 int grl_gemm_tn(void* stream, const GrlGemmTnArgs* args);
