@@ -403,6 +403,8 @@ class GrlLnTrainArgs(_Strict):
         ("row_scale", C.c_void_p),
         ("rows_per_image", C.c_int32),
         ("alpha", C.c_float),
+        ("stat_replicas", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 
@@ -417,6 +419,8 @@ class GrlPlanesArgs(_Strict):
         ("dscale", C.c_void_p),
         ("T", C.c_int32), ("S_in", C.c_int32), ("S_out", C.c_int32), ("nh", C.c_int32), ("d", C.c_int32),
         ("src", C.c_int32 * 8), ("raw", C.c_int32 * 8), ("one_col", C.c_int32 * 8), ("want_dscale", C.c_int32 * 8),
+        ("dscale_replicas", C.c_int32),
+        ("reserved0", C.c_int32),
     ]
 
 

@@ -535,9 +535,9 @@ class HeadPlanesFn(torch.autograd.Function):
     head_planes_bwd, csrc/planes.hip).  ``scale`` [S_out, nh]; ``src`` / ``raw`` / ``one_cols``: tuples per output slot."""
 
     @staticmethod
-    def forward(ctx, x, scale, src, raw, one_cols):
+    def forward(ctx, x, scale, src, raw, one_cols, write32=True):
         xc, sc = x.detach().float().contiguous(), scale.detach().float().contiguous()
-        out32, out16 = ops.head_planes(xc, sc, src, raw, one_cols)
+        out32, out16 = ops.head_planes(xc, sc, src, raw, one_cols, write32)
         ctx.save_for_backward(xc, sc)
         ctx.cfg = (tuple(src), tuple(raw), tuple(one_cols))
         p32, p16 = out32.unbind(0), out16.unbind(0)
@@ -552,7 +552,7 @@ class HeadPlanesFn(torch.autograd.Function):
         S = len(src)
         want = [ctx.needs_input_grad[1] and not r for r in raw]
         dx, dscale = ops.head_planes_bwd(x, scale, src, raw, one_cols, list(grads[:S]), want)
-        return dx, (dscale if ctx.needs_input_grad[1] else None), None, None, None
+        return dx, (dscale if ctx.needs_input_grad[1] else None), None, None, None, None
 
 
 class LayerNormFn(torch.autograd.Function):

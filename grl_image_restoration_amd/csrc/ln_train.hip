@@ -112,8 +112,9 @@ __global__ __launch_bounds__(256) void ln_train_bwd_kernel(GrlLnTrainArgs p) {
     __syncthreads();
     const int col = threadIdx.x;                   // 256 threads: one column each
     if (col < p.n) {
-        unsafeAtomicAdd(p.dgamma + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
-        unsafeAtomicAdd(p.dbeta + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
+        const int rep = p.stat_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.stat_replicas) * p.n : 0;    // (atomics on one address serialise)
+        unsafeAtomicAdd(p.dgamma + rep + col, red[0][0][col] + red[0][1][col] + red[0][2][col] + red[0][3][col]);
+        unsafeAtomicAdd(p.dbeta + rep + col, red[1][0][col] + red[1][1][col] + red[1][2][col] + red[1][3][col]);
     }
 }
 

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(PL_T) void planes_fwd_kernel(GrlPlanesArgs p) {
             if (c + 1 == p.one_col[s]) y1 = 1.0f;
             if (v < nvec) {
                 const int64_t o = (((int64_t)s * p.nh + h) * p.T + tt[u]) * 32 + c;
-                *(float2*)(p.out32 + o) = float2{y0, y1};
+                if (p.out32 != nullptr) *(float2*)(p.out32 + o) = float2{y0, y1};
                 *(uint32_t*)((f16*)p.out16 + o) = pack_f16(y0, y1);
             }
         }
@@ -135,7 +135,8 @@ __global__ __launch_bounds__(PL_T) void planes_bwd_kernel(GrlPlanesArgs p) {
     __syncthreads();
     if (threadIdx.x < 64) {
         const int s = threadIdx.x >> 3, h = threadIdx.x & 7;
-        if (s < p.S_out && h < p.nh && p.want_dscale[s] && ds[threadIdx.x] != 0.f) unsafeAtomicAdd(p.dscale + s * p.nh + h, ds[threadIdx.x]);
+        const int rep = p.dscale_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.dscale_replicas) * p.S_out * p.nh : 0;   // (see GrlLnTrainArgs.stat_replicas)
+        if (s < p.S_out && h < p.nh && p.want_dscale[s] && ds[threadIdx.x] != 0.f) unsafeAtomicAdd(p.dscale + rep + s * p.nh + h, ds[threadIdx.x]);
     }
 }
 
@@ -150,7 +151,7 @@ bool planes_ok(const GrlPlanesArgs& p) {
 
 extern "C" int grl_head_planes_fwd(void* stream, const GrlPlanesArgs* args) {
     const GrlPlanesArgs& p = *args;
-    if (!planes_ok(p) || !p.out32 || !p.out16) return GRL_ERR_BAD_ARG;
+    if (!planes_ok(p) || !p.out16) return GRL_ERR_BAD_ARG;      // (out32 optional: the fp32 planes are only autograd's handle on the operands)
     const int64_t nvec = (int64_t)p.T * p.S_out * p.nh;
     const int64_t wgs = (nvec + PL_T / 16 - 1) / (PL_T / 16);
     hipLaunchKernelGGL(planes_fwd_kernel, dim3((unsigned)(wgs < 8192 ? wgs : 8192)), dim3(PL_T), 0, (hipStream_t)stream, p);

@@ -1039,8 +1039,10 @@ class GRL(nn.Module):
             if ones is None:
                 ones = cache[("ones_nh", nh, str(dev))] = torch.ones(nh, dtype=torch.float32, device=dev)
             sc = torch.stack([ones if s is None else s for s in scales])                     # [S, nh] (differentiable in the q scales)
+            # (the fp32 planes are autograd's handle on the operands only -- every consumer takes the fp16 copies, f16= of the attention
+            # op -- so the kernel does not write them: GRL_PLANES_WRITE32=1 restores the values)
             outs = AG.HeadPlanesFn.apply(xin, sc, tuple(0 if expanded else j for j in range(S)), tuple(s is None for s in scales),
-                                         tuple(int(c) for c in one_cols))
+                                         tuple(int(c) for c in one_cols), os.environ.get("GRL_PLANES_WRITE32", "0") == "1")
             return outs[:S], outs[S:]
         key = ("planes_const", T, S, nh, d, tuple(s is None for s in scales), tuple(one_cols), str(dev))
         const = cache.get(key)

@@ -879,6 +879,9 @@ def cpb_table_bwd(coords: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: 
     return d_w1, d_b1, d_w2
 
 
+STAT_REPLICAS = int(os.environ.get("GRL_STAT_REPLICAS", "32"))     # copies of small cross-workgroup sums (LayerNorm dgamma / dbeta, plane scale gradients)
+
+
 def layernorm_train(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, eps: float = 1e-5, resid: Optional[torch.Tensor] = None,
                     row_scale: Optional[torch.Tensor] = None, rows_per_image: int = 0, alpha: float = 1.0):
     """Row LayerNorm of a token matrix x [M, n] (fp32, n a multiple of 4, <= 256) with the row statistics kept for the backward
@@ -910,12 +913,16 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: t
     assert dy.shape == x.shape and dy.dtype == torch.float32 and dy.stride(1) == 1 and dy.stride(0) % 4 == 0
     g = gamma.detach().float().contiguous()
     dx = empty(M, n, dtype=torch.float32, device=x.device)
-    dgb = torch.zeros(2, n, dtype=torch.float32, device=x.device)       # (dgamma | dbeta: one fill)
+    # dgamma | dbeta in STAT_REPLICAS copies (one fill), summed afterwards: 2048 workgroups adding into the same 2 n addresses serialise
+    # at ~36 ns per atomic -- 75 us of a kernel whose rows stream in 20
+    R = STAT_REPLICAS if M >= 4096 else 1
+    dgb = torch.zeros(2, R, n, dtype=torch.float32, device=x.device)
     args = L.GrlLnTrainArgs(x=_ptr(x), ldx=x.stride(0), gamma=_ptr(g), mean=_ptr(mean), rstd=_ptr(rstd), dy=_ptr(dy), lddy=dy.stride(0),
                             dx=_ptr(dx), lddx=n, dgamma=_ptr(dgb[0]), dbeta=_ptr(dgb[1]), M=M, n=n, eps=0.0,
-                            row_scale=_ptr(row_scale), rows_per_image=rows_per_image, alpha=alpha)
+                            row_scale=_ptr(row_scale), rows_per_image=rows_per_image, alpha=alpha, stat_replicas=R)
     with _timed("layernorm_bwd"):
         L.check(L.lib().grl_layernorm_bwd(L.stream_ptr(), C.byref(args)), "grl_layernorm_bwd")
+    dgb = dgb.sum(1) if R > 1 else dgb[:, 0]
     return dx, dgb[0], dgb[1]
 
 
@@ -931,9 +938,11 @@ def head_planes_ok(x: torch.Tensor, n_out: int) -> bool:
     return x.is_cuda and x.dim() == 4 and x.shape[1] <= 8 and n_out <= 8 and x.shape[2] <= 8 and x.shape[3] <= 32 and x.shape[3] % 2 == 0
 
 
-def head_planes(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols):
+def head_planes(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols, write32: bool = True):
     """grl_head_planes_fwd: x [T, S_in, nh, d] fp32 -> (fp32 planes [S_out, nh, T, 32], fp16 copy); output slot s reads input slot
-    src[s], raw[s]: copied, else L2-normalised over d and multiplied by scale[s][head]; one_cols[s] >= 0: that plane column is 1.0."""
+    src[s], raw[s]: copied, else L2-normalised over d and multiplied by scale[s][head]; one_cols[s] >= 0: that plane column is 1.0.
+    ``write32=False``: the fp32 planes are allocated but NOT written -- for callers whose consumer reads the fp16 copy only and needs
+    the fp32 tensors as autograd's handle on the operands (the attention op with ``f16=``): 40 % of the launch's bytes."""
     _dev_check(x, scale)
     assert x.dtype == torch.float32 and x.is_contiguous() and scale.dtype == torch.float32 and scale.is_contiguous()
     T, S_in, nh, d = x.shape
@@ -942,7 +951,7 @@ def head_planes(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols):
     out32 = empty(S_out, nh, T, 32, dtype=torch.float32, device=x.device)
     out16 = empty(S_out, nh, T, 32, dtype=PLANE_DTYPE, device=x.device)
     args = _planes_args(x, scale, src, raw, one_cols, [False] * S_out)
-    args.out32, args.out16 = _ptr(out32), _ptr(out16)
+    args.out32, args.out16 = (_ptr(out32) if write32 else None), _ptr(out16)
     with _timed("head_planes"):
         L.check(L.lib().grl_head_planes_fwd(L.stream_ptr(), C.byref(args)), "grl_head_planes_fwd")
     return out32, out16
@@ -954,8 +963,10 @@ def head_planes_bwd(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols, gr
     S_out = len(src)
     gs = [None if g is None else g.float().contiguous() for g in grads]
     dx = empty(x.shape, dtype=torch.float32, device=x.device)
-    dscale = torch.zeros(S_out, x.shape[2], dtype=torch.float32, device=x.device)
+    R = STAT_REPLICAS if x.shape[0] >= 4096 else 1          # (replicas of the scale-gradient sums: see layernorm_bwd)
+    dscale = torch.zeros(R, S_out, x.shape[2], dtype=torch.float32, device=x.device)
     args = _planes_args(x, scale, src, raw, one_cols, want_dscale)
+    args.dscale_replicas = R
     for s_, g in enumerate(gs):
         if g is not None:
             assert g.shape == (x.shape[2], x.shape[0], 32)
@@ -963,7 +974,7 @@ def head_planes_bwd(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols, gr
     args.dx, args.dscale = _ptr(dx), _ptr(dscale)
     with _timed("head_planes_bwd"):
         L.check(L.lib().grl_head_planes_bwd(L.stream_ptr(), C.byref(args)), "grl_head_planes_bwd")
-    return dx, dscale
+    return dx, (dscale.sum(0) if R > 1 else dscale[0])
 
 
 def pack_conv_train(w: torch.Tensor, b: Optional[torch.Tensor], rows_pad: int, cols_pad: int, flip_t: bool = False):

@@ -554,6 +554,9 @@ typedef struct GrlLnTrainArgs {
     const float* row_scale;
     int32_t rows_per_image;
     float alpha;
+    int32_t stat_replicas;   /* backward: dgamma / dbeta are [stat_replicas][n] arrays each (0 = 1); workgroup b adds into replica      */
+    int32_t reserved0;       /* b % stat_replicas and the caller sums the replicas: a few thousand atomics on ONE address serialise      */
+                             /* (~36 ns each on MI355X: 2048 workgroups on 180 + 180 addresses were 75 us of a 20-us kernel)              */
 } GrlLnTrainArgs;
 
 int grl_layernorm_train_fwd(void* stream, const GrlLnTrainArgs* args);
@@ -583,13 +586,15 @@ int grl_pack_linear(void* stream, const float* w, void* out_w, void* out_wt, int
 typedef struct GrlPlanesArgs {
     const float* x;
     const float* scale;      /* [S_out][nh] (ignored for raw slots) */
-    float* out32;            /* forward */
+    float* out32;            /* forward; optional (NULL: only out16 is written) */
     void* out16;             /* forward: fp16 [S_out][nh][T][32] */
     const float* dy[8];      /* backward */
     float* dx;
     float* dscale;
     int32_t T, S_in, S_out, nh, d;
     int32_t src[8], raw[8], one_col[8], want_dscale[8];
+    int32_t dscale_replicas; /* backward (ABI 22): dscale is [dscale_replicas][S_out][nh] (0 = 1), workgroup b adds into replica b % replicas,   */
+    int32_t reserved0;       /* the caller sums them (see GrlLnTrainArgs.stat_replicas)                                                          */
 } GrlPlanesArgs;
 
 int grl_head_planes_fwd(void* stream, const GrlPlanesArgs* args);

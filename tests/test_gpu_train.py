@@ -302,6 +302,9 @@ def test_head_planes_kernels_match_the_torch_chain(T, nh, d, anchors, monkeypatc
     from grl_image_restoration_amd import GRL, make_config
 
     m = GRL(**make_config("tiny", "yaml", upscale=2, img_size=16, depths=[1], num_heads_window=[2], num_heads_stripe=[2]))
+    # (the training path leaves the fp32 planes unwritten -- nothing reads them, the attention op takes the fp16 copies -- this test
+    # compares their values too)
+    monkeypatch.setenv("GRL_PLANES_WRITE32", "1")
     g = torch.Generator().manual_seed(63)
     k1, v1 = (31 if d <= 30 else -1), (d if d < 32 else -1)
     ones = torch.ones(nh, device="cuda")
