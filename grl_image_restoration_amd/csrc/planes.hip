@@ -74,22 +74,29 @@ __global__ __launch_bounds__(PL_T) void planes_bwd_kernel(GrlPlanesArgs p) {
     if (threadIdx.x < 64) ds[threadIdx.x] = 0.f;
     __syncthreads();
     const int c = 2 * sub;
-    const int64_t nvec = (int64_t)p.T * p.S_in * p.nh;
+    const int L = p.S_in * p.nh;                       // vectors per token
+    const int64_t nvec = (int64_t)p.T * L;
     const int64_t stride = (int64_t)gridDim.x * (PL_T / 16);
+    // The host picks the grid so that the stride is a multiple of L: a 16-lane group then meets the SAME (input slot, head) in every
+    // iteration, its scale-gradient terms add up in registers and reach the LDS histogram once (one LDS atomic per vector and slot
+    // before: 16 of them per iteration on a dozen addresses), and the index arithmetic leaves the loop.
+    const int64_t vfirst = (int64_t)blockIdx.x * (PL_T / 16) + (threadIdx.x >> 4);
+    const int h = (int)(vfirst % p.nh), i = (int)((vfirst / p.nh) % p.S_in);
     constexpr int U = 2;
-    for (int64_t v0 = (int64_t)blockIdx.x * (PL_T / 16) + (threadIdx.x >> 4); v0 < nvec; v0 += stride * U) {
+    float tot[8];
+    bool feeds[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) { tot[s] = 0.f; feeds[s] = s < p.S_out && p.src[s] == i && p.dy[s] != nullptr; }
+    for (int64_t v0 = vfirst; v0 < nvec; v0 += stride * U) {
         // v = (t * S_in + i) * nh + h: one INPUT vector; every output slot fed by it contributes
         float2 a[U], dd[U][8];
-        int hh[U], ii[U];
         bool live[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t v = v0 + u * stride;
             live[u] = v < nvec;
-            const int64_t vc = live[u] ? v : 0;
-            hh[u] = (int)(vc % p.nh);
-            ii[u] = (int)((vc / p.nh) % p.S_in);
-            const int64_t t = vc / ((int64_t)p.nh * p.S_in);
+            const int64_t vc = live[u] ? v : vfirst;
+            const int64_t t = vc / L;
             const float* xv = p.x + vc * p.d;
             a[u] = float2{0.f, 0.f};
             if (c + 1 < p.d) a[u] = *(const float2*)(xv + c);
@@ -97,46 +104,42 @@ __global__ __launch_bounds__(PL_T) void planes_bwd_kernel(GrlPlanesArgs p) {
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
                 dd[u][s] = float2{0.f, 0.f};
-                if (s < p.S_out && p.src[s] == ii[u] && p.dy[s] != nullptr)
-                    dd[u][s] = *(const float2*)(p.dy[s] + ((int64_t)hh[u] * p.T + t) * 32 + c);     // (pad columns carry no gradient)
+                if (feeds[s]) dd[u][s] = *(const float2*)(p.dy[s] + ((int64_t)h * p.T + t) * 32 + c);     // (pad columns carry no gradient)
             }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int64_t v = v0 + u * stride;
-            const int h = hh[u], i = ii[u];
             const float nrm = fmaxf(sqrtf(row16_sum(a[u].x * a[u].x + a[u].y * a[u].y)), 1e-12f);
             const float u0 = a[u].x / nrm, u1 = a[u].y / nrm;
             float g0 = 0.f, g1 = 0.f;
-            float acc[8];                              // this vector's scale-gradient term per output slot
 #pragma unroll
             for (int s = 0; s < 8; ++s) {
-                acc[s] = 0.f;
-                if (s >= p.S_out || p.src[s] != i || p.dy[s] == nullptr) continue;    // (group-uniform: the row reduction below is safe)
+                if (!feeds[s]) continue;                                                // (group-uniform: the row reduction below is safe)
                 const float d0 = c < p.d ? dd[u][s].x : 0.f, d1 = c + 1 < p.d ? dd[u][s].y : 0.f;
                 if (p.raw[s]) { g0 += d0; g1 += d1; continue; }
                 const float dot = row16_sum(d0 * u0 + d1 * u1);                         // dy . u  (= the scale gradient's term)
                 const float f = p.scale[s * p.nh + h] / nrm;
                 g0 = fmaf(f, d0 - u0 * dot, g0);
                 g1 = fmaf(f, d1 - u1 * dot, g1);
-                acc[s] = dot;
+                if (live[u]) tot[s] += dot;
             }
             if (live[u]) {
                 if (c + 1 < p.d) *(float2*)(p.dx + v * p.d + c) = float2{g0, g1};
                 else if (c < p.d) p.dx[v * p.d + c] = g0;
-                if (sub == 0) {
-#pragma unroll
-                    for (int s = 0; s < 8; ++s)
-                        if (s < p.S_out && p.want_dscale[s] && acc[s] != 0.f) atomicAdd(&ds[s * 8 + h], acc[s]);
-                }
             }
         }
     }
+    if (sub == 0) {
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            if (s < p.S_out && p.want_dscale[s] && tot[s] != 0.f) atomicAdd(&ds[s * 8 + h], tot[s]);
+    }
     __syncthreads();
     if (threadIdx.x < 64) {
-        const int s = threadIdx.x >> 3, h = threadIdx.x & 7;
+        const int s = threadIdx.x >> 3, hh = threadIdx.x & 7;
         const int rep = p.dscale_replicas > 1 ? (int)(blockIdx.x % (unsigned)p.dscale_replicas) * p.S_out * p.nh : 0;   // (see GrlLnTrainArgs.stat_replicas)
-        if (s < p.S_out && h < p.nh && p.want_dscale[s] && ds[threadIdx.x] != 0.f) unsafeAtomicAdd(p.dscale + rep + s * p.nh + h, ds[threadIdx.x]);
+        if (s < p.S_out && hh < p.nh && p.want_dscale[s] && ds[threadIdx.x] != 0.f) unsafeAtomicAdd(p.dscale + rep + s * p.nh + hh, ds[threadIdx.x]);
     }
 }
 
@@ -163,8 +166,17 @@ extern "C" int grl_head_planes_bwd(void* stream, const GrlPlanesArgs* args) {
     const GrlPlanesArgs& p = *args;
     if (!planes_ok(p) || !p.dx || !p.dscale) return GRL_ERR_BAD_ARG;
     const int64_t nvec = (int64_t)p.T * p.S_in * p.nh;
-    const int64_t wgs = (nvec + PL_T / 16 - 1) / (PL_T / 16);
-    hipLaunchKernelGGL(planes_bwd_kernel, dim3((unsigned)(wgs < 2048 ? wgs : 2048)), dim3(PL_T), 0, (hipStream_t)stream, p);
+    int64_t wgs = (nvec + PL_T / 16 - 1) / (PL_T / 16);
+    if (wgs > 2048) wgs = 2048;
+    // the kernel's precondition: the vector stride (16 per workgroup) is a multiple of the vectors per token, or the launch covers
+    // everything in one pass (L <= 64, so at least one such grid exists below 2048)
+    const int L = p.S_in * p.nh;
+    int g = L, x = PL_T / 16;
+    while (x) { const int r = g % x; g = x; x = r; }   // gcd(L, 16)
+    const int m = L / g;                               // the grid must be a multiple of m
+    if (wgs * (PL_T / 16) < nvec) wgs = wgs / m * m;   // (several passes: round down; never to zero: wgs = 2048 >= m here)
+    if (wgs <= 0) return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(planes_bwd_kernel, dim3((unsigned)wgs), dim3(PL_T), 0, (hipStream_t)stream, p);
     GRL_CHECK_LAUNCH();
     return 0;
 }
