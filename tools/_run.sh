@@ -1,2 +1,2 @@
-timeout 900 python -m pytest -q -m gpu tests/test_gpu_train.py -x -k "planes" 2>&1 | tail -2
-for i in 1 2; do timeout 200 python tools/train_steps.py --graph --steps 10 2>&1 | grep "graphed:"; done
+timeout 1100 python -m pytest -q -m gpu tests 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^ROCm\|^HIP version\|^Hostname\|^Librccl" | tail -15 > gpurun_out/r6_suite_f.log
+tail -3 gpurun_out/r6_suite_f.log

@@ -6,7 +6,7 @@
 set -u
 cd "$(dirname "$0")/../grl_image_restoration_amd/csrc"
 echo "# hipcc --offload-arch=gfx950 -O3 -Rpass-analysis=kernel-resource-usage  (tools/kernel_resources.sh)"
-for f in attention attention_rows attention_pipe attention_bwd mlp tail_regs qkv qkv_anchor conv conv192 cab_conv2 linear_split grad misc linear linear_k576; do
+for f in attention attention_rows attention_pipe attention_bwd mlp tail_regs qkv qkv_anchor conv conv192 cab_conv2 linear_split grad misc planes ln_train cpb linear linear_k576; do
   extra=""
   case $f in attention|attention_bwd) extra="-mllvm -amdgpu-mfma-vgpr-form";; esac   # as in csrc/Makefile
   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=fast -I../../include --cuda-device-only $extra -c $f.hip -o /dev/null \
