@@ -44,6 +44,8 @@ EXPORTS = [
     "grl_layernorm_bwd",
     "grl_pack_conv3x3",
     "grl_pack_linear",
+    "grl_se_mlp_fwd",
+    "grl_se_mlp_bwd",
     "grl_head_planes_fwd",
     "grl_head_planes_bwd",
     "grl_cpb_table_fwd",
@@ -424,6 +426,26 @@ class GrlPlanesArgs(_Strict):
     ]
 
 
+class GrlSeMlpArgs(_Strict):
+    _fields_ = [
+        ("pool", C.c_void_p),
+        ("w1", C.c_void_p),
+        ("b1", C.c_void_p),
+        ("w2", C.c_void_p),
+        ("b2", C.c_void_p),
+        ("gate", C.c_void_p),
+        ("hidden", C.c_void_p),
+        ("d_gate", C.c_void_p),
+        ("d_pool", C.c_void_p),
+        ("d_w1", C.c_void_p),
+        ("d_b1", C.c_void_p),
+        ("d_w2", C.c_void_p),
+        ("d_b2", C.c_void_p),
+        ("B", C.c_int32), ("C", C.c_int32), ("Cmid", C.c_int32),
+        ("reserved0", C.c_int32),
+    ]
+
+
 class GrlCpbArgs(_Strict):
     _fields_ = [
         ("coords", C.c_void_p),
@@ -522,6 +544,10 @@ def lib():
     L.grl_pack_conv3x3.restype = C.c_int
     L.grl_pack_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.grl_pack_linear.restype = C.c_int
+    L.grl_se_mlp_fwd.argtypes = [C.c_void_p, C.POINTER(GrlSeMlpArgs)]
+    L.grl_se_mlp_fwd.restype = C.c_int
+    L.grl_se_mlp_bwd.argtypes = [C.c_void_p, C.POINTER(GrlSeMlpArgs)]
+    L.grl_se_mlp_bwd.restype = C.c_int
     L.grl_head_planes_fwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]
     L.grl_head_planes_fwd.restype = C.c_int
     L.grl_head_planes_bwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]

@@ -19,6 +19,7 @@ true-valued fp32 gradients.  The factor is chosen once per backward pass from th
 (``GradScaleTop``: one host read per step).
 """
 import math
+import os
 import threading
 import weakref
 from typing import Optional, Sequence
@@ -612,6 +613,30 @@ def layer_norm(x, gamma, beta, eps: float = 1e-5):
     if x.is_cuda and x.dim() == 2 and n % 4 == 0 and n <= 256 and not ops.deterministic():
         return LayerNormFn.apply(x, gamma, beta, eps)
     return F.layer_norm(x, (n,), gamma, beta, eps)
+
+
+class SeMlpFn(torch.autograd.Function):
+    """sigmoid(W2 relu(W1 pool + b1) + b2) on the pooled channel means [B, C] (ops.se_mlp / se_mlp_bwd, csrc/se_train.hip)."""
+
+    @staticmethod
+    def forward(ctx, pool, w1, b1, w2, b2):
+        pc = pool.detach().float().contiguous()
+        gate, hidden = ops.se_mlp(pc, w1, b1, w2, b2)
+        ctx.save_for_backward(pc, gate, hidden, w1, w2)
+        return gate
+
+    @staticmethod
+    def backward(ctx, d_gate):
+        pool, gate, hidden, w1, w2 = ctx.saved_tensors
+        d_pool, d_w1, d_b1, d_w2, d_b2 = ops.se_mlp_bwd(d_gate, pool, gate, hidden, w1, w2)
+        return d_pool, d_w1.view_as(w1), d_b1, d_w2.view_as(w2), d_b2
+
+
+def se_gate(pool, w1, b1, w2, b2):
+    """The CAB's squeeze-excite gate from the pooled means (mixed_attn_block.py:956-963); w1 [Cmid, C], w2 [C, Cmid]."""
+    if pool.is_cuda and ops.se_mlp_ok(pool, w1) and os.environ.get("GRL_SE_KERNEL", "1") != "0":
+        return SeMlpFn.apply(pool, w1, b1, w2, b2)
+    return torch.sigmoid(F.linear(F.relu(F.linear(pool, w1, b1)), w2, b2))
 
 
 class CpbTableFn(torch.autograd.Function):

@@ -1,0 +1,110 @@
+// Squeeze-excite gate of the CAB in a TRAINING step (gfx950): the two-layer MLP on the pooled channel means, forward and backward.
+//
+// Replaces ChannelAttention.attention[1..4] (models/common/mixed_attn_block.py:956-963: Conv2d(C, C/r, 1) -> ReLU -> Conv2d(C/r, C, 1) ->
+// Sigmoid on the [B, C] output of AdaptiveAvgPool2d) and autograd through it.  The tensors are tiny ([8, 180] and [8, 10] for GRL-Base at
+// batch 8) and as torch code the chain was 4 launches forward (two BLAS GEMMs of ~8 us each, ReLU, sigmoid) and 8 backward (four BLAS
+// GEMMs, two column sums, the two activation adjoints): ~3 ms of a 100-ms captured step for a few kFLOP -- a captured step costs the SUM of
+// its kernels' durations, however small the work.
+//   forward : hid = relu(W1 pool + b1);  gate = sigmoid(W2 hid + b2)                       one workgroup per image
+//   backward: dz2 = d_gate gate (1 - gate);  dW2 += dz2 hid^T;  db2 += dz2;  dh = W2^T dz2;  dz1 = dh [hid > 0];
+//             dW1 += dz1 pool^T;  db1 += dz1;  d_pool = W1^T dz1                            ONE workgroup walks the images: the weight
+//             gradients are sums over the batch, each element owned by one thread -- no atomics, deterministic
+#include "common.h"
+#include "grl_hip_internal.h"
+
+namespace {
+
+constexpr int SE_T = 256;          // threads: one per channel (C <= 256)
+constexpr int SE_MID = 64;         // hidden units (C / reduction) <= 64
+
+__device__ __forceinline__ float se_wave_sum(float v) { return sum_halves(sum_rows16(row16_sum(v))); }
+
+__global__ __launch_bounds__(SE_T) void se_mlp_fwd_kernel(GrlSeMlpArgs p) {
+    __shared__ float pool[SE_T], hid[SE_MID];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid < p.C) pool[tid] = p.pool[(int64_t)b * p.C + tid];
+    __syncthreads();
+    for (int j = wave; j < p.Cmid; j += SE_T / 64) {
+        float s = 0.f;
+        for (int c = lane; c < p.C; c += 64) s = fmaf(p.w1[j * p.C + c], pool[c], s);
+        s = se_wave_sum(s);
+        if (lane == 0) {
+            const float h = fmaxf(s + p.b1[j], 0.f);
+            hid[j] = h;
+            p.hidden[(int64_t)b * p.Cmid + j] = h;
+        }
+    }
+    __syncthreads();
+    if (tid < p.C) {
+        float s = p.b2[tid];
+        for (int j = 0; j < p.Cmid; ++j) s = fmaf(p.w2[tid * p.Cmid + j], hid[j], s);
+        p.gate[(int64_t)b * p.C + tid] = 1.0f / (1.0f + __expf(-s));
+    }
+}
+
+__global__ __launch_bounds__(SE_T) void se_mlp_bwd_kernel(GrlSeMlpArgs p) {
+    __shared__ float dz2[SE_T], dz1[SE_MID], hid[SE_MID];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const bool own = tid < p.C;
+    float db2 = 0.f;
+    for (int i = tid; i < p.Cmid * p.C; i += SE_T) { p.d_w1[i] = 0.f; p.d_w2[i] = 0.f; }
+    if (tid < p.Cmid) p.d_b1[tid] = 0.f;
+    __syncthreads();
+    for (int b = 0; b < p.B; ++b) {
+        float pl = 0.f;
+        if (own) {
+            const float g = p.gate[(int64_t)b * p.C + tid];
+            const float z = p.d_gate[(int64_t)b * p.C + tid] * g * (1.0f - g);
+            dz2[tid] = z;
+            db2 += z;
+            pl = p.pool[(int64_t)b * p.C + tid];
+        }
+        if (tid < p.Cmid) hid[tid] = p.hidden[(int64_t)b * p.Cmid + tid];
+        __syncthreads();
+        if (own)                                                                   // dW2 [C][Cmid]: row tid is this thread's
+            for (int j = 0; j < p.Cmid; ++j) p.d_w2[tid * p.Cmid + j] += dz2[tid] * hid[j];
+        for (int j = wave; j < p.Cmid; j += SE_T / 64) {                           // dh = W2^T dz2, through the ReLU
+            float s = 0.f;
+            for (int c = lane; c < p.C; c += 64) s = fmaf(p.w2[c * p.Cmid + j], dz2[c], s);
+            s = se_wave_sum(s);
+            if (lane == 0) {
+                const float z = hid[j] > 0.f ? s : 0.f;
+                dz1[j] = z;
+                p.d_b1[j] += z;
+            }
+        }
+        __syncthreads();
+        if (own) {
+            float dp = 0.f;
+            for (int j = 0; j < p.Cmid; ++j) {
+                p.d_w1[j * p.C + tid] += dz1[j] * pl;                              // dW1 [Cmid][C]: column tid is this thread's
+                dp = fmaf(p.w1[j * p.C + tid], dz1[j], dp);
+            }
+            p.d_pool[(int64_t)b * p.C + tid] = dp;
+        }
+        __syncthreads();
+    }
+    if (own) p.d_b2[tid] = db2;
+}
+
+bool se_args_ok(const GrlSeMlpArgs& p) {
+    return p.B > 0 && p.C > 0 && p.C <= SE_T && p.Cmid > 0 && p.Cmid <= SE_MID && p.pool && p.w1 && p.b1 && p.w2 && p.b2 && p.gate && p.hidden;
+}
+
+}  // namespace
+
+extern "C" int grl_se_mlp_fwd(void* stream, const GrlSeMlpArgs* args) {
+    const GrlSeMlpArgs& p = *args;
+    if (!se_args_ok(p)) return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(se_mlp_fwd_kernel, dim3(p.B), dim3(SE_T), 0, (hipStream_t)stream, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
+extern "C" int grl_se_mlp_bwd(void* stream, const GrlSeMlpArgs* args) {
+    const GrlSeMlpArgs& p = *args;
+    if (!se_args_ok(p) || !p.d_gate || !p.d_pool || !p.d_w1 || !p.d_b1 || !p.d_w2 || !p.d_b2) return GRL_ERR_BAD_ARG;
+    hipLaunchKernelGGL(se_mlp_bwd_kernel, dim3(1), dim3(SE_T), 0, (hipStream_t)stream, p);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}

@@ -1000,3 +1000,39 @@ def pack_linear_train(w: torch.Tensor, wp: torch.Tensor, wt: Optional[torch.Tens
     wc = w.detach().float().contiguous()
     assert wp.dtype == GEMM_DTYPE and wp.is_contiguous() and (wt is None or (wt.dtype == GEMM_DTYPE and wt.is_contiguous() and wt.shape == (Kp, Np)))
     L.check(L.lib().grl_pack_linear(L.stream_ptr(), _ptr(wc), _ptr(wp), _ptr(wt), N, K, Np, Kp), "grl_pack_linear")
+
+
+def se_mlp_ok(pool: torch.Tensor, w1: torch.Tensor) -> bool:
+    return pool.is_cuda and pool.dim() == 2 and pool.shape[1] <= 256 and w1.shape[0] <= 64
+
+
+def se_mlp(pool: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor):
+    """grl_se_mlp_fwd: (gate [B, C] = sigmoid(w2 relu(w1 pool + b1) + b2), hidden [B, Cmid]) -- the CAB's squeeze-excite MLP, one launch."""
+    _dev_check(pool, w1, b1, w2, b2)
+    B, C_ = pool.shape
+    Cmid = w1.shape[0]
+    ts = [t.detach().float().contiguous() for t in (pool, w1, b1, w2, b2)]
+    assert ts[1].shape == (Cmid, C_) and ts[3].shape == (C_, Cmid) and ts[2].numel() == Cmid and ts[4].numel() == C_
+    gate = empty(B, C_, dtype=torch.float32, device=pool.device)
+    hidden = empty(B, Cmid, dtype=torch.float32, device=pool.device)
+    args = L.GrlSeMlpArgs(pool=_ptr(ts[0]), w1=_ptr(ts[1]), b1=_ptr(ts[2]), w2=_ptr(ts[3]), b2=_ptr(ts[4]), gate=_ptr(gate), hidden=_ptr(hidden),
+                          B=B, C=C_, Cmid=Cmid)
+    L.check(L.lib().grl_se_mlp_fwd(L.stream_ptr(), C.byref(args)), "grl_se_mlp_fwd")
+    return gate, hidden
+
+
+def se_mlp_bwd(d_gate: torch.Tensor, pool: torch.Tensor, gate: torch.Tensor, hidden: torch.Tensor, w1: torch.Tensor, w2: torch.Tensor):
+    """grl_se_mlp_bwd: (d_pool, d_w1, d_b1, d_w2, d_b2) of se_mlp; one workgroup walks the batch (no atomics)."""
+    _dev_check(d_gate, pool, gate, hidden, w1, w2)
+    B, C_ = pool.shape
+    Cmid = w1.shape[0]
+    dg, pl, w1c, w2c = (t.detach().float().contiguous() for t in (d_gate, pool, w1, w2))
+    dev = pool.device
+    d_pool = empty(B, C_, dtype=torch.float32, device=dev)
+    d_w1, d_b1 = empty(Cmid, C_, dtype=torch.float32, device=dev), empty(Cmid, dtype=torch.float32, device=dev)
+    d_w2, d_b2 = empty(C_, Cmid, dtype=torch.float32, device=dev), empty(C_, dtype=torch.float32, device=dev)
+    args = L.GrlSeMlpArgs(pool=_ptr(pl), w1=_ptr(w1c), w2=_ptr(w2c), gate=_ptr(gate), hidden=_ptr(hidden), d_gate=_ptr(dg), d_pool=_ptr(d_pool),
+                          d_w1=_ptr(d_w1), d_b1=_ptr(d_b1), d_w2=_ptr(d_w2), d_b2=_ptr(d_b2), B=B, C=C_, Cmid=Cmid,
+                          b1=_ptr(d_b1), b2=_ptr(d_b2))     # (b1 / b2 are not read by the backward kernel; non-null for the argument check)
+    L.check(L.lib().grl_se_mlp_bwd(L.stream_ptr(), C.byref(args)), "grl_se_mlp_bwd")
+    return d_pool, d_w1, d_b1, d_w2, d_b2

@@ -600,6 +600,32 @@ typedef struct GrlPlanesArgs {
 int grl_head_planes_fwd(void* stream, const GrlPlanesArgs* args);
 int grl_head_planes_bwd(void* stream, const GrlPlanesArgs* args);
 
+/* Squeeze-excite gate MLP of the CAB in a training step (ABI 22), forward and backward:
+ *   replaces  ChannelAttention.attention[1..4]  models/common/mixed_attn_block.py:956-963  (Conv2d(C, C/r, 1) -> ReLU -> Conv2d(C/r, C, 1)
+ *   -> Sigmoid on the pooled [B, C] means) and autograd through it.  C <= 256, Cmid <= 64; all arrays fp32, contiguous.
+ * forward: hidden [B, Cmid] = relu(w1 pool + b1), gate [B, C] = sigmoid(w2 hidden + b2);  backward: d_pool [B, C] and the parameter
+ * gradients d_w1 [Cmid, C], d_b1 [Cmid], d_w2 [C, Cmid], d_b2 [C] (written, not accumulated; one workgroup, no atomics). */
+typedef struct GrlSeMlpArgs {
+    const float* pool;       /* [B, C] */
+    const float* w1;         /* [Cmid, C] */
+    const float* b1;
+    const float* w2;         /* [C, Cmid] */
+    const float* b2;
+    float* gate;             /* forward output / backward input */
+    float* hidden;           /* forward output / backward input */
+    const float* d_gate;     /* backward */
+    float* d_pool;
+    float* d_w1;
+    float* d_b1;
+    float* d_w2;
+    float* d_b2;
+    int32_t B, C, Cmid;
+    int32_t reserved0;
+} GrlSeMlpArgs;
+
+int grl_se_mlp_fwd(void* stream, const GrlSeMlpArgs* args);
+int grl_se_mlp_bwd(void* stream, const GrlSeMlpArgs* args);
+
 /* Relative-position bias tables for MANY AffineTransforms at once, forward and backward (ABI 21, training path):
  *   replaces  16 * sigmoid(cpb_mlp(relative_coords_table))  models/common/mixed_attn_block_efficient.py:23-34,49-58  (cpb_mlp =
  *   Linear(2, 512, bias) -> ReLU -> Linear(512, nh, no bias)) and autograd through it, without the [G, rows, 512] hidden layer in

@@ -468,3 +468,23 @@ def test_pack_linear_train_matches_the_torch_packing():
         ref = torch.zeros(Np, Kp, dtype=torch.float16).cuda()
         ref[:N, :K] = w.half()
         assert torch.equal(wp, ref) and torch.equal(wt, ref.t().contiguous())
+
+
+@pytest.mark.parametrize("B,C,Cmid", [(8, 180, 10), (3, 64, 4), (16, 256, 64)])
+def test_se_gate_kernels_match_torch(B, C, Cmid):
+    """grl_se_mlp_fwd / _bwd (csrc/se_train.hip) against the torch expression of ChannelAttention's MLP, values and all five gradients."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(51)
+    pool = torch.randn(B, C, generator=g).cuda()
+    w1, b1 = (torch.randn(Cmid, C, generator=g) / math.sqrt(C)).cuda(), (0.1 * torch.randn(Cmid, generator=g)).cuda()
+    w2, b2 = (torch.randn(C, Cmid, generator=g) / math.sqrt(Cmid)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    dy = torch.randn(B, C, generator=g).cuda()
+    outs = []
+    for kernel in (True, False):
+        ts = [t.clone().requires_grad_(True) for t in (pool, w1, b1, w2, b2)]
+        y = AG.se_gate(*ts) if kernel else torch.sigmoid(F.linear(F.relu(F.linear(ts[0], ts[1], ts[2])), ts[3], ts[4]))
+        y.backward(dy)
+        outs.append([y.detach()] + [t.grad for t in ts])
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and _rel(a, b) < 2e-5

@@ -1,2 +1,2 @@
-timeout 1100 python -m pytest -q -m gpu tests 2>&1 | grep -v "amdgpu.ids\|^RCCL\|^ROCm\|^HIP version\|^Hostname\|^Librccl" | tail -15 > gpurun_out/r6_suite_f.log
-tail -3 gpurun_out/r6_suite_f.log
+timeout 900 python -m pytest -q -m gpu tests/test_gpu_train.py tests/test_gpu_train_step.py -x 2>&1 | grep "passed\|failed\|Error" | tail -3
+for t in 0 1 0 1; do echo "SE_KERNEL=$t"; GRL_SE_KERNEL=$t timeout 200 python tools/train_steps.py --graph --steps 10 2>&1 | grep "graphed:"; done
