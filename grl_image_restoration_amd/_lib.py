@@ -542,7 +542,7 @@ def lib():
     L.grl_layernorm_bwd.restype = C.c_int
     L.grl_pack_conv3x3.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.grl_pack_conv3x3.restype = C.c_int
-    L.grl_pack_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
+    L.grl_pack_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.grl_pack_linear.restype = C.c_int
     L.grl_se_mlp_fwd.argtypes = [C.c_void_p, C.POINTER(GrlSeMlpArgs)]
     L.grl_se_mlp_fwd.restype = C.c_int

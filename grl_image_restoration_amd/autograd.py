@@ -168,15 +168,18 @@ def _is_registered(ptr: int) -> bool:
     return any(ptr in s for s in _REGISTERED.values())
 
 
-def _padded_weight(w: torch.Tensor, Np: int, Kp: int, transposed: bool = False) -> torch.Tensor:
+def _padded_weight(w: torch.Tensor, Np: int, Kp: int, transposed: bool = False, bias: Optional[torch.Tensor] = None, want_bias: bool = False):
     """fp16 [Np, Kp] zero-padded copy of a weight (``transposed``: its [Kp, Np] transpose, the operand of the data-gradient
     launch); for registered parameters kept per parameter and refreshed when the version counter moves (an optimizer step),
-    so the backward of a step finds the copy its forward made."""
+    so the backward of a step finds the copy its forward made.  ``want_bias``: returns (copy, fp32 bias [Np] zero padded) -- the
+    bias of the layer packed by the same launch (round 6: a cat per linear layer and step before)."""
     key = w.data_ptr()
+    bver = None if bias is None else (bias.data_ptr(), bias._version)
     sig = (tuple(w.shape), Np, Kp, w.device)
     keep = _is_registered(key)
     ent = _WEIGHTS.get(key) if keep else None
-    if ent is None or ent[0] != w._version or ent[1] != sig:
+    stale = ent is None or ent[0] != w._version or ent[1] != sig or (want_bias and ent[5] != bver)
+    if stale:
         reuse = ent is not None and ent[1] == sig
         buf = ent[2] if reuse else ops.empty(Np, Kp, dtype=ops.GEMM_DTYPE, device=w.device)
         # a parameter that needs gradients will want the transpose in this step's backward pass: both in one launch (the buffers
@@ -184,16 +187,25 @@ def _padded_weight(w: torch.Tensor, Np: int, Kp: int, transposed: bool = False) 
         tbuf = ent[4] if reuse else None
         if tbuf is None and (w.requires_grad or transposed):
             tbuf = ops.empty(Kp, Np, dtype=ops.GEMM_DTYPE, device=w.device)
+        bbuf = ent[6] if reuse and len(ent) > 6 else None
+        if bbuf is None and want_bias:
+            bbuf = ops.empty(Np, dtype=torch.float32, device=w.device)
         if w.is_cuda:
-            ops.pack_linear_train(w, buf, tbuf)
+            ops.pack_linear_train(w, buf, tbuf, bias if want_bias else None, bbuf if want_bias else None)
         else:                                  # (host-side cache logic is tested on CPU tensors; nothing computes there)
             buf.zero_()
             buf[: w.shape[0], : w.shape[1]].copy_(w.detach())
             if tbuf is not None:
                 tbuf.copy_(buf.t())
-        ent = [w._version, sig, buf, tbuf, tbuf]
+            if want_bias:
+                bbuf.zero_()
+                if bias is not None:
+                    bbuf[: bias.numel()].copy_(bias.detach())
+        ent = [w._version, sig, buf, tbuf, tbuf, bver if want_bias else (ent[5] if reuse and len(ent) > 5 else None), bbuf]
         if keep:
             _WEIGHTS[key] = ent
+    if want_bias:
+        return ent[2], ent[6]
     if not transposed:
         return ent[2]
     if ent[3] is None:
@@ -250,13 +262,6 @@ _REAL_WIDTHS = [__import__("os").environ.get("GRL_REAL_WIDTHS", "1") != "0"]
 _F16_HANDOVER = [__import__("os").environ.get("GRL_F16_HANDOVER", "1") != "0"]     # linear layers: fp16 operand copies for the weight gradient
 
 
-def _bias_padded(b, N, Np, device):
-    bp = _zeros(Np, device)
-    if b is not None:
-        bp = torch.cat([b.detach().float(), _zeros(Np - N, device)]) if Np > N else b.detach().float()
-    return bp
-
-
 @torch.library.custom_op("grl::linear", mutates_args=())
 def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_col: int = -1) -> torch.Tensor:
     """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in grl_linear_fwd).  ``one_col`` >= 0: the caller's promise
@@ -265,8 +270,7 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_c
     M, K = x.shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
-    wp = _padded_weight(w, Np, Kp)
-    bp = _bias_padded(b, N, Np, x.device)
+    wp, bp = _padded_weight(w, Np, Kp, bias=b, want_bias=True)     # (weight, its transpose and the padded bias: one launch per step)
     if _real(K, Kp):
         xa, kw = _rows16(x.detach()), dict(a_cols=K, a_one=True)      # (the ones column meets a zero weight column)
         _leave_operand(x, xa)

@@ -152,10 +152,12 @@ extern "C" int grl_pack_conv3x3(void* stream, const float* w, const float* b, vo
 // (torch: a converting slice copy + .t().contiguous(), two launches per linear layer, 400 per step).
 namespace {
 __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restrict__ w, f16* __restrict__ wp, f16* __restrict__ wt, int N, int K,
-                                                          int Np, int Kp) {
+                                                          int Np, int Kp, const float* __restrict__ b, float* __restrict__ bp) {
     __shared__ f16 tile[32][33];
     const int n0 = blockIdx.y * 32, k0 = blockIdx.x * 32;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    if (bp != nullptr && blockIdx.x == 0 && threadIdx.x < 32 && n0 + threadIdx.x < Np)       // the zero-padded fp32 bias [Np] rides along
+        bp[n0 + threadIdx.x] = (b != nullptr && n0 + threadIdx.x < N) ? b[n0 + threadIdx.x] : 0.f;
     for (int r = ty; r < 32; r += 8) {
         const int n = n0 + r, k = k0 + tx;
         const f16 v = (n < N && k < K) ? (f16)w[(int64_t)n * K + k] : (f16)0.f;
@@ -171,10 +173,11 @@ __global__ __launch_bounds__(256) void pack_linear_kernel(const float* __restric
 }
 }  // namespace
 
-extern "C" int grl_pack_linear(void* stream, const float* w, void* out_w, void* out_wt, int32_t N, int32_t K, int32_t Np, int32_t Kp) {
+extern "C" int grl_pack_linear(void* stream, const float* w, const float* b, void* out_w, void* out_wt, float* out_b, int32_t N, int32_t K,
+                               int32_t Np, int32_t Kp) {
     if (!w || !out_w || N <= 0 || K <= 0 || Np < N || Kp < K) return GRL_ERR_BAD_ARG;
     hipLaunchKernelGGL(pack_linear_kernel, dim3((Kp + 31) / 32, (Np + 31) / 32), dim3(256), 0, (hipStream_t)stream, w, (f16*)out_w, (f16*)out_wt,
-                       N, K, Np, Kp);
+                       N, K, Np, Kp, b, out_b);
     GRL_CHECK_LAUNCH();
     return 0;
 }

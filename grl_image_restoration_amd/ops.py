@@ -992,14 +992,18 @@ def pack_conv_train(w: torch.Tensor, b: Optional[torch.Tensor], rows_pad: int, c
     return ow, ob
 
 
-def pack_linear_train(w: torch.Tensor, wp: torch.Tensor, wt: Optional[torch.Tensor]) -> None:
-    """grl_pack_linear: wp [Np, Kp] (fp16) <- zero-padded w [N, K]; wt [Kp, Np] <- its transpose (optional); one launch."""
-    _dev_check(w, wp, wt)
+def pack_linear_train(w: torch.Tensor, wp: torch.Tensor, wt: Optional[torch.Tensor], b: Optional[torch.Tensor] = None,
+                      bp: Optional[torch.Tensor] = None) -> None:
+    """grl_pack_linear: wp [Np, Kp] (fp16) <- zero-padded w [N, K]; wt [Kp, Np] <- its transpose (optional); bp [Np] (fp32) <- the
+    zero-padded bias b (optional; b None: zeros); one launch."""
+    _dev_check(w, wp, wt, b, bp)
     N, K = w.shape
     Np, Kp = wp.shape
     wc = w.detach().float().contiguous()
+    bc = None if b is None else b.detach().float().contiguous()
     assert wp.dtype == GEMM_DTYPE and wp.is_contiguous() and (wt is None or (wt.dtype == GEMM_DTYPE and wt.is_contiguous() and wt.shape == (Kp, Np)))
-    L.check(L.lib().grl_pack_linear(L.stream_ptr(), _ptr(wc), _ptr(wp), _ptr(wt), N, K, Np, Kp), "grl_pack_linear")
+    assert bp is None or (bp.dtype == torch.float32 and bp.is_contiguous() and bp.numel() == Np and (bc is None or bc.numel() == N))
+    L.check(L.lib().grl_pack_linear(L.stream_ptr(), _ptr(wc), _ptr(bc), _ptr(wp), _ptr(wt), _ptr(bp), N, K, Np, Kp), "grl_pack_linear")
 
 
 def se_mlp_ok(pool: torch.Tensor, w1: torch.Tensor) -> bool:

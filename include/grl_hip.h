@@ -572,8 +572,10 @@ int grl_pack_conv3x3(void* stream, const float* w, const float* b, void* out_w, 
 
 /* nn.Linear weight for grl_linear_fwd and for its data-gradient launch in one launch (ABI 22, training path):
  *   w [N][K] fp32 (mixed_attn_block.py:669-676, 727-736; mixed_attn_block_efficient.py:379; swin_v1_block.py:29-33)
- *   -> out_w fp16 [Np][Kp] zero padded, and (optional) out_wt fp16 [Kp][Np], its transpose. */
-int grl_pack_linear(void* stream, const float* w, void* out_w, void* out_wt, int32_t N, int32_t K, int32_t Np, int32_t Kp);
+ *   -> out_w fp16 [Np][Kp] zero padded, (optional) out_wt fp16 [Kp][Np], its transpose, and (optional) out_b fp32 [Np] = the bias b [N]
+ *   zero padded (b NULL: zeros). */
+int grl_pack_linear(void* stream, const float* w, const float* b, void* out_w, void* out_wt, float* out_b, int32_t N, int32_t K, int32_t Np,
+                    int32_t Kp);
 
 /* Head planes of the training path (ABI 21): projection output x [T, S_in, nh, d] (fp32) -> the attention operands, fp32 planes
  * out32 [S_out][nh][T][32] and their fp16 copy out16, forward; dx and the scale gradients, backward.

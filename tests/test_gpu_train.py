@@ -464,10 +464,14 @@ def test_pack_linear_train_matches_the_torch_packing():
     for N, K, Np, Kp in [(180, 180, 192, 192), (540, 180, 576, 192), (90, 180, 96, 192), (180, 360, 192, 384), (33, 70, 64, 96)]:
         w = torch.randn(N, K, generator=g).cuda()
         wp, wt = torch.full((Np, Kp), 7.0, dtype=torch.float16).cuda(), torch.full((Kp, Np), 7.0, dtype=torch.float16).cuda()
-        ops.pack_linear_train(w, wp, wt)
+        b, bp = torch.randn(N, generator=g).cuda(), torch.full((Np,), 7.0).cuda()
+        ops.pack_linear_train(w, wp, wt, b, bp)
         ref = torch.zeros(Np, Kp, dtype=torch.float16).cuda()
         ref[:N, :K] = w.half()
         assert torch.equal(wp, ref) and torch.equal(wt, ref.t().contiguous())
+        assert torch.equal(bp[:N], b) and float(bp[N:].abs().sum()) == 0.0
+        ops.pack_linear_train(w, wp, None, None, bp)
+        assert float(bp.abs().sum()) == 0.0
 
 
 @pytest.mark.parametrize("B,C,Cmid", [(8, 180, 10), (3, 64, 4), (16, 256, 64)])
