@@ -619,6 +619,22 @@ def layer_norm(x, gamma, beta, eps: float = 1e-5):
     return F.layer_norm(x, (n,), gamma, beta, eps)
 
 
+class PadGradMask(torch.autograd.Function):
+    """Identity forward (a view, no launch); the gradient is multiplied by ``mask`` (broadcast over the last dimension).  For a tensor
+    whose pad columns already hold the constants its consumer wants -- the anchors -> stripe attention output used as the values of the
+    reverse direction: column d is the softmax denominator over itself = 1.0, column 31 is 0 -- but must not carry gradient."""
+
+    @staticmethod
+    def forward(ctx, y, mask):
+        ctx.save_for_backward(mask)
+        return y.view_as(y)
+
+    @staticmethod
+    def backward(ctx, g):
+        (mask,) = ctx.saved_tensors
+        return g * mask, None
+
+
 class SeMlpFn(torch.autograd.Function):
     """sigmoid(W2 relu(W1 pool + b1) + b2) on the pooled channel means [B, C] (ops.se_mlp / se_mlp_bwd, csrc/se_train.hip)."""
 

@@ -1019,7 +1019,7 @@ class GRL(nn.Module):
             cache[key] = blk
         return torch.cat([t.permute(1, 0, 2), blk], dim=2)
 
-    def _block_planes(self, x, scales, one_cols):
+    def _block_planes(self, x, scales, one_cols, sc=None):
         """All head planes of a block's projection in ONE chain: ``x`` [tokens, S, nh, d] (S slots: q / k / v of the window branch and of
         the stripe branch; or the anchors, used twice) -> fp32 planes [S, nh, tokens, 32] plus their fp16 copy (the kernels' operands).
         ``scales[j]``: None = slot j is taken as it is (values), a tensor [nh] = L2-normalise over d and multiply (q: the clamped
@@ -1038,7 +1038,8 @@ class GRL(nn.Module):
             ones = cache.get(("ones_nh", nh, str(dev)))
             if ones is None:
                 ones = cache[("ones_nh", nh, str(dev))] = torch.ones(nh, dtype=torch.float32, device=dev)
-            sc = torch.stack([ones if s is None else s for s in scales])                     # [S, nh] (differentiable in the q scales)
+            if sc is None:                                                                   # (else: prebuilt for all blocks, _train_tables)
+                sc = torch.stack([ones if s is None else s for s in scales])                 # [S, nh] (differentiable in the q scales)
             # (the fp32 planes are autograd's handle on the operands only -- every consumer takes the fp16 copies, f16= of the attention
             # op -- so the kernel does not write them: GRL_PLANES_WRITE32=1 restores the values)
             outs = AG.HeadPlanesFn.apply(xin, sc, tuple(0 if expanded else j for j in range(S)), tuple(s is None for s in scales),
@@ -1104,8 +1105,13 @@ class GRL(nn.Module):
             ls = torch.stack([m.logit_scale.reshape(-1) for _, ts in blocks for m in ts]).view(len(blocks), 3, -1)
             scales = torch.clamp(ls, max=math.log(1.0 / 0.01)).exp() * LOG2E      # efficient.py:39, exp2 domain
             floors = -1.0 - torch.ceil(scales.detach())                           # tables.lazy_floor
-            for (key, _), sc, fl in zip(blocks, scales.unbind(0), floors.unbind(0)):
-                out[key] = (tuple(tabs[key + (slot,)] for slot in range(3)), sc, fl)
+            # the [slots, nh] scale matrices of the two plane launches of every block (q k v q k v | anchors as q, as k) from one cat
+            # each and one unbind (per block: a stack forward, a stack backward)
+            one = torch.ones(len(blocks), 1, scales.shape[2], dtype=scales.dtype, device=scales.device)
+            sc6 = torch.cat([scales[:, 0:1], one, one, scales[:, 2:3], one, one], dim=1).unbind(0)
+            sc2 = torch.cat([scales[:, 1:2], one], dim=1).unbind(0)
+            for i, ((key, _), sc, fl) in enumerate(zip(blocks, scales.unbind(0), floors.unbind(0))):
+                out[key] = (tuple(tabs[key + (slot,)] for slot in range(3)), sc, fl, sc6[i], sc2[i])
         return out
 
     def _attn_table(self, m: _Affine, win, df, dev):
@@ -1209,8 +1215,9 @@ class GRL(nn.Module):
             floors = -1.0 - torch.ceil(scales.detach())                      # tables.lazy_floor from the already scaled values
             tabs = (self._attn_table(tw, geo.window, 1, dev), self._attn_table(t1, geo.stripe, df, dev),
                     self._attn_table(t2, geo.stripe, df, dev))
-        else:                                                                # (built for all blocks at once: _train_tables)
-            tabs, scales, floors = pre
+        sc6 = sc2 = None
+        if pre is not None:                                                  # (built for all blocks at once: _train_tables)
+            tabs, scales, floors, sc6, sc2 = pre
         sw, s1, s2 = scales.unbind(0)
         fw, f1, f2 = floors.unbind(0)
         cache = self.__dict__.setdefault("_coords_cache", {})
@@ -1219,8 +1226,8 @@ class GRL(nn.Module):
             ones = cache[("ones_nh", nh, str(dev))] = torch.ones(nh, dtype=torch.float32, device=dev)
         # slots of the projection: q k v (window branch), q k v (stripe branch); the anchors serve as queries (scaled) and as keys
         (qw, kw, vw, qs, ks, vs), (qw16, kw16, vw16, qs16, ks16, vs16) = self._block_planes(
-            qkv.view(M, 6, nh, d), (sw, ones, None, s2, ones, None), (-1, k1, v1, -1, k1, v1))
-        (aq, ak), (aq16, ak16) = self._block_planes(anc.view(-1, 1, nh, d).expand(-1, 2, nh, d), (s1, ones), (-1, k1))
+            qkv.view(M, 6, nh, d), (sw, ones, None, s2, ones, None), (-1, k1, v1, -1, k1, v1), sc=sc6)
+        (aq, ak), (aq16, ak16) = self._block_planes(anc.view(-1, 1, nh, d).expand(-1, 2, nh, d), (s1, ones), (-1, k1), sc=sc2)
 
         ws, sh = geo.window, geo.window_shift
         st, ss = geo.stripe, geo.stripe_shift_size
@@ -1244,7 +1251,13 @@ class GRL(nn.Module):
         onev = cache.get(("onev", d, str(dev)))
         if onev is None:
             onev = cache[("onev", d, str(dev))] = (torch.arange(32, device=dev) == v1).float()
-        yv = torch.addcmul(onev, y, dmask)                              # real head dims only, and the constant 1.0 in column d again
+        if y.is_cuda and d < 31:
+            # the kernel's output already IS the prepared value operand: column d = the softmax denominator over itself (1.0, exact
+            # once rounded to fp16), column 31 = 0.  Only the gradient of the pad columns has to go (round 6: an addcmul forward and
+            # three multiplies backward before).
+            yv = AG.PadGradMask.apply(y, dmask)
+        else:
+            yv = torch.addcmul(onev, y, dmask)                          # real head dims only, and the constant 1.0 in column d again
         os_ = AG.AttentionFn.apply(qs, ak, yv, tabs[2],
                                    dict(q=g_tok_s, k=g_anc, B=B, nh=nh, d=d, masked=geo.stripe_shift, floor=f2, prepared=True,
                                         f16=(qs16, ak16, None), token_major=tm))
