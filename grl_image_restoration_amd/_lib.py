@@ -46,6 +46,8 @@ EXPORTS = [
     "grl_pack_linear",
     "grl_se_mlp_fwd",
     "grl_se_mlp_bwd",
+    "grl_se_colsum",
+    "grl_se_apply",
     "grl_head_planes_fwd",
     "grl_head_planes_bwd",
     "grl_cpb_table_fwd",
@@ -446,6 +448,18 @@ class GrlSeMlpArgs(_Strict):
     ]
 
 
+class GrlSeRowsArgs(_Strict):
+    _fields_ = [
+        ("a", C.c_void_p), ("lda", C.c_int64),
+        ("f", C.c_void_p), ("ldf", C.c_int64),
+        ("g", C.c_void_p),
+        ("h", C.c_void_p),
+        ("out", C.c_void_p), ("ldo", C.c_int64),
+        ("k", C.c_float),
+        ("M", C.c_int32), ("C", C.c_int32), ("rows_per_image", C.c_int32),
+    ]
+
+
 class GrlCpbArgs(_Strict):
     _fields_ = [
         ("coords", C.c_void_p),
@@ -548,6 +562,10 @@ def lib():
     L.grl_se_mlp_fwd.restype = C.c_int
     L.grl_se_mlp_bwd.argtypes = [C.c_void_p, C.POINTER(GrlSeMlpArgs)]
     L.grl_se_mlp_bwd.restype = C.c_int
+    L.grl_se_colsum.argtypes = [C.c_void_p, C.POINTER(GrlSeRowsArgs)]
+    L.grl_se_colsum.restype = C.c_int
+    L.grl_se_apply.argtypes = [C.c_void_p, C.POINTER(GrlSeRowsArgs)]
+    L.grl_se_apply.restype = C.c_int
     L.grl_head_planes_fwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]
     L.grl_head_planes_fwd.restype = C.c_int
     L.grl_head_planes_bwd.argtypes = [C.c_void_p, C.POINTER(GrlPlanesArgs)]

@@ -652,6 +652,43 @@ class SeMlpFn(torch.autograd.Function):
         return d_pool, d_w1.view_as(w1), d_b1, d_w2.view_as(w2), d_b2
 
 
+class SeResidualFn(torch.autograd.Function):
+    """x1 + u * gate(u) with gate = sigmoid(W2 relu(W1 mean_rows(u) + b1) + b2) per image: ChannelAttention on the CAB's conv output u
+    [M, C] and the block's residual (mixed_attn_block.py:956-967, mixed_attn_block_efficient.py:548) -- pool, MLP, apply: three launches
+    forward; three backward (csrc/se_train.hip).  As torch code: mean, the MLP chain, addcmul forward; three multiplies, a reduction,
+    the MLP's adjoints, the mean's expand / divide and a gradient add backward."""
+
+    @staticmethod
+    def forward(ctx, x1, u, w1, b1, w2, b2, rows_per_image):
+        xc, uc = _rows16(x1.detach()), _rows16(u.detach())
+        pool = ops.se_colsum(uc, rows_per_image, 1.0 / rows_per_image)
+        gate, hidden = ops.se_mlp(pool, w1, b1, w2, b2)
+        y = ops.se_apply(uc, gate, rows_per_image, f=xc)
+        ctx.save_for_backward(uc, pool, gate, hidden, w1, w2)
+        ctx.rpi = rows_per_image
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        u, pool, gate, hidden, w1, w2 = ctx.saved_tensors
+        rpi = ctx.rpi
+        dyc = _rows16(dy)
+        d_gate = ops.se_colsum(dyc, rpi, 1.0, f=u)
+        d_pool, d_w1, d_b1, d_w2, d_b2 = ops.se_mlp_bwd(d_gate, pool, gate, hidden, w1, w2)
+        d_u = ops.se_apply(dyc, gate, rpi, h=d_pool, k=1.0 / rpi)
+        return dy, d_u, d_w1.view_as(w1), d_b1, d_w2.view_as(w2), d_b2, None
+
+
+def se_residual(x1, u, w1, b1, w2, b2, rows_per_image: int):
+    """x1 + u * ChannelAttention-gate(u) on token matrices [B * rows_per_image, C]; w1 [Cmid, C], w2 [C, Cmid]."""
+    C_ = u.shape[1]
+    if u.is_cuda and ops.se_mlp_ok(u[:1], w1) and C_ % 4 == 0 and os.environ.get("GRL_SE_KERNEL", "1") != "0":
+        return SeResidualFn.apply(x1, u, w1, b1, w2, b2, rows_per_image)
+    B = u.shape[0] // rows_per_image
+    gate = se_gate(u.view(B, rows_per_image, C_).mean(dim=1), w1, b1, w2, b2)
+    return torch.addcmul(x1.view(B, rows_per_image, C_), u.view(B, rows_per_image, C_), gate.unsqueeze(1)).view_as(x1)
+
+
 def se_gate(pool, w1, b1, w2, b2):
     """The CAB's squeeze-excite gate from the pooled means (mixed_attn_block.py:956-963); w1 [Cmid, C], w2 [C, Cmid]."""
     if pool.is_cuda and ops.se_mlp_ok(pool, w1) and os.environ.get("GRL_SE_KERNEL", "1") != "0":

@@ -1289,9 +1289,8 @@ class GRL(nn.Module):
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
             c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention
             u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
-            pool = u.view(B, H * W, C).mean(dim=1)
-            gate = AG.se_gate(pool, se[1].weight.flatten(1), se[1].bias, se[3].weight.flatten(1), se[3].bias)   # (one launch each way: se_train.hip)
-            x1 = torch.addcmul(x1.view(B, H * W, C), u.view(B, H * W, C), gate.unsqueeze(1)).view(M, C)      # x1 + u * gate in one launch
+            # x1 + u * gate(u): pool, squeeze-excite MLP and the gated residual as three launches each way (autograd.se_residual)
+            x1 = AG.se_residual(x1, u, se[1].weight.flatten(1), se[1].bias, se[3].weight.flatten(1), se[3].bias, H * W)
         m = AG.linear(F.gelu(AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
         return self._norm_residual(x1, m, blk.norm2, H * W, dp)
 

@@ -1040,3 +1040,34 @@ def se_mlp_bwd(d_gate: torch.Tensor, pool: torch.Tensor, gate: torch.Tensor, hid
                           b1=_ptr(d_b1), b2=_ptr(d_b2))     # (b1 / b2 are not read by the backward kernel; non-null for the argument check)
     L.check(L.lib().grl_se_mlp_bwd(L.stream_ptr(), C.byref(args)), "grl_se_mlp_bwd")
     return d_pool, d_w1, d_b1, d_w2, d_b2
+
+
+def _rows_ok(t: torch.Tensor) -> bool:
+    return t.dtype == torch.float32 and t.dim() == 2 and t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 16 == 0
+
+
+def se_colsum(a: torch.Tensor, rows_per_image: int, k: float = 1.0, f: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """grl_se_colsum: [M / rows_per_image, C] = k * per-image column sums of a (* f): the CAB's average pool / the gate's gradient."""
+    _dev_check(a, f)
+    M, C_ = a.shape
+    assert _rows_ok(a) and (f is None or (_rows_ok(f) and f.shape == a.shape)) and C_ % 4 == 0 and C_ <= 256 and M % rows_per_image == 0
+    out = torch.zeros(M // rows_per_image, C_, dtype=torch.float32, device=a.device)
+    args = L.GrlSeRowsArgs(a=_ptr(a), lda=a.stride(0), f=_ptr(f), ldf=f.stride(0) if f is not None else 0, out=_ptr(out), ldo=C_, k=k,
+                           M=M, C=C_, rows_per_image=rows_per_image)
+    L.check(L.lib().grl_se_colsum(L.stream_ptr(), C.byref(args)), "grl_se_colsum")
+    return out
+
+
+def se_apply(a: torch.Tensor, g: torch.Tensor, rows_per_image: int, f: Optional[torch.Tensor] = None, h: Optional[torch.Tensor] = None,
+             k: float = 0.0) -> torch.Tensor:
+    """grl_se_apply: out[row] = a[row] * g[image] (+ f[row]) (+ k * h[image]) on token matrices [M, C]; g / h [images, C]."""
+    _dev_check(a, g, f, h)
+    M, C_ = a.shape
+    assert _rows_ok(a) and (f is None or (_rows_ok(f) and f.shape == a.shape)) and C_ % 4 == 0 and C_ <= 256 and M % rows_per_image == 0
+    assert g.dtype == torch.float32 and g.is_contiguous() and g.shape == (M // rows_per_image, C_)
+    assert h is None or (h.dtype == torch.float32 and h.is_contiguous() and h.shape == g.shape)
+    out = empty(M, C_, dtype=torch.float32, device=a.device)
+    args = L.GrlSeRowsArgs(a=_ptr(a), lda=a.stride(0), f=_ptr(f), ldf=f.stride(0) if f is not None else 0, g=_ptr(g), h=_ptr(h), out=_ptr(out),
+                           ldo=C_, k=k, M=M, C=C_, rows_per_image=rows_per_image)
+    L.check(L.lib().grl_se_apply(L.stream_ptr(), C.byref(args)), "grl_se_apply")
+    return out

@@ -628,6 +628,26 @@ typedef struct GrlSeMlpArgs {
 int grl_se_mlp_fwd(void* stream, const GrlSeMlpArgs* args);
 int grl_se_mlp_bwd(void* stream, const GrlSeMlpArgs* args);
 
+/* The two passes over the token matrix around that MLP (ABI 22; [M, ld] fp32 matrices, rows 16-byte aligned, C <= 256 a multiple of 4,
+ * image of row m = m / rows_per_image):
+ *   grl_se_colsum: out[b][c] += k * sum over the rows of image b of a[row][c] (* f[row][c] when f != NULL); out [M / rows_per_image, C],
+ *                  zeroed by the caller (atomics).  AdaptiveAvgPool2d(1) of ChannelAttention (mixed_attn_block.py:956-958) with k = 1 / HW;
+ *                  backward: the gate's gradient sum_rows dy * u.
+ *   grl_se_apply : out[row][c] = a[row][c] * g[b][c] (+ f[row][c]) (+ k * h[b][c]).  Forward x + cab(x) * gate (:965-967 and the residual
+ *                  of mixed_attn_block_efficient.py:548); backward d_u = dy * gate + d_pool / HW. */
+typedef struct GrlSeRowsArgs {
+    const float* a; int64_t lda;
+    const float* f; int64_t ldf;     /* optional */
+    const float* g;                  /* apply: [images, C] */
+    const float* h;                  /* apply, optional: [images, C] */
+    float* out;     int64_t ldo;     /* colsum: [images, C] (ldo ignored); apply: [M, ldo] */
+    float k;
+    int32_t M, C, rows_per_image;
+} GrlSeRowsArgs;
+
+int grl_se_colsum(void* stream, const GrlSeRowsArgs* args);
+int grl_se_apply(void* stream, const GrlSeRowsArgs* args);
+
 /* Relative-position bias tables for MANY AffineTransforms at once, forward and backward (ABI 21, training path):
  *   replaces  16 * sigmoid(cpb_mlp(relative_coords_table))  models/common/mixed_attn_block_efficient.py:23-34,49-58  (cpb_mlp =
  *   Linear(2, 512, bias) -> ReLU -> Linear(512, nh, no bias)) and autograd through it, without the [G, rows, 512] hidden layer in

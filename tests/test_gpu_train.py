@@ -492,3 +492,26 @@ def test_se_gate_kernels_match_torch(B, C, Cmid):
         outs.append([y.detach()] + [t.grad for t in ts])
     for a, b in zip(*outs):
         assert a.shape == b.shape and _rel(a, b) < 2e-5
+
+
+@pytest.mark.parametrize("B,HW,C,Cmid", [(4, 1000, 180, 10), (2, 64, 64, 4), (8, 4096, 180, 10)])
+def test_se_residual_matches_the_torch_chain(B, HW, C, Cmid, monkeypatch):
+    """x1 + u * ChannelAttention-gate(u) as pool / MLP / apply launches (autograd.se_residual, csrc/se_train.hip) against the torch chain
+    it replaces (mean, two linears with ReLU / sigmoid, addcmul) -- values and the gradients of both token matrices and all four parameters."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(52)
+    M = B * HW
+    x1, u = torch.randn(M, C, generator=g).cuda(), torch.randn(M, C, generator=g).cuda() + 0.3
+    w1, b1 = (torch.randn(Cmid, C, generator=g) / math.sqrt(C)).cuda(), (0.1 * torch.randn(Cmid, generator=g)).cuda()
+    w2, b2 = (torch.randn(C, Cmid, generator=g) / math.sqrt(Cmid)).cuda(), (0.1 * torch.randn(C, generator=g)).cuda()
+    dy = torch.randn(M, C, generator=g).cuda()
+    outs = []
+    for mode in ("1", "0"):
+        monkeypatch.setenv("GRL_SE_KERNEL", mode)
+        ts = [t.clone().requires_grad_(True) for t in (x1, u, w1, b1, w2, b2)]
+        y = AG.se_residual(*ts, HW)
+        y.backward(dy)
+        outs.append([y.detach()] + [t.grad for t in ts])
+    for a, b in zip(*outs):
+        assert a.shape == b.shape and _rel(a, b) < 3e-5
