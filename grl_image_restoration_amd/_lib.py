@@ -12,7 +12,7 @@ LIB_PATH = os.path.join(_HERE, "libgrl_hip.so")
 ABI_VERSION = 22
 DT_F32, DT_BF16, DT_F16 = 0, 1, 2
 
-EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES = 0, 1, 2, 3
+EPI_PLAIN, EPI_GELU, EPI_GROUPNORM, EPI_LN_RES, EPI_GELU_GRAD = 0, 1, 2, 3, 4
 
 # every symbol include/grl_hip.h declares (tests check the .so exports all of them)
 EXPORTS = [
@@ -108,7 +108,7 @@ class GrlLinearArgs(_Strict):
         ("a_cols", C.c_int32),
         ("a_one", C.c_int32),
         ("n_store", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("a_gelu", C.c_int32),
         ("a16_out", C.c_void_p),
         ("lda16", C.c_int64),
     ]

@@ -263,10 +263,12 @@ _F16_HANDOVER = [__import__("os").environ.get("GRL_F16_HANDOVER", "1") != "0"]  
 
 
 @torch.library.custom_op("grl::linear", mutates_args=())
-def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_col: int = -1) -> torch.Tensor:
+def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_col: int = -1, gelu_in: bool = False) -> torch.Tensor:
     """y[M, N] = x[M, K] w[N, K]^T + b  (fp32 in / out, fp16 operands in grl_linear_fwd).  ``one_col`` >= 0: the caller's promise
     that column one_col of x holds 1.0 (against a zero weight column) -- the bias gradient is then read off the weight-gradient
-    contraction, as with the pad column elsewhere, instead of a separate column sum of dy."""
+    contraction, as with the pad column elsewhere, instead of a separate column sum of dy.  ``gelu_in``: y = gelu(x) w^T + b -- fc2 of the
+    Mlp on fc1's pre-activation (swin_v1_block.py:37-43): the loader applies the GELU on its way to fp16 and the data-gradient launch
+    multiplies by gelu'(x) in its epilogue, so neither the activation nor its adjoint is a launch (or a tensor) of its own."""
     M, K = x.shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
@@ -277,6 +279,8 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_c
     else:
         xa, kw = _padded(x.detach().float(), Kp, ones=True), {}
         _leave_operand(x, xa)
+    if gelu_in:
+        kw["a_gelu"] = True
     if w.requires_grad and _F16_HANDOVER[0] and K % 4 == 0:
         # the fp16 operand [x | 1 | 0] the kernel contracts, kept for the weight gradient INSTEAD of x: grl_gemm_tn then reads 2-byte
         # values from 16-byte aligned rows once per output tile instead of converting the fp32 matrix every time (and the saved
@@ -291,25 +295,36 @@ def linear_op(x: torch.Tensor, w: torch.Tensor, b: Optional[torch.Tensor], one_c
 
 
 @linear_op.register_fake
-def _(x, w, b, one_col=-1):
+def _(x, w, b, one_col=-1, gelu_in=False):
     return x.new_empty(x.shape[0], w.shape[0], dtype=torch.float32)
 
 
 def _linear_setup(ctx, inputs, output):
-    x, w, b, one_col = inputs
+    x, w, b, one_col, gelu_in = inputs
     ctx.one_col = int(one_col)
+    ctx.gelu_in = bool(gelu_in)
     xp = _take_operand(x)
     # the operand the forward launch read -- [x | 1 | 0], or x itself where the kernels take real widths -- is all the backward needs
     # of x: saved INSTEAD of x (both were kept, doubling the saved activation of every layer whose width is not a kernel
     # width -- C = 180 in all GRL-Base blocks)
-    ctx.save_for_backward(xp if xp is not None else x, w)
     ctx.x_shape, ctx.padded = tuple(x.shape), xp is not None and xp.shape[1] != x.shape[1]
     ctx.x16 = xp is not None and xp.dtype == ops.GEMM_DTYPE
+    if ctx.gelu_in:        # the pre-activation for gelu' in the backward pass, and the operand the launch contracted (fp16 gelu(x), if handed over)
+        ctx.save_for_backward(xp if ctx.x16 else x, w, x)
+    else:
+        ctx.save_for_backward(xp if xp is not None else x, w)
     ctx.has_b = b is not None
 
 
 def _linear_backward(ctx, dy):
-    xs, w = ctx.saved_tensors
+    if ctx.gelu_in:
+        xs, w, pre = ctx.saved_tensors
+        pre = _rows16(pre.detach())
+        if not ctx.x16:                        # (no fp16 operand was handed over: the weight gradient needs gelu(x) as a tensor)
+            xs = F.gelu(pre)
+    else:
+        xs, w = ctx.saved_tensors
+        pre = None
     M, K = ctx.x_shape
     N = w.shape[0]
     Kp, Np = pad_width(K), pad_width(N)
@@ -327,6 +342,8 @@ def _linear_backward(ctx, dy):
         wt = _padded_weight(w, Np, Kp, transposed=True)            # [Kp, Np]: rows = input channels
         if need_w and ctx.x16:                                     # the fp16 (scaled) dy of this launch feeds the weight gradient below
             dy16 = dkw["a16_out"] = ops.empty(M, Np, dtype=ops.GEMM_DTYPE, device=dy.device)
+        if pre is not None:                                        # ... times gelu'(x), in the launch's epilogue
+            dkw.update(epi=L.EPI_GELU_GRAD, resid=pre if (rk or K == Kp) else _padded(pre, Kp))
         if rk:
             dx = ops.linear(dya, wt, _zeros(Kp, dy.device), out_dtype=torch.float32, a_scale=s, out_scale=1.0 / s, n_store=K, **dkw)
         else:
@@ -366,7 +383,7 @@ def _linear_backward(ctx, dy):
             dw = full[0][:N, :K]                                     # (contiguous -- adopted as .grad without a copy -- when Kg == K)
     if want_b and db is None:
         db = dy.float().sum(0)
-    return dx, dw, db, None
+    return dx, dw, db, None, None
 
 
 linear_op.register_autograd(_linear_backward, setup_context=_linear_setup)
@@ -740,10 +757,10 @@ class AttentionFn:
                             bool(geo.get("prepared", False)), q16, k16, v16, tm)[0]
 
 
-def linear(x, w, b=None, one_col: int = -1):
+def linear(x, w, b=None, one_col: int = -1, gelu_in: bool = False):
     if not x.is_cuda:                      # CPU tensors: the composite torch path (composite.py; never a CUDA tensor)
-        return composite.linear(x, w, b)
-    return linear_op(x, w, b, one_col)
+        return composite.linear(F.gelu(x) if gelu_in else x, w, b)
+    return linear_op(x, w, b, one_col, gelu_in)
 
 
 def conv3x3(x, w, b, B, H, W):

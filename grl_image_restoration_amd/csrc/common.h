@@ -115,6 +115,19 @@ __device__ __forceinline__ float gelu_erf(float x) {
     return 0.5f * x * (1.0f + erf_x);
 }
 
+// d/dx of the exact GELU: Phi(x) + x phi(x), same erf approximation as gelu_erf (the backward of Mlp's activation, swin_v1_block.py:38)
+__device__ __forceinline__ float gelu_grad(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float poly = fmaf(1.061405429f, t, -1.453152027f);
+    poly = fmaf(poly, t, 1.421413741f);
+    poly = fmaf(poly, t, -0.284496736f);
+    poly = fmaf(poly, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f(-z * z * LOG2E_F);      // exp(-x^2 / 2)
+    const float erf_x = copysignf(1.0f - poly * t * e, x);
+    return fmaf(x * e, 0.39894228040143267794f, 0.5f * (1.0f + erf_x));
+}
+
 // Two GELUs at once on packed fp32 math (v_pk_mul/fma/add_f32: one issue slot for two elements -- the fused kernels are bound by
 // instruction issue, not by the VALU pipes): same formula and accuracy as gelu_erf, 19 instructions per pair instead of 28.
 typedef __attribute__((ext_vector_type(2))) float f32x2v;

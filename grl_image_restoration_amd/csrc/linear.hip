@@ -39,8 +39,12 @@ extern "C" int grl_linear_fwd(void* stream, const GrlLinearArgs* args) {
                          (p.a_one && p.a_cols >= p.Kpad)))
         return GRL_ERR_BAD_ARG;
     if (p.n_store > 0 && ((p.n_store % 4) || p.n_store > p.Npad || p.ldo < p.n_store || p.out_dtype != GRL_DT_F32 || p.out_plane_stride > 0 ||
-                          (p.epi != GRL_EPI_PLAIN && p.epi != GRL_EPI_GELU)))
+                          (p.epi != GRL_EPI_PLAIN && p.epi != GRL_EPI_GELU && p.epi != GRL_EPI_GELU_GRAD)))
         return GRL_ERR_BAD_ARG;
+    if (p.epi == GRL_EPI_GELU_GRAD && (p.resid == nullptr || (p.ldr % 4) || p.out_dtype != GRL_DT_F32 || p.out_plane_stride > 0 ||
+                                       (p.n_store == 0 && p.ldr < p.Npad) || (p.n_store > 0 && p.ldr < p.n_store)))
+        return GRL_ERR_BAD_ARG;
+    if (p.a_gelu && (p.a_dtype != GRL_DT_F32 || p.pool_df > 1 || p.a_split == 3)) return GRL_ERR_BAD_ARG;
     if (p.out_dtype != GRL_DT_F32 && p.out_plane_stride <= 0 && (p.ldo % 8) != 0) return GRL_ERR_BAD_ARG;  // 16-B stores
     if (p.epi == GRL_EPI_LN_RES && (p.Npad > 192 || p.n_real > p.Npad || p.resid == nullptr)) return GRL_ERR_BAD_ARG;
     hipStream_t st = (hipStream_t)stream;

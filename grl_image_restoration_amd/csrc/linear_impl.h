@@ -86,12 +86,18 @@ __device__ __forceinline__ void load_a_slab(const GrlLinearArgs& p, int row0, in
                 const bool lo = split && s / KS3 == 1;
                 const float4* q = (const float4*)(base + 32 * ss + 8 * kg);
                 float4 v0, v1;
-                if (p.a_cols > 0) {   // operand at its real width: columns >= a_cols are constants (0; 1.0 in column a_cols with a_one)
-                    const int c0 = 32 * ss + 8 * kg;
-                    v0 = c0 < p.a_cols ? q[0] : float4{(c0 == p.a_cols && p.a_one) ? 1.0f : 0.0f, 0, 0, 0};
-                    v1 = c0 + 4 < p.a_cols ? q[1] : float4{(c0 + 4 == p.a_cols && p.a_one) ? 1.0f : 0.0f, 0, 0, 0};
-                } else {
-                    v0 = q[0]; v1 = q[1];
+                const int c0 = 32 * ss + 8 * kg;
+                const bool in0 = p.a_cols <= 0 || c0 < p.a_cols, in1 = p.a_cols <= 0 || c0 + 4 < p.a_cols;
+                v0 = in0 ? q[0] : float4{0, 0, 0, 0};
+                v1 = in1 ? q[1] : float4{0, 0, 0, 0};
+                if (p.a_gelu) {       // the operand is gelu(A) (fc2 of the Mlp on fc1's pre-activation); gelu(0) = 0 keeps the pad columns
+                    const f32x2v g0 = gelu_erf2(f32x2v{v0.x, v0.y}), g1 = gelu_erf2(f32x2v{v0.z, v0.w});
+                    const f32x2v g2 = gelu_erf2(f32x2v{v1.x, v1.y}), g3 = gelu_erf2(f32x2v{v1.z, v1.w});
+                    v0 = float4{g0.x, g0.y, g1.x, g1.y}; v1 = float4{g2.x, g2.y, g3.x, g3.y};
+                }
+                if (p.a_cols > 0 && p.a_one) {   // operand at its real width: 1.0 in column a_cols (the other pad columns are 0)
+                    if (c0 == p.a_cols) v0.x = 1.0f;
+                    if (c0 + 4 == p.a_cols) v1.x = 1.0f;
                 }
                 if (!valid) { v0 = float4{0, 0, 0, 0}; v1 = v0; }
                 gemm_x8 v;
@@ -130,6 +136,17 @@ __device__ __forceinline__ void epilogue(const GrlLinearArgs& p, f32x4 (&acc)[NC
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[0][mt][nt][e] = gelu_erf(acc[0][mt][nt][e]);
+    } else if constexpr (EPI == GRL_EPI_GELU_GRAD) {
+        // the product times gelu'(h) of the same element: h = resid [M, ldr] (fc1's pre-activation), columns < n_store only
+        const float* hrow = p.resid + (valid ? (int64_t)m : (int64_t)p.M - 1) * p.ldr;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            const int col = n0 + 16 * nt + 4 * g4;
+            if (p.n_store > 0 && col >= p.n_store) continue;
+            const float4 h4 = *(const float4*)(hrow + col);
+            acc[0][mt][nt][0] *= gelu_grad(h4.x); acc[0][mt][nt][1] *= gelu_grad(h4.y);
+            acc[0][mt][nt][2] *= gelu_grad(h4.z); acc[0][mt][nt][3] *= gelu_grad(h4.w);
+        }
     } else if constexpr (EPI == GRL_EPI_LN_RES) {
         // LayerNorm over the n_real real channels (eps 1e-5), then residual (+ gated extra branch).
         // Branch-free and batched: out-of-range rows are clamped (only the store is predicated) and the
@@ -423,6 +440,7 @@ int launch_k(const GrlLinearArgs& p, hipStream_t st) {
         switch (p.epi) {                                                                          \
             case GRL_EPI_PLAIN: return launch_one<KSTEPS, NTV, 1, GRL_EPI_PLAIN>(p, st);          \
             case GRL_EPI_GELU: return launch_one<KSTEPS, NTV, 1, GRL_EPI_GELU>(p, st);            \
+            case GRL_EPI_GELU_GRAD: return launch_one<KSTEPS, NTV, 1, GRL_EPI_GELU_GRAD>(p, st);  \
             case GRL_EPI_GROUPNORM: return launch_one<KSTEPS, NTV, 1, GRL_EPI_GROUPNORM>(p, st);  \
             default: return GRL_ERR_UNSUPPORTED;                                                  \
         }
@@ -465,6 +483,7 @@ int launch_split(const GrlLinearArgs& p0, hipStream_t st) {
         }
         p.w = (const char*)p0.w + (size_t)c0 * KSTEPS * 32 * 2;
         p.bias = p0.bias + c0;
+        if (p0.epi == GRL_EPI_GELU_GRAD) p.resid = p0.resid + c0;
         if (p0.gscale) p.gscale = p0.gscale + c0 / 32;
         const size_t esz = p0.out_dtype == GRL_DT_F32 ? 4 : 2;
         if (p0.out_plane_stride > 0) p.out = (char*)p0.out + (size_t)(c0 / 32) * p0.out_plane_stride * esz;

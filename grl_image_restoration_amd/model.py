@@ -1291,7 +1291,13 @@ class GRL(nn.Module):
             u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
             # x1 + u * gate(u): pool, squeeze-excite MLP and the gated residual as three launches each way (autograd.se_residual)
             x1 = AG.se_residual(x1, u, se[1].weight.flatten(1), se[1].bias, se[3].weight.flatten(1), se[3].bias, H * W)
-        m = AG.linear(F.gelu(AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
+        # Mlp (swin_v1_block.py:37-43): the GELU between fc1 and fc2 is taken by fc2's loader, its adjoint by the epilogue of fc2's
+        # data-gradient launch (autograd.linear gelu_in; GRL_GELU_FUSED=0: the torch activation)
+        h1 = AG.linear(x1, blk.mlp.fc1.weight, blk.mlp.fc1.bias)
+        if os.environ.get("GRL_GELU_FUSED", "1") != "0":
+            m = AG.linear(h1, blk.mlp.fc2.weight, blk.mlp.fc2.bias, gelu_in=True)
+        else:
+            m = AG.linear(F.gelu(h1), blk.mlp.fc2.weight, blk.mlp.fc2.bias)
         return self._norm_residual(x1, m, blk.norm2, H * W, dp)
 
     def _norm_residual(self, r, t, norm, rows_per_image: int, p: float):

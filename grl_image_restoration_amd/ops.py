@@ -174,6 +174,7 @@ def linear(
     a_one: bool = False,
     n_store: int = 0,
     a16_out: Optional[torch.Tensor] = None,
+    a_gelu: bool = False,
 ) -> torch.Tensor:
     """out[M, Npad] = epilogue(a[M, :Kpad] @ w[Npad, Kpad]^T + bias).  ``a``: 2-D fp32/fp16, row
     stride in elements = a.stride(0); ``pool=(df, H, W)`` averages df x df token blocks first.
@@ -195,7 +196,8 @@ def linear(
     Npad, Kpad = w.shape
     assert a_split in (1, 3) and a.shape[1] >= (a_cols if a_cols > 0 else Kpad // a_split) and bias.numel() == Npad
     assert a_cols == 0 or (a.dtype == torch.float32 and pool is None and a_split == 1 and a_cols % 4 == 0 and a.stride(0) % 4 == 0)
-    assert n_store == 0 or (n_store % 4 == 0 and n_store <= Npad and not planes and epi in (L.EPI_PLAIN, L.EPI_GELU))
+    assert n_store == 0 or (n_store % 4 == 0 and n_store <= Npad and not planes and epi in (L.EPI_PLAIN, L.EPI_GELU, L.EPI_GELU_GRAD))
+    assert not a_gelu or (a.dtype == torch.float32 and pool is None and a_split == 1)      # operand = gelu(a), taken in the loader
     assert a_split == 1 or (a.dtype == torch.float32 and Kpad % 96 == 0)
     if pool is not None:
         df, H, W = pool
@@ -228,7 +230,7 @@ def linear(
         add2_scale=_ptr(add2_scale), rows_per_image=rows_per_image, a_split=a_split, a_scale=a_scale, out_scale=out_scale,
         out_lo=_ptr(out_lo), out=_ptr(out), out_dtype=_KIND[out.dtype], ldo=ldo, out_plane_stride=plane_stride,
         w_regs=_ptr(w_regs), a_cols=a_cols, a_one=int(a_one), n_store=n_store,
-        a16_out=_ptr(a16_out), lda16=a16_out.stride(0) if a16_out is not None else 0,
+        a16_out=_ptr(a16_out), lda16=a16_out.stride(0) if a16_out is not None else 0, a_gelu=int(a_gelu),
     )
     assert a16_out is None or (a16_out.dtype == GEMM_DTYPE and a16_out.dim() == 2 and a16_out.stride(1) == 1 and a16_out.shape[0] >= M
                                and a16_out.shape[1] >= Kpad and a16_out.stride(0) % 8 == 0 and a.dtype == torch.float32)
@@ -239,6 +241,9 @@ def linear(
     if epi == L.EPI_LN_RES:
         assert resid is not None and resid.dtype == torch.float32 and ln_g.numel() == Npad and ln_b.numel() == Npad
         assert out.dtype == torch.float32
+    if epi == L.EPI_GELU_GRAD:   # out = product * gelu'(resid): resid [M, >= n_store or Npad] fp32
+        assert resid is not None and resid.dtype == torch.float32 and resid.stride(1) == 1 and resid.stride(0) % 4 == 0 and out.dtype == torch.float32
+        assert resid.shape[0] >= M and resid.shape[1] >= (n_store if n_store > 0 else Npad)
     with _timed(f"linear {Kpad}->{Npad}" if _PROFILE is not None else "linear"):
         L.check(L.lib().grl_linear_fwd(L.stream_ptr(), C.byref(args)), "grl_linear_fwd")
     return out

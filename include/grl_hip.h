@@ -35,7 +35,8 @@ enum { GRL_DT_F32 = 0, GRL_DT_BF16 = 1, GRL_DT_F16 = 2 };
  *             MixedAttention.proj + norm1  models/common/mixed_attn_block_efficient.py:379,543-548
  *             Mlp.forward + norm2          models/common/swin_v1_block.py:37-43, efficient.py:554
  * ------------------------------------------------------------------------------------------- */
-enum { GRL_EPI_PLAIN = 0, GRL_EPI_GELU = 1, GRL_EPI_GROUPNORM = 2, GRL_EPI_LN_RES = 3 };
+enum { GRL_EPI_PLAIN = 0, GRL_EPI_GELU = 1, GRL_EPI_GROUPNORM = 2, GRL_EPI_LN_RES = 3,
+       GRL_EPI_GELU_GRAD = 4 /* ABI 22: out = (A W^T + bias) * gelu'(resid[m][col]) -- the data gradient through Mlp's activation; fp32 out */ };
 
 typedef struct GrlLinearArgs {
     const void* a;          /* [M, lda] activations: GRL_DT_F32 (converted in-kernel) or GRL_DT_F16 */
@@ -91,7 +92,8 @@ typedef struct GrlLinearArgs {
                             /* forward launch; the weight-gradient contraction finds the bias gradient there)                     */
     int32_t n_store;        /* > 0 (fp32 output, PLAIN / GELU epilogue, no planes): only the columns < n_store (multiple of 4)    */
                             /* are stored; ldo >= n_store, ldo % 4 == 0                                                           */
-    int32_t reserved0;
+    int32_t a_gelu;         /* != 0 (fp32 A, no pooling, a_split <= 1): the operand is gelu(A), taken on the way to fp16 -- fc2 of the Mlp reads    */
+                            /* fc1's pre-activation (swin_v1_block.py:37-43); constants of a_cols / a_one are not passed through it              */
     void* a16_out;          /* optional (fp32 A, a_split <= 1): the fp16 operand the kernel contracts -- a_scale * A, pad columns     */
     int64_t lda16;          /* and the a_one column included -- written as [M, lda16] (lda16 >= Kpad, multiple of 8): the weight-     */
                             /* gradient GEMM of the same layer reads it instead of converting the fp32 matrix once per output tile     */

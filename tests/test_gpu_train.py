@@ -515,3 +515,24 @@ def test_se_residual_matches_the_torch_chain(B, HW, C, Cmid, monkeypatch):
         outs.append([y.detach()] + [t.grad for t in ts])
     for a, b in zip(*outs):
         assert a.shape == b.shape and _rel(a, b) < 3e-5
+
+
+@pytest.mark.parametrize("M,K,N", [(1000, 360, 180), (513, 128, 64)])
+def test_linear_with_gelu_input_matches_torch(M, K, N):
+    """y = gelu(x) W^T + b with the activation in the linear kernel's loader and gelu'(x) in the epilogue of the data-gradient launch
+    (autograd.linear gelu_in=True) against F.linear(F.gelu(x)) in float64."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(53)
+    x = torch.randn(M, K, generator=g) * 1.5
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = 0.1 * torch.randn(N, generator=g)
+    dy = torch.randn(M, N, generator=g) * 1e-6
+    xr, wr, br = (t.clone().double().requires_grad_(True) for t in (x, w, b))
+    ref = F.linear(F.gelu(xr), wr, br)
+    (ref * dy.double()).sum().backward()
+    xd, wd, bd = (t.clone().cuda().requires_grad_(True) for t in (x, w, b))
+    y = AG.GradScaleTop.apply(AG.linear(xd, wd, bd, gelu_in=True))
+    assert _rel(y, ref.detach()) < 2e-3
+    y.backward(dy.cuda())
+    assert _rel(xd.grad, xr.grad) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 2e-3
