@@ -1038,11 +1038,14 @@ def se_mlp_bwd(d_gate: torch.Tensor, pool: torch.Tensor, gate: torch.Tensor, hid
     dg, pl, w1c, w2c = (t.detach().float().contiguous() for t in (d_gate, pool, w1, w2))
     dev = pool.device
     d_pool = empty(B, C_, dtype=torch.float32, device=dev)
-    d_w1, d_b1 = empty(Cmid, C_, dtype=torch.float32, device=dev), empty(Cmid, dtype=torch.float32, device=dev)
-    d_w2, d_b2 = empty(C_, Cmid, dtype=torch.float32, device=dev), empty(C_, dtype=torch.float32, device=dev)
+    par = not deterministic()          # one workgroup per image + atomics into ONE zeroed buffer (else: one workgroup walks the batch)
+    n1, n2 = Cmid * C_, Cmid
+    flat = torch.zeros(2 * n1 + n2 + C_, dtype=torch.float32, device=dev) if par else empty(2 * n1 + n2 + C_, dtype=torch.float32, device=dev)
+    d_w1, d_b1 = flat[:n1].view(Cmid, C_), flat[n1 : n1 + n2]
+    d_w2, d_b2 = flat[n1 + n2 : 2 * n1 + n2].view(C_, Cmid), flat[2 * n1 + n2 :]
     args = L.GrlSeMlpArgs(pool=_ptr(pl), w1=_ptr(w1c), w2=_ptr(w2c), gate=_ptr(gate), hidden=_ptr(hidden), d_gate=_ptr(dg), d_pool=_ptr(d_pool),
                           d_w1=_ptr(d_w1), d_b1=_ptr(d_b1), d_w2=_ptr(d_w2), d_b2=_ptr(d_b2), B=B, C=C_, Cmid=Cmid,
-                          b1=_ptr(d_b1), b2=_ptr(d_b2))     # (b1 / b2 are not read by the backward kernel; non-null for the argument check)
+                          b1=_ptr(d_b1), b2=_ptr(d_b2), reserved0=int(par))     # (b1 / b2 are not read by the backward kernel; non-null for the argument check)
     L.check(L.lib().grl_se_mlp_bwd(L.stream_ptr(), C.byref(args)), "grl_se_mlp_bwd")
     return d_pool, d_w1, d_b1, d_w2, d_b2
 

@@ -608,7 +608,7 @@ int grl_head_planes_bwd(void* stream, const GrlPlanesArgs* args);
  *   replaces  ChannelAttention.attention[1..4]  models/common/mixed_attn_block.py:956-963  (Conv2d(C, C/r, 1) -> ReLU -> Conv2d(C/r, C, 1)
  *   -> Sigmoid on the pooled [B, C] means) and autograd through it.  C <= 256, Cmid <= 64; all arrays fp32, contiguous.
  * forward: hidden [B, Cmid] = relu(w1 pool + b1), gate [B, C] = sigmoid(w2 hidden + b2);  backward: d_pool [B, C] and the parameter
- * gradients d_w1 [Cmid, C], d_b1 [Cmid], d_w2 [C, Cmid], d_b2 [C] (written, not accumulated; one workgroup, no atomics). */
+ * gradients d_w1 [Cmid, C], d_b1 [Cmid], d_w2 [C, Cmid], d_b2 [C] (see reserved0). */
 typedef struct GrlSeMlpArgs {
     const float* pool;       /* [B, C] */
     const float* w1;         /* [Cmid, C] */
@@ -624,7 +624,8 @@ typedef struct GrlSeMlpArgs {
     float* d_w2;
     float* d_b2;
     int32_t B, C, Cmid;
-    int32_t reserved0;
+    int32_t reserved0;       /* backward: != 0 ("parallel") one workgroup per image that ADDS the parameter gradients with atomics into  */
+                             /* arrays the caller zeroed; 0: one workgroup walks the batch and writes them (bit-reproducible, serial)    */
 } GrlSeMlpArgs;
 
 int grl_se_mlp_fwd(void* stream, const GrlSeMlpArgs* args);
