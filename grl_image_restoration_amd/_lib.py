@@ -444,7 +444,7 @@ class GrlSeMlpArgs(_Strict):
         ("d_w2", C.c_void_p),
         ("d_b2", C.c_void_p),
         ("B", C.c_int32), ("C", C.c_int32), ("Cmid", C.c_int32),
-        ("reserved0", C.c_int32),
+        ("parallel", C.c_int32),
     ]
 
 

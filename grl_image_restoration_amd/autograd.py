@@ -258,8 +258,8 @@ def _real(n: int, npad: int) -> bool:
     return n % 4 == 0 and n < npad and _REAL_WIDTHS[0]
 
 
-_REAL_WIDTHS = [__import__("os").environ.get("GRL_REAL_WIDTHS", "1") != "0"]
-_F16_HANDOVER = [__import__("os").environ.get("GRL_F16_HANDOVER", "1") != "0"]     # linear layers: fp16 operand copies for the weight gradient
+_REAL_WIDTHS = [os.environ.get("GRL_REAL_WIDTHS", "1") != "0"]
+_F16_HANDOVER = [os.environ.get("GRL_F16_HANDOVER", "1") != "0"]     # linear layers: fp16 operand copies for the weight gradient
 
 
 @torch.library.custom_op("grl::linear", mutates_args=())

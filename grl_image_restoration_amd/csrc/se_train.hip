@@ -178,7 +178,7 @@ extern "C" int grl_se_mlp_fwd(void* stream, const GrlSeMlpArgs* args) {
 extern "C" int grl_se_mlp_bwd(void* stream, const GrlSeMlpArgs* args) {
     const GrlSeMlpArgs& p = *args;
     if (!se_args_ok(p) || !p.d_gate || !p.d_pool || !p.d_w1 || !p.d_b1 || !p.d_w2 || !p.d_b2) return GRL_ERR_BAD_ARG;
-    if (p.reserved0) hipLaunchKernelGGL(se_mlp_bwd_kernel<true>, dim3(p.B), dim3(SE_T), 0, (hipStream_t)stream, p);   // parallel: zeroed outputs
+    if (p.parallel) hipLaunchKernelGGL(se_mlp_bwd_kernel<true>, dim3(p.B), dim3(SE_T), 0, (hipStream_t)stream, p);   // parallel: zeroed outputs
     else hipLaunchKernelGGL(se_mlp_bwd_kernel<false>, dim3(1), dim3(SE_T), 0, (hipStream_t)stream, p);
     GRL_CHECK_LAUNCH();
     return 0;

@@ -1045,7 +1045,7 @@ def se_mlp_bwd(d_gate: torch.Tensor, pool: torch.Tensor, gate: torch.Tensor, hid
     d_w2, d_b2 = flat[n1 + n2 : 2 * n1 + n2].view(C_, Cmid), flat[2 * n1 + n2 :]
     args = L.GrlSeMlpArgs(pool=_ptr(pl), w1=_ptr(w1c), w2=_ptr(w2c), gate=_ptr(gate), hidden=_ptr(hidden), d_gate=_ptr(dg), d_pool=_ptr(d_pool),
                           d_w1=_ptr(d_w1), d_b1=_ptr(d_b1), d_w2=_ptr(d_w2), d_b2=_ptr(d_b2), B=B, C=C_, Cmid=Cmid,
-                          b1=_ptr(d_b1), b2=_ptr(d_b2), reserved0=int(par))     # (b1 / b2 are not read by the backward kernel; non-null for the argument check)
+                          b1=_ptr(d_b1), b2=_ptr(d_b2), parallel=int(par))     # (b1 / b2 are not read by the backward kernel; non-null for the argument check)
     L.check(L.lib().grl_se_mlp_bwd(L.stream_ptr(), C.byref(args)), "grl_se_mlp_bwd")
     return d_pool, d_w1, d_b1, d_w2, d_b2
 

@@ -467,6 +467,7 @@ typedef struct GrlGemmTnArgs {
     /* column N / K of a row -- and the bias gradient without a ones column in memory:                                          */
     int32_t b_ones;         /* != 0: b has a VIRTUAL column K that holds 1.0 (taps = 9: inside the image); its products, the   */
     int32_t reserved0;      /* column sums of a, go to c_bias[n] (taps = 9: of the centre tap) instead of a column of c         */
+                            /* (reserved0: ignored -- the entry point uses the slot to tell the kernel its tile order)          */
     float* c_bias;          /* [N] fp32, zeroed by the caller (required with b_ones unless c_bias_fix)                          */
     int64_t* c_bias_fix;    /* [N], the deterministic counterpart (with c_fix)                                                  */
     int32_t a_dtype;        /* 0 / GRL_DT_F32: a is fp32 (the field `a`); GRL_DT_F16: a points at fp16 values that are ALREADY     */
@@ -608,7 +609,7 @@ int grl_head_planes_bwd(void* stream, const GrlPlanesArgs* args);
  *   replaces  ChannelAttention.attention[1..4]  models/common/mixed_attn_block.py:956-963  (Conv2d(C, C/r, 1) -> ReLU -> Conv2d(C/r, C, 1)
  *   -> Sigmoid on the pooled [B, C] means) and autograd through it.  C <= 256, Cmid <= 64; all arrays fp32, contiguous.
  * forward: hidden [B, Cmid] = relu(w1 pool + b1), gate [B, C] = sigmoid(w2 hidden + b2);  backward: d_pool [B, C] and the parameter
- * gradients d_w1 [Cmid, C], d_b1 [Cmid], d_w2 [C, Cmid], d_b2 [C] (see reserved0). */
+ * gradients d_w1 [Cmid, C], d_b1 [Cmid], d_w2 [C, Cmid], d_b2 [C] (see `parallel`). */
 typedef struct GrlSeMlpArgs {
     const float* pool;       /* [B, C] */
     const float* w1;         /* [Cmid, C] */
@@ -624,7 +625,7 @@ typedef struct GrlSeMlpArgs {
     float* d_w2;
     float* d_b2;
     int32_t B, C, Cmid;
-    int32_t reserved0;       /* backward: != 0 ("parallel") one workgroup per image that ADDS the parameter gradients with atomics into  */
+    int32_t parallel;        /* backward: != 0: one workgroup per image that ADDS the parameter gradients with atomics into              */
                              /* arrays the caller zeroed; 0: one workgroup walks the batch and writes them (bit-reproducible, serial)    */
 } GrlSeMlpArgs;
 
