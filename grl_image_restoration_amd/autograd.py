@@ -90,6 +90,7 @@ class GradScaleTop(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        ops.zero_arena_begin(dy.device)          # (the backward pass starts here: one zero fill for its accumulation buffers)
         if _State.frozen:
             return dy
         amax = float(dy.abs().max())

@@ -51,6 +51,54 @@ def deterministic() -> bool:
     return os.environ.get("GRL_DETERMINISTIC", "0") == "1"
 
 
+# ---- one zero fill per backward pass -----------------------------------------------------------------------------------------
+# The backward wrappers need ~700 small zeroed fp32 buffers per training step -- the destinations of atomics: weight gradients (the M
+# slabs of grl_gemm_tn), bias-table gradients, replicated column sums -- and a fill launch each was 2 ms of a 90-ms captured step.  They
+# are cut from ONE arena that is zeroed by one launch when the backward pass starts (autograd.GradScaleTop.backward calls
+# zero_arena_begin): sized by what the previous pass used; a pass that needs more falls back to torch.zeros for the rest and the next
+# arena is larger.  The slices become gradients (``.grad`` of the parameters): the arena lives as long as any of them.
+# GRL_ZERO_ARENA=0: torch.zeros per buffer.
+_ARENA: dict = {}            # device index -> [buffer, next free element, elements requested in this pass, autograd graph-task id]
+_ARENA_SIZE: dict = {}       # device index -> elements the last complete pass requested
+_ARENA_ON = os.environ.get("GRL_ZERO_ARENA", "1") != "0"
+
+
+def _graph_task() -> int:
+    """Id of the autograd backward pass this thread is executing (-1: none)."""
+    f = getattr(torch._C, "_current_graph_task_id", None)
+    return f() if f is not None else -1
+
+
+def zero_arena_begin(device) -> None:
+    """Start of a backward pass on ``device``: one zeroed arena for its small accumulation buffers (scoped to THIS pass by the
+    autograd graph-task id: a request from anywhere else -- a forward pass, a direct call, another backward -- gets torch.zeros)."""
+    task = _graph_task()
+    if not _ARENA_ON or device.type != "cuda" or task < 0:
+        return
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    prev = _ARENA.get(idx)
+    if prev is not None:
+        _ARENA_SIZE[idx] = max(prev[2], 1)
+    n = _ARENA_SIZE.get(idx, 0)
+    buf = torch.zeros(n + n // 8 + 1024, dtype=torch.float32, device=device) if n > 0 else None
+    _ARENA[idx] = [buf, 0, 0, task]
+
+
+def zeros_f32(n: int, device) -> torch.Tensor:
+    """A zeroed fp32 vector of n elements (16-byte aligned): a slice of the running backward pass's arena when there is room, else
+    torch.zeros."""
+    if _ARENA_ON and device.type == "cuda":
+        a = _ARENA.get(device.index if device.index is not None else torch.cuda.current_device())
+        if a is not None and a[3] == _graph_task():
+            n4 = (n + 3) // 4 * 4
+            a[2] += n4
+            if a[0] is not None and a[1] + n4 <= a[0].numel():
+                out = a[0][a[1] : a[1] + n]
+                a[1] += n4
+                return out
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 def empty(*shape, dtype, device) -> torch.Tensor:
     return _poison(torch.empty(*shape, dtype=dtype, device=device))
 
@@ -795,7 +843,8 @@ def gemm_tn(a: torch.Tensor, b: torch.Tensor, N: int, K: int, *, taps: int = 1, 
     H, W = hw if hw is not None else (0, 0)
     det = deterministic()
     # one zeroed buffer for the taps and -- behind them -- the bias sums (a second fill per weight gradient otherwise)
-    buf = torch.zeros(taps * N * K + (N if b_ones else 0), dtype=torch.int64 if det else torch.float32, device=a.device)
+    nbuf = taps * N * K + (N if b_ones else 0)
+    buf = torch.zeros(nbuf, dtype=torch.int64, device=a.device) if det else zeros_f32(nbuf, a.device)
     c = buf[: taps * N * K].view(taps, N, K)
     cb = buf[taps * N * K :] if b_ones else None
     kcols = K + (1 if b_ones else 0)
@@ -839,7 +888,7 @@ def attention_bwd(q: TokenGrid, k: TokenGrid, v: TokenGrid, o: TokenGrid, d_o: t
     d_q = empty(q.t.shape, dtype=torch.float32, device=q.t.device)
     d_k = empty(k.t.shape, dtype=torch.float32, device=q.t.device)
     d_v = empty(v.t.shape, dtype=torch.float32, device=q.t.device)
-    d_table = torch.zeros_like(table)
+    d_table = zeros_f32(table.numel(), table.device).view(table.shape)
     fix = torch.zeros(table.shape, dtype=torch.int64, device=table.device) if deterministic() else None
     fwd = _attn_args(q, k, v, o, B, nh, table, masked, ones_col, head_dim, False, None, lse)
     args = L.GrlAttnBwdArgs(fwd=fwd, d_o=_ptr(d_o), d_q=_ptr(d_q), d_k=_ptr(d_k), d_v=_ptr(d_v), d_table=_ptr(d_table), g_scale=g_scale,
@@ -876,7 +925,7 @@ def cpb_table_bwd(coords: torch.Tensor, w1: torch.Tensor, b1: torch.Tensor, w2: 
     rows, rows4 = coords.shape[0], d_out.shape[2]
     assert d_out.shape == (G, nh, rows4) and d_out.dtype == torch.float32
     cs, a, b, c, g = (t.detach().float().contiguous() for t in (coords, w1, b1, w2, d_out))
-    d_w1, d_b1, d_w2 = torch.zeros_like(a), torch.zeros_like(b), torch.zeros_like(c)
+    d_w1, d_b1, d_w2 = (zeros_f32(t.numel(), t.device).view(t.shape) for t in (a, b, c))
     args = L.GrlCpbArgs(coords=_ptr(cs), w1=_ptr(a), b1=_ptr(b), w2=_ptr(c), d_out=_ptr(g), d_w1=_ptr(d_w1), d_b1=_ptr(d_b1), d_w2=_ptr(d_w2),
                         G=G, rows=rows, rows4=rows4, nh=nh, hidden=hid)
     with _timed("cpb_table_bwd"):
@@ -921,7 +970,7 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, mean: torch.Tensor, rstd: t
     # dgamma | dbeta in STAT_REPLICAS copies (one fill), summed afterwards: 2048 workgroups adding into the same 2 n addresses serialise
     # at ~36 ns per atomic -- 75 us of a kernel whose rows stream in 20
     R = STAT_REPLICAS if M >= 4096 else 1
-    dgb = torch.zeros(2, R, n, dtype=torch.float32, device=x.device)
+    dgb = zeros_f32(2 * R * n, x.device).view(2, R, n)
     args = L.GrlLnTrainArgs(x=_ptr(x), ldx=x.stride(0), gamma=_ptr(g), mean=_ptr(mean), rstd=_ptr(rstd), dy=_ptr(dy), lddy=dy.stride(0),
                             dx=_ptr(dx), lddx=n, dgamma=_ptr(dgb[0]), dbeta=_ptr(dgb[1]), M=M, n=n, eps=0.0,
                             row_scale=_ptr(row_scale), rows_per_image=rows_per_image, alpha=alpha, stat_replicas=R)
@@ -969,7 +1018,7 @@ def head_planes_bwd(x: torch.Tensor, scale: torch.Tensor, src, raw, one_cols, gr
     gs = [None if g is None else g.float().contiguous() for g in grads]
     dx = empty(x.shape, dtype=torch.float32, device=x.device)
     R = STAT_REPLICAS if x.shape[0] >= 4096 else 1          # (replicas of the scale-gradient sums: see layernorm_bwd)
-    dscale = torch.zeros(R, S_out, x.shape[2], dtype=torch.float32, device=x.device)
+    dscale = zeros_f32(R * S_out * x.shape[2], x.device).view(R, S_out, x.shape[2])
     args = _planes_args(x, scale, src, raw, one_cols, want_dscale)
     args.dscale_replicas = R
     for s_, g in enumerate(gs):
@@ -1040,7 +1089,7 @@ def se_mlp_bwd(d_gate: torch.Tensor, pool: torch.Tensor, gate: torch.Tensor, hid
     d_pool = empty(B, C_, dtype=torch.float32, device=dev)
     par = not deterministic()          # one workgroup per image + atomics into ONE zeroed buffer (else: one workgroup walks the batch)
     n1, n2 = Cmid * C_, Cmid
-    flat = torch.zeros(2 * n1 + n2 + C_, dtype=torch.float32, device=dev) if par else empty(2 * n1 + n2 + C_, dtype=torch.float32, device=dev)
+    flat = zeros_f32(2 * n1 + n2 + C_, dev) if par else empty(2 * n1 + n2 + C_, dtype=torch.float32, device=dev)
     d_w1, d_b1 = flat[:n1].view(Cmid, C_), flat[n1 : n1 + n2]
     d_w2, d_b2 = flat[n1 + n2 : 2 * n1 + n2].view(C_, Cmid), flat[2 * n1 + n2 :]
     args = L.GrlSeMlpArgs(pool=_ptr(pl), w1=_ptr(w1c), w2=_ptr(w2c), gate=_ptr(gate), hidden=_ptr(hidden), d_gate=_ptr(dg), d_pool=_ptr(d_pool),
@@ -1059,7 +1108,7 @@ def se_colsum(a: torch.Tensor, rows_per_image: int, k: float = 1.0, f: Optional[
     _dev_check(a, f)
     M, C_ = a.shape
     assert _rows_ok(a) and (f is None or (_rows_ok(f) and f.shape == a.shape)) and C_ % 4 == 0 and C_ <= 256 and M % rows_per_image == 0
-    out = torch.zeros(M // rows_per_image, C_, dtype=torch.float32, device=a.device)
+    out = zeros_f32((M // rows_per_image) * C_, a.device).view(M // rows_per_image, C_)
     args = L.GrlSeRowsArgs(a=_ptr(a), lda=a.stride(0), f=_ptr(f), ldf=f.stride(0) if f is not None else 0, out=_ptr(out), ldo=C_, k=k,
                            M=M, C=C_, rows_per_image=rows_per_image)
     L.check(L.lib().grl_se_colsum(L.stream_ptr(), C.byref(args)), "grl_se_colsum")

@@ -1,10 +1,2 @@
-Q="--no-cpu-baseline --no-train --no-other-scales --no-precision-legs --no-traffic --steps 30 --warmup 5"
-run() { echo "== $1"; env $1 python bench.py $Q 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print(d['ms_per_step'])"; }
-run "GRL_X=0"
-run "GRL_CONV_KC=32"
-run "GRL_SPLIT_STREAMS=1"
-run "GRL_SPLIT_STREAMS=3"
-run "GRL_SPLIT_STREAMS=4"
-run "GRL_X=0"
-python bench.py $Q --tiles 16 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tiles16', d['ms_per_step'], d['value'])"
-python bench.py $Q --tiles 12 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('tiles12', d['ms_per_step'], d['value'])"
+timeout 900 python -m pytest -q -m gpu tests/test_gpu_train.py tests/test_gpu_train_step.py tests/test_gpu_train_graph.py tests/test_gpu_train_replicas.py -x 2>&1 | grep "passed\|failed\|Error" | tail -3
+for t in 0 1 0 1; do echo "ZERO_ARENA=$t"; GRL_ZERO_ARENA=$t timeout 200 python tools/train_steps.py --graph --steps 20 2>&1 | grep "graphed:"; done
