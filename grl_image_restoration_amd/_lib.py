@@ -44,6 +44,7 @@ EXPORTS = [
     "grl_layernorm_bwd",
     "grl_pack_conv3x3",
     "grl_pack_linear",
+    "grl_sum4",
     "grl_se_mlp_fwd",
     "grl_se_mlp_bwd",
     "grl_se_colsum",
@@ -558,6 +559,8 @@ def lib():
     L.grl_pack_conv3x3.restype = C.c_int
     L.grl_pack_linear.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32]
     L.grl_pack_linear.restype = C.c_int
+    L.grl_sum4.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64]
+    L.grl_sum4.restype = C.c_int
     L.grl_se_mlp_fwd.argtypes = [C.c_void_p, C.POINTER(GrlSeMlpArgs)]
     L.grl_se_mlp_fwd.restype = C.c_int
     L.grl_se_mlp_bwd.argtypes = [C.c_void_p, C.POINTER(GrlSeMlpArgs)]

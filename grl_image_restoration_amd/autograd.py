@@ -637,6 +637,34 @@ def layer_norm(x, gamma, beta, eps: float = 1e-5):
     return F.layer_norm(x, (n,), gamma, beta, eps)
 
 
+class FanOut(torch.autograd.Function):
+    """n aliases of x for n consumers; the backward pass adds their gradients in ONE launch (ops.sum_tensors) where autograd would add
+    them pairwise as they arrive."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.set_materialize_grads(False)
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        gs = [g for g in gs if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = ops.sum_tensors(gs[:4])
+        for g in gs[4:]:
+            out = out + g
+        return out, None
+
+
+def fan_out(x, n: int):
+    if x.is_cuda and x.requires_grad and os.environ.get("GRL_FAN_OUT", "1") != "0":
+        return FanOut.apply(x, n)
+    return (x,) * n
+
+
 class PadGradMask(torch.autograd.Function):
     """Identity forward (a view, no launch); the gradient is multiplied by ``mask`` (broadcast over the last dimension).  For a tensor
     whose pad columns already hold the constants its consumer wants -- the anchors -> stripe attention output used as the values of the

@@ -182,6 +182,32 @@ extern "C" int grl_pack_linear(void* stream, const float* w, const float* b, voi
     return 0;
 }
 
+// out = a + b (+ c) (+ d) on flat fp32 arrays (16-byte aligned, n a multiple of 4): the gradient of a tensor with several consumers in ONE
+// pass -- autograd adds the contributions pairwise as they arrive (a block's input feeds the QKV projection, the anchor pooling, the CAB
+// and the residual: three launches of 71 MB each for what one launch of 118 MB does).
+namespace {
+__global__ __launch_bounds__(256) void sum4_kernel(const float4* __restrict__ a, const float4* __restrict__ b, const float4* __restrict__ c,
+                                                   const float4* __restrict__ d, float4* __restrict__ out, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (int64_t)gridDim.x * 256) {
+        float4 s = a[i];
+        const float4 t = b[i];
+        s.x += t.x; s.y += t.y; s.z += t.z; s.w += t.w;
+        if (c != nullptr) { const float4 u = c[i]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+        if (d != nullptr) { const float4 u = d[i]; s.x += u.x; s.y += u.y; s.z += u.z; s.w += u.w; }
+        out[i] = s;
+    }
+}
+}  // namespace
+
+extern "C" int grl_sum4(void* stream, const float* a, const float* b, const float* c, const float* d, float* out, int64_t n) {
+    if (!a || !b || !out || n <= 0 || (n & 3) || (((uintptr_t)a | (uintptr_t)b | (uintptr_t)c | (uintptr_t)d | (uintptr_t)out) & 15)) return GRL_ERR_BAD_ARG;
+    const int64_t n4 = n >> 2, wgs = (n4 + 255) / 256;
+    hipLaunchKernelGGL(sum4_kernel, dim3((unsigned)(wgs < 4096 ? wgs : 4096)), dim3(256), 0, (hipStream_t)stream, (const float4*)a, (const float4*)b,
+                       (const float4*)c, (const float4*)d, (float4*)out, n4);
+    GRL_CHECK_LAUNCH();
+    return 0;
+}
+
 // Debug aid (GRL_DIRTY_LDS=1 in the Python wrappers calls it before every C-ABI launch): overwrites the LDS of every CU with
 // 0xFF bytes (fp32 / fp16 NaN).  LDS is not cleared between workgroups, so a kernel that reads a location it has not written sees
 // whatever the previous workgroup on that CU left there -- zeros or finite numbers most of the time, which hides the bug and makes

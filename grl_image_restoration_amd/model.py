@@ -1143,13 +1143,15 @@ class GRL(nn.Module):
         Ha, Wa = H // df, W // df
         a = blk.attn
         dev = r.device
-        qkv = AG.linear(r, a.qkv.body.weight, a.qkv.body.bias)                                 # QKVProjection (mixed_attn_block.py:669-676)
-        pooled = r.view(B, Ha, df, Wa, df, C).mean(dim=(2, 4)).reshape(B * Ha * Wa, C)          # AnchorLinear avg-pool (:727-736)
+        # (r has four consumers -- QKV projection, anchor pooling, the CAB, the residual: their gradients are added in one launch)
+        r_q, r_p, r_c, r = AG.fan_out(r, 4)
+        qkv = AG.linear(r_q, a.qkv.body.weight, a.qkv.body.bias)                               # QKVProjection (mixed_attn_block.py:669-676)
+        pooled = r_p.view(B, Ha, df, Wa, df, C).mean(dim=(2, 4)).reshape(B * Ha * Wa, C)        # AnchorLinear avg-pool (:727-736)
         anc = AG.linear(pooled, a.anchor.body[0].reduction.weight, a.anchor.body[0].reduction.bias).view(-1, nh_s, d_s)
         same = (nh_w, d_w) == (nh_s, d_s) and os.environ.get("GRL_TRAIN_BATCHED_PLANES", "1") != "0"
         if same:
             att = self._attention_train_batched(qkv, anc, a, geo, B, H, W, pre)
-            return self._block_train_tail(r, att, blk, B, H, W, dp)
+            return self._block_train_tail(r, att, blk, B, H, W, dp, r_c)
         if (nh_w, d_w) == (nh_s, d_s):   # one view, one unbind: the backward is a single stack instead of two slice-backwards (zeros + copy) and an add
             qw, kw, vw, qs, ks, vs = qkv.view(M, 6, nh_w, d_w).unbind(1)
         else:
@@ -1265,7 +1267,7 @@ class GRL(nn.Module):
             return torch.cat([ow, os_], dim=1)                          # [M, 2 * nh * 32]
         return torch.cat([ow, os_], dim=0).permute(1, 0, 2)[..., :d].reshape(M, C)
 
-    def _block_train_tail(self, r, att, blk: _Block, B, H, W, dp: float):
+    def _block_train_tail(self, r, att, blk: _Block, B, H, W, dp: float, r_conv=None):
         """proj + norm1 + residual, CAB, MLP + norm2 + residual of a block (efficient.py:543-556) on token matrices."""
         C = self.embed_dim
         M = B * H * W
@@ -1288,7 +1290,7 @@ class GRL(nn.Module):
         x1 = self._norm_residual(r, x1, blk.norm1, H * W, dp)
         if self.local_connection:   # CAB + ChannelAttention (mixed_attn_block.py:948-983)
             c0, c2, se = blk.conv.cab[0], blk.conv.cab[2], blk.conv.cab[3].attention
-            u = AG.conv3x3(F.gelu(AG.conv3x3(r, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
+            u = AG.conv3x3(F.gelu(AG.conv3x3(r if r_conv is None else r_conv, c0.weight, c0.bias, B, H, W)), c2.weight, c2.bias, B, H, W)
             # x1 + u * gate(u): pool, squeeze-excite MLP and the gated residual as three launches each way (autograd.se_residual)
             x1 = AG.se_residual(x1, u, se[1].weight.flatten(1), se[1].bias, se[3].weight.flatten(1), se[3].bias, H * W)
         # Mlp (swin_v1_block.py:37-43): the GELU between fc1 and fc2 is taken by fc2's loader, its adjoint by the epilogue of fc2's

@@ -1128,3 +1128,20 @@ def se_apply(a: torch.Tensor, g: torch.Tensor, rows_per_image: int, f: Optional[
                            ldo=C_, k=k, M=M, C=C_, rows_per_image=rows_per_image)
     L.check(L.lib().grl_se_apply(L.stream_ptr(), C.byref(args)), "grl_se_apply")
     return out
+
+
+def sum_tensors(ts) -> torch.Tensor:
+    """grl_sum4: the sum of 2 .. 4 fp32 tensors of one shape in one launch (contiguous copies are made of inputs that are not)."""
+    ts = [t.float().contiguous() for t in ts]
+    _dev_check(*ts)
+    assert 2 <= len(ts) <= 4 and all(t.shape == ts[0].shape for t in ts)
+    n = ts[0].numel()
+    if n % 4 or any(t.data_ptr() % 16 for t in ts):
+        out = ts[0] + ts[1]
+        for t in ts[2:]:
+            out = out + t
+        return out
+    out = empty(ts[0].shape, dtype=torch.float32, device=ts[0].device)
+    p = [_ptr(t) for t in ts] + [None] * (4 - len(ts))
+    L.check(L.lib().grl_sum4(L.stream_ptr(), p[0], p[1], p[2], p[3], _ptr(out), n), "grl_sum4")
+    return out

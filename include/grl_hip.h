@@ -580,6 +580,11 @@ int grl_pack_conv3x3(void* stream, const float* w, const float* b, void* out_w, 
 int grl_pack_linear(void* stream, const float* w, const float* b, void* out_w, void* out_wt, float* out_b, int32_t N, int32_t K, int32_t Np,
                     int32_t Kp);
 
+/* out[i] = a[i] + b[i] (+ c[i]) (+ d[i]) on flat fp32 arrays (ABI 22; 16-byte aligned, n a multiple of 4; c, d optional): the gradient of a
+ * tensor with several consumers in one launch (a block's input x feeds QKVProjection, AnchorLinear, the CAB and the residual:
+ * mixed_attn_block_efficient.py:539-556) instead of autograd's pairwise adds. */
+int grl_sum4(void* stream, const float* a, const float* b, const float* c, const float* d, float* out, int64_t n);
+
 /* Head planes of the training path (ABI 21): projection output x [T, S_in, nh, d] (fp32) -> the attention operands, fp32 planes
  * out32 [S_out][nh][T][32] and their fp16 copy out16, forward; dx and the scale gradients, backward.
  *   replaces F.normalize(q) * exp(min(logit_scale, ln 100)), F.normalize(k) and the head reshape / permute of

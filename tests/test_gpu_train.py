@@ -536,3 +536,18 @@ def test_linear_with_gelu_input_matches_torch(M, K, N):
     assert _rel(y, ref.detach()) < 2e-3
     y.backward(dy.cuda())
     assert _rel(xd.grad, xr.grad) < 5e-3 and _rel(wd.grad, wr.grad) < 5e-3 and _rel(bd.grad, br.grad) < 2e-3
+
+
+def test_fan_out_adds_the_consumers_gradients_in_one_launch():
+    """autograd.fan_out: n aliases forward, grl_sum4 backward -- against autograd's own pairwise accumulation (2, 3 and 4 live consumers)."""
+    from grl_image_restoration_amd import autograd as AG
+
+    g = torch.Generator().manual_seed(54)
+    x0 = torch.randn(1000, 180, generator=g).cuda()
+    ws = [torch.randn(1000, 180, generator=g).cuda() for _ in range(4)]
+    for live in (2, 3, 4):
+        x = x0.clone().requires_grad_(True)
+        parts = AG.fan_out(x, 4)
+        sum((p * w).sum() for p, w in zip(parts[:live], ws)).backward()
+        ref = sum(ws[:live])
+        assert torch.allclose(x.grad, ref, rtol=0, atol=1e-6)
